@@ -1,0 +1,55 @@
+/* exact_math_check.c -- host check of rtl-wmbus_amd/csrc/wm_exact.h against this image's libm
+ * (glibc 2.35), bit for bit, on the discriminator's operand domain.  Built and run by
+ * tests/test_exact_math.py with gcc -O2 -ffp-contract=off.  argv[1] = number of random cases. */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include "../rtl-wmbus_amd/csrc/wm_exact.h"
+
+static uint64_t s = 0x1234567887654321ull;
+static uint64_t rnd(void) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; }
+
+static long check(float im, float re)
+{
+    const float a = atan2f(im, re), b = wm_atan2f(im, re);
+    if (wm_f2u(a) != wm_f2u(b)) {
+        static int shown;
+        if (shown++ < 10) printf("MISMATCH atan2f(%a,%a): libm %a ours %a\n", im, re, a, b);
+        return 1;
+    }
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    const long n = argc > 1 ? atol(argv[1]) : 10000000;
+    long bad = 0, tot = 0;
+    /* exhaustive small grid, both scalings (k/8 and k/16 operands) */
+    for (int sc = 64; sc <= 256; sc *= 4)
+        for (int y = -300; y <= 300; y++)
+            for (int x = -300; x <= 300; x++) { bad += check((float)y / sc, (float)x / sc); tot++; }
+    /* signed zeros */
+    const float z[2] = {0.0f, -0.0f};
+    for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) { bad += check(z[a], z[b]); tot++;
+        bad += check(z[a], 3.5f); bad += check(z[a], -3.5f); bad += check(2.25f, z[b]); bad += check(-2.25f, z[b]); tot += 4; }
+    /* random operands exactly as the discriminator forms them */
+    for (long k = 0; k < n; k++) {
+        const uint64_t r = rnd(), r2 = rnd();
+        const int lim = (k & 1) ? 2880 : 1016;            /* S1 (k/16) vs T1/C1 (k/8) numerators */
+        const float sc = (k & 1) ? 16.0f : 8.0f;
+        int v[4];
+        for (int j = 0; j < 4; j++) {
+            int amp = (int)((r2 >> (8 * j)) & 0xFF) < 64 ? 12 : lim;  /* mix of weak and strong */
+            v[j] = (int)((r >> (16 * j)) & 0xFFFF) % (2 * amp + 1) - amp;
+        }
+        const float i = v[0] / sc, q = v[1] / sc, pi_ = v[2] / sc, pq_ = v[3] / sc;
+        const float c = pi_, d = -pq_;
+        const float re = i * c - q * d, im = i * d + q * c;
+        bad += check(im, re); tot++;
+        /* whole discriminator vs the reference's expression cargf(y)*(float)M_1_PI */
+        const float ref = atan2f(im, re) * (float)M_1_PI;
+        if (wm_f2u(ref) != wm_f2u(wm_discriminator(i, q, pi_, pq_))) bad++;
+    }
+    printf("checked %ld cases, %ld mismatches\n", tot, bad);
+    return bad != 0;
+}

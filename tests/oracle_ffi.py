@@ -1,0 +1,151 @@
+"""ctypes bindings for oracle/libwmbus_oracle.so and the reference binary (TEST INFRASTRUCTURE).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "libwmbus_oracle.so")
+ORACLE_CLI = os.path.join(ORACLE_DIR, "wmbus_oracle_cli")
+REF_BIN = os.path.join(ORACLE_DIR, "_ref", "rtl_wmbus")
+REF_PROBE = os.path.join(ORACLE_DIR, "_ref", "ref_probe")
+
+_TS = re.compile(rb"[0-9]{4}-[0-9]{2}-[0-9]{2} [0-9:.]+")
+
+
+def build(ref=True):
+    """make -C oracle (restatement always; reference binaries when /root/reference exists)."""
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR, "oracle"] + (["ref"] if ref else []), check=True)
+
+
+class Opts(ctypes.Structure):
+    _fields_ = [("decimation", ctypes.c_uint), ("simultaneous", ctypes.c_int),
+                ("accurate_atan", ctypes.c_int), ("remove_dc", ctypes.c_int),
+                ("t1c1_enabled", ctypes.c_int), ("s1_enabled", ctypes.c_int),
+                ("rla_enabled", ctypes.c_int), ("time2_enabled", ctypes.c_int),
+                ("show_algorithm", ctypes.c_int), ("fixed_timestamp", ctypes.c_int)]
+
+
+class Chip(ctypes.Structure):
+    _fields_ = [("sample", ctypes.c_uint32), ("chain", ctypes.c_uint8), ("algo", ctypes.c_uint8),
+                ("value", ctypes.c_uint8), ("rssi", ctypes.c_uint8)]
+
+
+CHIP_DTYPE = np.dtype([("sample", "<u4"), ("chain", "u1"), ("algo", "u1"), ("value", "u1"), ("rssi", "u1")])
+
+
+class Taps(ctypes.Structure):
+    _fields_ = [("cap", ctypes.c_size_t), ("iq", ctypes.c_void_p * 2), ("dphi_raw", ctypes.c_void_p * 2),
+                ("dphi", ctypes.c_void_p * 2), ("rssi", ctypes.c_void_p * 2), ("clk", ctypes.c_void_p * 2),
+                ("bit", ctypes.c_void_p * 2), ("chips", ctypes.c_void_p), ("chips_cap", ctypes.c_size_t),
+                ("chips_len", ctypes.c_size_t)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(ORACLE_SO):
+            build(ref=os.path.exists("/root/reference/rtl_wmbus.c"))
+        L = ctypes.CDLL(ORACLE_SO)
+        L.wmo_default_opts.argtypes = [ctypes.POINTER(Opts)]
+        L.wmo_new.restype = ctypes.c_void_p
+        L.wmo_new.argtypes = [ctypes.POINTER(Opts)]
+        L.wmo_free.argtypes = [ctypes.c_void_p]
+        L.wmo_set_taps.argtypes = [ctypes.c_void_p, ctypes.POINTER(Taps)]
+        L.wmo_feed.restype = ctypes.c_size_t
+        L.wmo_feed.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+        L.wmo_output.restype = ctypes.c_void_p
+        L.wmo_output.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]
+        L.wmo_decimated_count.restype = ctypes.c_uint64
+        L.wmo_decimated_count.argtypes = [ctypes.c_void_p]
+        _lib = L
+    return _lib
+
+
+def make_opts(decimation=2, simultaneous=0, accurate_atan=1, remove_dc=0, t1c1=1, s1=1, rla=1,
+              time2=1, show_algorithm=1):
+    o = Opts()
+    lib().wmo_default_opts(ctypes.byref(o))
+    o.decimation, o.simultaneous, o.accurate_atan, o.remove_dc = decimation, simultaneous, accurate_atan, remove_dc
+    o.t1c1_enabled, o.s1_enabled, o.rla_enabled, o.time2_enabled = t1c1, s1, rla, time2
+    o.show_algorithm, o.fixed_timestamp = show_algorithm, 1
+    return o
+
+
+def opts_to_argv(o):
+    """The reference/oracle CLI switches equivalent to an Opts."""
+    a = []
+    if o.remove_dc: a.append("-o")
+    if not o.accurate_atan: a.append("-a")
+    if o.decimation != 2: a += ["-d", str(o.decimation)]
+    if not o.t1c1_enabled: a += ["-p", "T"]
+    if not o.s1_enabled: a += ["-p", "S"]
+    if not o.rla_enabled: a += ["-r", "0"]
+    if not o.time2_enabled: a += ["-t", "0"]
+    if o.show_algorithm: a.append("-v")
+    if o.simultaneous: a.append("-s")
+    return a
+
+
+def run(cu8, opts, taps=False, chips=False):
+    """Run the restatement over a cu8 array.  Returns dict(text=..., m=..., taps...)."""
+    L = lib()
+    cu8 = np.ascontiguousarray(cu8, dtype=np.uint8)
+    ctx = L.wmo_new(ctypes.byref(opts))
+    out = {}
+    keep = []
+    t = Taps()
+    m_cap = cu8.size // 2 // max(1, opts.decimation) + 1
+    if taps or chips:
+        t.cap = m_cap
+        if taps:
+            for name, dt, mult in [("iq", np.float32, 2), ("dphi_raw", np.float32, 1), ("dphi", np.float32, 1),
+                                   ("rssi", np.float32, 1), ("clk", np.float32, 1), ("bit", np.uint8, 1)]:
+                arrs = [np.zeros(m_cap * mult, dt) for _ in range(2)]
+                keep.append(arrs)
+                out[name] = arrs
+                getattr(t, name)[0] = arrs[0].ctypes.data
+                getattr(t, name)[1] = arrs[1].ctypes.data
+        if chips:
+            ch = np.zeros(4 * m_cap, CHIP_DTYPE)
+            keep.append(ch)
+            t.chips = ch.ctypes.data
+            t.chips_cap = ch.size
+        L.wmo_set_taps(ctx, ctypes.byref(t))
+    L.wmo_feed(ctx, cu8.ctypes.data, cu8.size)
+    n = ctypes.c_size_t()
+    p = L.wmo_output(ctx, ctypes.byref(n))
+    out["text"] = ctypes.string_at(p, n.value).decode() if n.value else ""
+    out["m"] = int(L.wmo_decimated_count(ctx))
+    if taps:
+        for k in ("iq", "dphi_raw", "dphi", "rssi", "clk", "bit"):
+            mult = 2 if k == "iq" else 1
+            out[k] = [a[: out["m"] * mult] for a in out[k]]
+    if chips:
+        out["chips"] = ch[: t.chips_len].copy()
+    L.wmo_free(ctx)
+    return out
+
+
+def mask_ts(b):
+    return _TS.sub(b"TS", b)
+
+
+def run_reference(cu8, argv):
+    """The unmodified reference binary on the same bytes (timestamp field masked)."""
+    p = subprocess.run([REF_BIN] + list(argv), input=np.ascontiguousarray(cu8, np.uint8).tobytes(),
+                       capture_output=True, check=True)
+    return mask_ts(p.stdout).decode()
+
+
+def have_reference():
+    return os.path.exists(REF_BIN)
