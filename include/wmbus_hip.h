@@ -1,0 +1,132 @@
+/*
+ * wmbus_hip.h -- C ABI of libwmbus_hip.so, the MI355X (gfx950) back end for the rtl-wmbus
+ * cu8 -> datagram hot path.
+ *
+ * The reference (xaelsouth/rtl-wmbus) has no library interface: its boundary is the process
+ * (stdin cu8, argv switches, stdout lines) and, inside it, the per-sample loop of main()
+ * (/root/reference/rtl_wmbus.c:1298-1357) that drives t1_c1_signal_chain (:1038-1116) and
+ * s1_signal_chain (:1130-1208), which in turn call the packet decoders
+ * (t1_c1_packet_decoder.h:649-712, s1_packet_decoder.h:233-282).  This header is the seam a
+ * maintainer would bind instead of that loop; each entry point names what it replaces.
+ * INTEGRATION.md shows the replacement main() and the ctypes binding.
+ *
+ * Plain C, plain pointers and sizes, no C++/torch types.  All functions return 0 on success or
+ * a negative WMBUS_E* code; nothing in the library calls exit().  One context serves
+ * `n_streams` independent captures that advance in lock step (same byte count per push).
+ */
+#ifndef WMBUS_HIP_H
+#define WMBUS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WMBUS_BLOCK_BYTES 4096u   /* the reference consumes stdin in 4096-byte units (rtl_wmbus.c:1249,1301) */
+
+enum {
+    WMBUS_OK = 0,
+    WMBUS_EINVAL = -1,      /* bad argument / configuration                         */
+    WMBUS_ENOMEM = -2,      /* host or device allocation failed                     */
+    WMBUS_EDEVICE = -3,     /* HIP runtime error (see wmbus_last_error)             */
+    WMBUS_EOVERFLOW = -4,   /* a chip or window buffer overflowed (raise capacities) */
+    WMBUS_ENODEVICE = -5    /* no HIP device: this library has no CPU fallback      */
+};
+
+enum { WMBUS_CHAIN_T1C1 = 0, WMBUS_CHAIN_S1 = 1 };
+enum { WMBUS_ALGO_RLA = 0, WMBUS_ALGO_T2A = 1 };
+
+/* Mirrors the reference's switches (rtl_wmbus.c:855-866, parsed at :892-967). */
+typedef struct wmbus_cfg {
+    unsigned decimation;        /* -d N, default 2                                   */
+    int simultaneous;           /* -s                                                */
+    int accurate_atan;          /* 1 unless -a                                       */
+    int remove_dc;              /* -o                                                */
+    int t1c1_enabled;           /* 0 after -p T                                      */
+    int s1_enabled;             /* 0 after -p S                                      */
+    int rla_enabled;            /* 0 after -r 0                                      */
+    int time2_enabled;          /* 0 after -t 0                                      */
+    int show_algorithm;         /* -v                                                */
+    int fixed_timestamp;        /* 1: print "TS" instead of the wall clock (tests)   */
+    /* batch geometry */
+    unsigned n_streams;         /* independent captures processed per push           */
+    int device;                 /* HIP device ordinal                                */
+    size_t max_push_bytes;      /* capacity per stream per push, multiple of 4096    */
+    /* tuning (0 = default) */
+    unsigned seg_len;           /* decimated samples per time segment (<= 65536)     */
+    unsigned warmup_t1c1;       /* IIR warm-up before a segment, T1/C1 chain         */
+    unsigned warmup_s1;         /* IIR warm-up before a segment, S1 chain            */
+    unsigned rla_lookback;      /* speculative run-length lookback                   */
+    unsigned host_threads;      /* host decoder threads, 0 = auto                    */
+    int keep_taps;              /* 1: keep soft symbols readable via wmbus_read_tap  */
+} wmbus_cfg;
+
+typedef struct wmbus_ctx wmbus_ctx;
+
+/* One datagram line as the reference prints it (t1_c1_packet_decoder.h:671-699,
+ * s1_packet_decoder.h:248-269), plus the keys that define its place in stdout. */
+typedef struct wmbus_line {
+    uint32_t stream;
+    uint8_t  chain, algo, crc_ok, pad;
+    uint64_t sample;            /* global decimated-sample index of the completing chip */
+    uint32_t text_off, text_len;/* into the buffer returned by wmbus_lines_text()        */
+} wmbus_line;
+
+/* Per-push timings measured with HIP events on the library's own stream (ms). */
+typedef struct wmbus_timing {
+    float demod_ms;             /* front end + discriminator + FIR + RSSI kernel      */
+    float clock_ms;             /* IIR clock recovery + time2 framer (incl. re-runs)  */
+    float rla_ms;               /* run-length framer (incl. re-runs)                  */
+    float gather_ms;            /* burst extraction                                   */
+    float d2h_ms;               /* burst copy to pinned host memory                   */
+    float gpu_total_ms;         /* first kernel start -> last copy done               */
+    float host_decode_ms;       /* packet decoders + formatting (wall clock)          */
+    unsigned clock_reruns, rla_reruns, ema_retries;
+    uint64_t chips[2][2];       /* chips produced per chain/algo                      */
+    uint64_t bursts;            /* candidate bursts handed to the host decoders       */
+} wmbus_timing;
+
+void wmbus_default_cfg(wmbus_cfg *cfg);
+
+/* Replaces the state set-up at rtl_wmbus.c:1249-1273,1296 (framer/decoder resets, LUT). */
+int  wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out);
+void wmbus_close(wmbus_ctx *ctx);
+const char *wmbus_last_error(const wmbus_ctx *ctx);
+
+/* Replaces fread() at rtl_wmbus.c:1301: copy `nbytes` (multiple of 4096) of stream `stream`
+ * from host memory into the device input window of the next push. */
+int  wmbus_stage(wmbus_ctx *ctx, unsigned stream, const uint8_t *cu8, size_t nbytes);
+/* Same for HBM-resident producers: device address of the stream's input window. */
+void *wmbus_device_input(wmbus_ctx *ctx, unsigned stream);
+
+/* Replaces the sample loop rtl_wmbus.c:1310-1356 for `nbytes` staged bytes of every stream:
+ * launches the kernels (asynchronously on the context's stream). */
+int  wmbus_process(wmbus_ctx *ctx, size_t nbytes);
+/* Waits for the push, runs the host packet decoders, makes the lines available.  Lines are in
+ * the reference's stdout order within each stream, streams in ascending order. */
+int  wmbus_collect(wmbus_ctx *ctx);
+
+size_t wmbus_lines(const wmbus_ctx *ctx, const wmbus_line **lines);
+const char *wmbus_lines_text(const wmbus_ctx *ctx, size_t *len);
+
+int  wmbus_get_timing(const wmbus_ctx *ctx, wmbus_timing *t);
+
+/* Debug taps of the last push (requires cfg.keep_taps): what = "dphi" (f32), "rssi" (u8),
+ * "bits" (u8 0/1).  Returns the number of elements written, or a negative error. */
+long wmbus_read_tap(wmbus_ctx *ctx, const char *what, int chain, unsigned stream,
+                    void *dst, size_t max_elems);
+/* All chips of the last push for one stream/chain/algo as u32 words
+ * [31:16] offset-in-segment, [15:8] rssi, [7:0] value (bit0 data, bit1 sync, bit2 framer reset
+ * before this chip); `pos` (optional) receives the global decimated-sample index per chip. */
+long wmbus_read_chips(wmbus_ctx *ctx, int chain, int algo, unsigned stream,
+                      uint32_t *dst, uint64_t *pos, size_t max_elems);
+
+/* Number of visible HIP devices (0 if none). */
+int  wmbus_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WMBUS_HIP_H */

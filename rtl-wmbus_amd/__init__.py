@@ -1,0 +1,273 @@
+"""rtl-wmbus_amd -- MI355X-native back end for the rtl-wmbus cu8 -> datagram hot path.
+
+Thin ctypes mirror of the C ABI in include/wmbus_hip.h (libwmbus_hip.so: hand-written HIP kernels
+for gfx950 + host packet decoders).  The directory name contains a hyphen, so import it with
+
+    import importlib; wm = importlib.import_module("rtl-wmbus_amd")
+
+There is no CPU fallback: opening a receiver without a HIP device raises WmbusError.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libwmbus_hip.so")
+SYNTH_PATH = os.path.join(HERE, "libwmbus_synth.so")
+CLI_PATH = os.path.join(HERE, "rtl_wmbus_hip")
+
+CHAIN_T1C1, CHAIN_S1 = 0, 1
+ALGO_RLA, ALGO_T2A = 0, 1
+BLOCK_BYTES = 4096
+
+
+class WmbusError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile every native target for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.run(["make", "-s", "-C", HERE, "clean"], check=True)
+    subprocess.run(["make", "-s", "-C", HERE], check=True)
+
+
+class Cfg(ctypes.Structure):
+    _fields_ = [("decimation", ctypes.c_uint), ("simultaneous", ctypes.c_int), ("accurate_atan", ctypes.c_int),
+                ("remove_dc", ctypes.c_int), ("t1c1_enabled", ctypes.c_int), ("s1_enabled", ctypes.c_int),
+                ("rla_enabled", ctypes.c_int), ("time2_enabled", ctypes.c_int), ("show_algorithm", ctypes.c_int),
+                ("fixed_timestamp", ctypes.c_int), ("n_streams", ctypes.c_uint), ("device", ctypes.c_int),
+                ("max_push_bytes", ctypes.c_size_t), ("seg_len", ctypes.c_uint), ("warmup_t1c1", ctypes.c_uint),
+                ("warmup_s1", ctypes.c_uint), ("rla_lookback", ctypes.c_uint), ("host_threads", ctypes.c_uint),
+                ("keep_taps", ctypes.c_int)]
+
+
+class Line(ctypes.Structure):
+    _fields_ = [("stream", ctypes.c_uint32), ("chain", ctypes.c_uint8), ("algo", ctypes.c_uint8),
+                ("crc_ok", ctypes.c_uint8), ("pad", ctypes.c_uint8), ("sample", ctypes.c_uint64),
+                ("text_off", ctypes.c_uint32), ("text_len", ctypes.c_uint32)]
+
+
+class Timing(ctypes.Structure):
+    _fields_ = [("demod_ms", ctypes.c_float), ("clock_ms", ctypes.c_float), ("rla_ms", ctypes.c_float),
+                ("gather_ms", ctypes.c_float), ("d2h_ms", ctypes.c_float), ("gpu_total_ms", ctypes.c_float),
+                ("host_decode_ms", ctypes.c_float), ("clock_reruns", ctypes.c_uint), ("rla_reruns", ctypes.c_uint),
+                ("ema_retries", ctypes.c_uint), ("chips", (ctypes.c_uint64 * 2) * 2), ("bursts", ctypes.c_uint64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k in ("demod_ms", "clock_ms", "rla_ms", "gather_ms", "d2h_ms", "gpu_total_ms",
+                                              "host_decode_ms", "clock_reruns", "rla_reruns", "bursts")}
+
+
+EXPORTS = ["wmbus_default_cfg", "wmbus_open", "wmbus_close", "wmbus_last_error", "wmbus_stage", "wmbus_device_input",
+           "wmbus_process", "wmbus_collect", "wmbus_lines", "wmbus_lines_text", "wmbus_get_timing", "wmbus_read_tap",
+           "wmbus_read_chips", "wmbus_device_count"]
+
+_lib = None
+
+
+def lib():
+    """Load libwmbus_hip.so (fails loudly if it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise WmbusError(f"{LIB_PATH} is missing: run __graft_entry__.build() / make -C rtl-wmbus_amd")
+        L = ctypes.CDLL(LIB_PATH)
+        vp, u, sz = ctypes.c_void_p, ctypes.c_uint, ctypes.c_size_t
+        L.wmbus_default_cfg.argtypes = [ctypes.POINTER(Cfg)]
+        L.wmbus_open.argtypes = [ctypes.POINTER(Cfg), ctypes.POINTER(vp)]
+        L.wmbus_close.argtypes = [vp]
+        L.wmbus_last_error.argtypes = [vp]; L.wmbus_last_error.restype = ctypes.c_char_p
+        L.wmbus_stage.argtypes = [vp, u, vp, sz]
+        L.wmbus_device_input.argtypes = [vp, u]; L.wmbus_device_input.restype = vp
+        L.wmbus_process.argtypes = [vp, sz]
+        L.wmbus_collect.argtypes = [vp]
+        L.wmbus_lines.argtypes = [vp, ctypes.POINTER(ctypes.POINTER(Line))]; L.wmbus_lines.restype = sz
+        L.wmbus_lines_text.argtypes = [vp, ctypes.POINTER(sz)]; L.wmbus_lines_text.restype = vp
+        L.wmbus_get_timing.argtypes = [vp, ctypes.POINTER(Timing)]
+        L.wmbus_read_tap.argtypes = [vp, ctypes.c_char_p, ctypes.c_int, u, vp, sz]; L.wmbus_read_tap.restype = ctypes.c_long
+        L.wmbus_read_chips.argtypes = [vp, ctypes.c_int, ctypes.c_int, u, vp, vp, sz]; L.wmbus_read_chips.restype = ctypes.c_long
+        L.wmbus_device_count.restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def device_count():
+    return int(lib().wmbus_device_count())
+
+
+class Receiver:
+    """`n_streams` captures through the GPU back end, in lock step.
+
+    Keyword arguments mirror the reference's switches: decimation (-d), simultaneous (-s),
+    accurate_atan (not -a), remove_dc (-o), t1c1 / s1 (not -p T / -p S), rla (-r), time2 (-t),
+    show_algorithm (-v).
+    """
+
+    def __init__(self, n_streams=1, max_push_bytes=4 << 20, decimation=2, simultaneous=False, accurate_atan=True,
+                 remove_dc=False, t1c1=True, s1=True, rla=True, time2=True, show_algorithm=True, device=0,
+                 seg_len=0, warmup_t1c1=0, warmup_s1=0, rla_lookback=0, host_threads=0, fixed_timestamp=True):
+        L = lib()
+        c = Cfg()
+        L.wmbus_default_cfg(ctypes.byref(c))
+        c.decimation, c.simultaneous, c.accurate_atan, c.remove_dc = decimation, int(simultaneous), int(accurate_atan), int(remove_dc)
+        c.t1c1_enabled, c.s1_enabled, c.rla_enabled, c.time2_enabled = int(t1c1), int(s1), int(rla), int(time2)
+        c.show_algorithm, c.fixed_timestamp = int(show_algorithm), int(fixed_timestamp)
+        c.n_streams, c.device, c.max_push_bytes = n_streams, device, max_push_bytes
+        c.seg_len, c.warmup_t1c1, c.warmup_s1, c.rla_lookback, c.host_threads = seg_len, warmup_t1c1, warmup_s1, rla_lookback, host_threads
+        c.keep_taps = 1
+        self.cfg = c
+        self.n_streams = n_streams
+        self._h = ctypes.c_void_p()
+        rc = L.wmbus_open(ctypes.byref(c), ctypes.byref(self._h))
+        if rc:
+            msg = L.wmbus_last_error(self._h).decode() if self._h else "allocation failed"
+            L.wmbus_close(self._h)
+            self._h = None
+            raise WmbusError(f"wmbus_open failed ({rc}): {msg}")
+
+    def close(self):
+        if self._h:
+            lib().wmbus_close(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc):
+        if rc:
+            raise WmbusError(f"error {rc}: {lib().wmbus_last_error(self._h).decode()}")
+
+    def device_input(self, stream):
+        return lib().wmbus_device_input(self._h, stream)
+
+    def stage(self, stream, cu8):
+        cu8 = np.ascontiguousarray(cu8, dtype=np.uint8)
+        self._chk(lib().wmbus_stage(self._h, stream, cu8.ctypes.data, cu8.size))
+
+    def process(self, nbytes):
+        self._chk(lib().wmbus_process(self._h, nbytes))
+
+    def collect(self):
+        """Returns the datagram text of the push, streams in order, reference stdout order within."""
+        L = lib()
+        self._chk(L.wmbus_collect(self._h))
+        n = ctypes.c_size_t()
+        p = L.wmbus_lines_text(self._h, ctypes.byref(n))
+        return ctypes.string_at(p, n.value).decode() if n.value else ""
+
+    def lines(self):
+        L = lib()
+        p = ctypes.POINTER(Line)()
+        n = L.wmbus_lines(self._h, ctypes.byref(p))
+        sz = ctypes.c_size_t()
+        t = L.wmbus_lines_text(self._h, ctypes.byref(sz))
+        text = ctypes.string_at(t, sz.value) if sz.value else b""
+        return [dict(stream=p[i].stream, chain=p[i].chain, algo=p[i].algo, crc_ok=p[i].crc_ok, sample=p[i].sample,
+                     text=text[p[i].text_off:p[i].text_off + p[i].text_len].decode()) for i in range(n)]
+
+    def timing(self):
+        t = Timing()
+        self._chk(lib().wmbus_get_timing(self._h, ctypes.byref(t)))
+        return t.as_dict()
+
+    def push(self, streams):
+        """Stage one equally long cu8 array per stream, process, decode; returns the text."""
+        n = None
+        for s, a in enumerate(streams):
+            a = np.ascontiguousarray(a, dtype=np.uint8)
+            n = a.size if n is None else n
+            assert a.size == n and n % BLOCK_BYTES == 0
+            self.stage(s, a)
+        self.process(n)
+        return self.collect()
+
+    def run(self, cu8, push_bytes=None):
+        """Whole capture(s) through the receiver in pushes of `push_bytes`; partial tail dropped
+        like the reference does at EOF (rtl_wmbus.c:1304-1308).  cu8: one array or a list."""
+        streams = [cu8] if isinstance(cu8, np.ndarray) and cu8.ndim == 1 else list(cu8)
+        streams = [np.ascontiguousarray(a, dtype=np.uint8) for a in streams]
+        total = streams[0].size // BLOCK_BYTES * BLOCK_BYTES
+        step = push_bytes or self.cfg.max_push_bytes
+        per_stream = [[] for _ in streams]
+        for off in range(0, total, step):
+            n = min(step, total - off)
+            self.push([a[off:off + n] for a in streams])
+            for ln in self.lines():
+                per_stream[ln["stream"]].append(ln["text"])
+        return ["".join(x) for x in per_stream]
+
+    def read_tap(self, what, chain, stream, n):
+        dt = np.float32 if what == "dphi" else np.uint8
+        out = np.zeros(n, dt)
+        r = lib().wmbus_read_tap(self._h, what.encode(), chain, stream, out.ctypes.data, n)
+        if r < 0:
+            raise WmbusError(f"read_tap({what}) failed: {r}")
+        return out[:r]
+
+    def read_chips(self, chain, algo, stream, cap=1 << 22):
+        w = np.zeros(cap, np.uint32)
+        pos = np.zeros(cap, np.uint64)
+        r = lib().wmbus_read_chips(self._h, chain, algo, stream, w.ctypes.data, pos.ctypes.data, cap)
+        if r < 0:
+            raise WmbusError(f"read_chips failed: {r}")
+        if r > cap:
+            raise WmbusError("read_chips: capacity too small")
+        return w[:r], pos[:r]
+
+
+# ---- synthetic captures (host-only helper library) -------------------------------------------------
+class SynthCfg(ctypes.Structure):
+    _fields_ = [("seed", ctypes.c_uint64), ("fs_khz", ctypes.c_uint), ("noise_sigma", ctypes.c_double),
+                ("amplitude", ctypes.c_double), ("frames_per_s", ctypes.c_double), ("kinds", ctypes.c_uint),
+                ("l_min", ctypes.c_int), ("l_max", ctypes.c_int), ("t1c1_center_khz", ctypes.c_double),
+                ("s1_center_khz", ctypes.c_double), ("max_offset_khz", ctypes.c_double)]
+
+
+class SynthFrame(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_uint32), ("n_samples", ctypes.c_uint32), ("start_sample", ctypes.c_uint64),
+                ("len", ctypes.c_uint16), ("complete", ctypes.c_uint8), ("pad", ctypes.c_uint8),
+                ("telegram", ctypes.c_uint8 * 256)]
+
+
+T1, C1A, C1B, S1 = 1, 2, 4, 8
+_synth = None
+
+
+def _synth_lib():
+    global _synth
+    if _synth is None:
+        if not os.path.exists(SYNTH_PATH):
+            raise WmbusError(f"{SYNTH_PATH} is missing: run make -C rtl-wmbus_amd")
+        L = ctypes.CDLL(SYNTH_PATH)
+        L.wmsynth_default_cfg.argtypes = [ctypes.POINTER(SynthCfg)]
+        L.wmsynth_generate.restype = ctypes.c_size_t
+        L.wmsynth_generate.argtypes = [ctypes.POINTER(SynthCfg), ctypes.c_void_p, ctypes.c_size_t,
+                                       ctypes.POINTER(SynthFrame), ctypes.c_size_t]
+        _synth = L
+    return _synth
+
+
+def synth_capture(seed, n_samples, fs_khz=1600, kinds=T1 | C1A | C1B, frames_per_s=20.0, amplitude=60.0,
+                  noise_sigma=3.0, t1c1_center_khz=0.0, s1_center_khz=0.0, l_min=10, l_max=60, out=None,
+                  max_frames=1024):
+    """SURVEY.md section 8(d) recipe.  Returns (cu8 uint8[2*n_samples], [frame dicts])."""
+    L = _synth_lib()
+    c = SynthCfg()
+    L.wmsynth_default_cfg(ctypes.byref(c))
+    c.seed, c.fs_khz, c.kinds, c.frames_per_s = seed, fs_khz, kinds, frames_per_s
+    c.amplitude, c.noise_sigma, c.t1c1_center_khz, c.s1_center_khz = amplitude, noise_sigma, t1c1_center_khz, s1_center_khz
+    c.l_min, c.l_max = l_min, l_max
+    buf = out if out is not None else np.empty(2 * n_samples, np.uint8)
+    fr = (SynthFrame * max_frames)()
+    k = L.wmsynth_generate(ctypes.byref(c), buf.ctypes.data, n_samples, fr, max_frames)
+    frames = [dict(kind=fr[i].kind, start=fr[i].start_sample, n=fr[i].n_samples, complete=bool(fr[i].complete),
+                   telegram=bytes(fr[i].telegram[:fr[i].len])) for i in range(min(k, max_frames))]
+    return buf, frames

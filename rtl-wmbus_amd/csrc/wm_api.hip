@@ -1,0 +1,607 @@
+/*
+ * wm_api.hip -- host pipeline behind the C ABI of include/wmbus_hip.h.
+ *
+ * One context owns one HIP stream, the HBM-resident buffers of wm_dev.h, pinned host staging
+ * for bursts, and the persistent host packet decoders (4 per capture: chain x framer).
+ * There is NO CPU fallback: without a HIP device wmbus_open() fails with WMBUS_ENODEVICE.
+ */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/wmbus_hip.h"
+#include "wm_decoder.h"
+#include "wm_dev.h"
+#include "wm_kernels.hip"
+
+namespace {
+
+struct LineRec {
+    uint64_t sample; uint32_t stream; uint8_t chain, algo, crc_ok; uint32_t seq; std::string text;
+};
+
+struct HostDecoder {           /* persistent across pushes */
+    wm_decoder dec;
+    uint32_t owed;             /* chips to request at the start of the next push */
+};
+
+}  // namespace
+
+struct wmbus_ctx {
+    wmbus_cfg cfg{};
+    char err[256] = {0};
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8] = {};
+    /* geometry */
+    uint32_t d = 2, S = 1, C = 65536, Mcap = 0, nseg_cap = 0, ntiles_cap = 0, RF = 8;
+    uint32_t cap_t2 = 0, cap_rl = 0, flags = 0;
+    uint64_t in_stride = 0, n0 = 0;
+    size_t staged = 0;
+    /* device buffers */
+    uint8_t *d_in = nullptr; float *d_dphi = nullptr; uint8_t *d_rssi = nullptr; uint32_t *d_bits = nullptr;
+    float *d_lut = nullptr;
+    float *d_ema_head = nullptr, *d_ema_tail = nullptr, *d_ema_carry = nullptr;
+    uint32_t *d_chips[2] = {}, *d_counts[2] = {};
+    void *d_st_start[2] = {}, *d_st_final[2] = {}, *d_st_carry[2] = {};
+    uint32_t *d_list = nullptr, *d_scalars = nullptr;   /* scalars: err, n_list, n_hits, n_hdr, n_words */
+    uint2 *d_hits = nullptr; uint32_t hits_cap = 0;
+    uint32_t *d_pending = nullptr;
+    WmBurstHdr *d_hdr = nullptr; uint32_t hdr_cap = 0;
+    uint32_t *d_words = nullptr; uint32_t words_cap = 0;
+    /* host */
+    uint32_t *h_scalars = nullptr;                      /* pinned */
+    WmBurstHdr *h_hdr = nullptr; uint32_t *h_words = nullptr; uint32_t *h_pending = nullptr;
+    uint32_t n_hdr = 0, n_words = 0;
+    std::vector<HostDecoder> decs;                      /* [stream][chain][algo] */
+    std::vector<wmbus_line> lines; std::string text;
+    WmPush last{}; bool have_last = false, in_flight = false;
+    wmbus_timing tim{};
+};
+
+namespace {
+
+int fail(wmbus_ctx *c, int code, const char *fmt, ...)
+{
+    va_list ap; va_start(ap, fmt);
+    vsnprintf(c->err, sizeof c->err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
+    return fail((c), WMBUS_EDEVICE, "%s: %s", #call, hipGetErrorString(e_)); } while (0)
+
+template <typename T> hipError_t dalloc(T **p, size_t n) { return hipMalloc((void **)p, n * sizeof(T)); }
+
+enum { SC_ERR = 0, SC_NLIST = 1, SC_NHITS = 2, SC_NHDR = 3, SC_NWORDS = 4, SC_COUNT = 8 };
+
+__global__ void k_roll_history(uint8_t *in, uint64_t stride, uint32_t nbytes)
+{
+    /* new history = the 4096 bytes that end at the end of the staged data */
+    uint8_t *row = in + (uint64_t)blockIdx.x * stride;
+    const uint4 v = *(const uint4 *)(row + nbytes + 16u * threadIdx.x);
+    __syncthreads();
+    *(uint4 *)(row + 16u * threadIdx.x) = v;
+}
+
+__global__ void k_fill(uint8_t *p, uint64_t stride, uint32_t n, uint8_t v)
+{
+    uint8_t *row = p + (uint64_t)blockIdx.x * stride;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) row[i] = v;
+}
+
+__global__ void k_carry(const uint32_t *fin, uint32_t *carry, uint32_t words, uint32_t rows, uint32_t nseg_cap, uint32_t nseg)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    for (uint32_t k = 0; k < words; k++) carry[(uint64_t)r * words + k] = fin[((uint64_t)r * nseg_cap + nseg - 1) * words + k];
+}
+
+template <int RF> size_t k1_smem(uint32_t d, bool shift)
+{
+    constexpr int T = 256 * RF, NA = T + WM_K1_HALO;
+    const size_t stage = ((size_t)(NA * d + 16 + 8 + 7) / 8 * 8 + 4) * 4 * (shift ? 2 : 1);
+    const size_t y = (size_t)(NA + 8) * 4 * 4 + 512 * 4;
+    return std::max(stage, y) + 64;
+}
+
+template <int RF> int launch_k1(wmbus_ctx *c, const K1Args &a, uint32_t ntiles)
+{
+    const bool shift = c->flags & WM_F_SHIFT;
+    const size_t sm = k1_smem<RF>(c->d, shift);
+    dim3 grid(ntiles, c->S);
+    if (shift) {
+        HIPCHK(c, hipFuncSetAttribute((const void *)k1_demod<RF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+        hipLaunchKernelGGL((k1_demod<RF, true>), grid, dim3(256), sm, c->stream, a);
+    } else {
+        HIPCHK(c, hipFuncSetAttribute((const void *)k1_demod<RF, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+        hipLaunchKernelGGL((k1_demod<RF, false>), grid, dim3(256), sm, c->stream, a);
+    }
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+double now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+extern "C" {
+
+void wmbus_default_cfg(wmbus_cfg *cfg)
+{
+    memset(cfg, 0, sizeof *cfg);
+    cfg->decimation = 2; cfg->accurate_atan = 1; cfg->t1c1_enabled = 1; cfg->s1_enabled = 1;
+    cfg->rla_enabled = 1; cfg->time2_enabled = 1; cfg->n_streams = 1;
+    cfg->max_push_bytes = 4u << 20;
+}
+
+int wmbus_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *wmbus_last_error(const wmbus_ctx *ctx) { return ctx ? ctx->err : "null context"; }
+
+void wmbus_close(wmbus_ctx *c)
+{
+    if (!c) return;
+    if (c->stream) hipStreamSynchronize(c->stream);
+    void *dev[] = {c->d_in, c->d_dphi, c->d_rssi, c->d_bits, c->d_lut, c->d_ema_head, c->d_ema_tail, c->d_ema_carry,
+                   c->d_chips[0], c->d_chips[1], c->d_counts[0], c->d_counts[1], c->d_st_start[0], c->d_st_start[1],
+                   c->d_st_final[0], c->d_st_final[1], c->d_st_carry[0], c->d_st_carry[1], c->d_list, c->d_scalars,
+                   c->d_hits, c->d_pending, c->d_hdr, c->d_words};
+    for (void *p : dev) if (p) hipFree(p);
+    void *host[] = {c->h_scalars, c->h_hdr, c->h_words, c->h_pending};
+    for (void *p : host) if (p) hipHostFree(p);
+    for (auto &e : c->ev) if (e) hipEventDestroy(e);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
+{
+    if (!cfg || !out) return WMBUS_EINVAL;
+    *out = nullptr;
+    wmbus_ctx *c = new wmbus_ctx();
+    c->cfg = *cfg;
+    auto bail = [&](int code) { *out = c; return code; };   /* caller reads the message, then closes */
+
+    if (cfg->decimation < 1 || cfg->decimation > WM_MAX_DECIM) return bail(fail(c, WMBUS_EINVAL, "decimation must be 1..%u", WM_MAX_DECIM));
+    if (cfg->n_streams < 1) return bail(fail(c, WMBUS_EINVAL, "n_streams must be >= 1"));
+    if (cfg->max_push_bytes < WMBUS_BLOCK_BYTES || cfg->max_push_bytes % WMBUS_BLOCK_BYTES)
+        return bail(fail(c, WMBUS_EINVAL, "max_push_bytes must be a positive multiple of 4096"));
+    if (wmbus_device_count() <= cfg->device) return bail(fail(c, WMBUS_ENODEVICE, "no HIP device %d (this library has no CPU fallback)", cfg->device));
+    if (hipSetDevice(cfg->device) != hipSuccess) return bail(fail(c, WMBUS_EDEVICE, "hipSetDevice(%d) failed", cfg->device));
+
+    c->d = cfg->decimation; c->S = cfg->n_streams;
+    c->C = cfg->seg_len ? cfg->seg_len : 65536u;
+    if (c->C < 1024u || c->C > 65536u || (c->C & (c->C - 1))) return bail(fail(c, WMBUS_EINVAL, "seg_len must be a power of two in [1024, 65536]"));
+    c->cfg.warmup_t1c1 = cfg->warmup_t1c1 ? (cfg->warmup_t1c1 + 3u) & ~3u : 24576u;
+    c->cfg.warmup_s1 = cfg->warmup_s1 ? (cfg->warmup_s1 + 3u) & ~3u : 49152u;
+    c->cfg.rla_lookback = cfg->rla_lookback ? cfg->rla_lookback : 1024u;
+    c->flags = (cfg->simultaneous ? WM_F_SHIFT : 0) | (cfg->accurate_atan ? WM_F_ACCURATE : 0) | (cfg->remove_dc ? WM_F_DC : 0) |
+               (cfg->t1c1_enabled ? WM_F_T1C1 : 0) | (cfg->s1_enabled ? WM_F_S1 : 0) | (cfg->rla_enabled ? WM_F_RLA : 0) |
+               (cfg->time2_enabled ? WM_F_T2A : 0);
+    /* tile: 2048 decimated samples up to d = 2, fewer for larger d so the staging fits in LDS */
+    c->RF = c->d <= 2 ? 8 : c->d <= 5 ? 4 : 2;
+    const uint32_t T = 256 * c->RF;
+    const uint64_t max_samples = cfg->max_push_bytes / 2;
+    c->Mcap = (uint32_t)(((max_samples / c->d + 1 + 8) + 127) / 128 * 128);
+    c->Mcap = (c->Mcap + T - 1) / T * T;                 /* whole tiles: partial tiles still store full runs */
+    c->nseg_cap = (c->Mcap + c->C - 1) / c->C;
+    c->ntiles_cap = c->Mcap / T;
+    c->cap_t2 = c->C / 4 + 8; c->cap_rl = c->C / 2 + 8;
+    c->in_stride = (WM_HIST_BYTES + cfg->max_push_bytes + WM_IN_SLACK + 255) / 256 * 256;
+
+    const uint64_t rows = 2ull * c->S;
+    hipError_t e = hipSuccess;
+    auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+    A(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (auto &ev : c->ev) A(hipEventCreate(&ev));
+    A(dalloc(&c->d_in, (size_t)c->in_stride * c->S));
+    A(dalloc(&c->d_dphi, (size_t)rows * c->Mcap));
+    A(dalloc(&c->d_rssi, (size_t)rows * c->Mcap));
+    A(dalloc(&c->d_bits, (size_t)rows * (c->Mcap / 32)));
+    A(dalloc(&c->d_lut, (size_t)2 * 32 * WM_MAX_DECIM));
+    A(dalloc(&c->d_ema_head, (size_t)rows * c->ntiles_cap));
+    A(dalloc(&c->d_ema_tail, (size_t)rows * c->ntiles_cap));
+    A(dalloc(&c->d_ema_carry, (size_t)rows));
+    const size_t caps[2] = {c->cap_rl, c->cap_t2};
+    const size_t stw[2] = {sizeof(WmRlaState), sizeof(WmClkState)};
+    for (int a = 0; a < 2; a++) {
+        A(dalloc(&c->d_chips[a], (size_t)rows * c->nseg_cap * caps[a]));
+        A(dalloc(&c->d_counts[a], (size_t)rows * c->nseg_cap));
+        A(hipMalloc(&c->d_st_start[a], (size_t)rows * c->nseg_cap * stw[a]));
+        A(hipMalloc(&c->d_st_final[a], (size_t)rows * c->nseg_cap * stw[a]));
+        A(hipMalloc(&c->d_st_carry[a], (size_t)rows * stw[a]));
+    }
+    A(dalloc(&c->d_list, (size_t)rows * c->nseg_cap));
+    A(dalloc(&c->d_scalars, (size_t)SC_COUNT));
+    const uint64_t dec_total = (uint64_t)c->S * c->Mcap;
+    c->hdr_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(65536, dec_total / 1024), 1u << 24);
+    c->hits_cap = c->hdr_cap;
+    c->words_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1u << 20, dec_total / 8), 1u << 29);
+    A(dalloc(&c->d_hits, (size_t)c->hits_cap));
+    A(dalloc(&c->d_pending, (size_t)4 * c->S));
+    A(dalloc(&c->d_hdr, (size_t)c->hdr_cap));
+    A(dalloc(&c->d_words, (size_t)c->words_cap));
+    A(hipHostMalloc((void **)&c->h_scalars, SC_COUNT * sizeof(uint32_t)));
+    A(hipHostMalloc((void **)&c->h_hdr, (size_t)c->hdr_cap * sizeof(WmBurstHdr)));
+    A(hipHostMalloc((void **)&c->h_words, (size_t)c->words_cap * sizeof(uint32_t)));
+    A(hipHostMalloc((void **)&c->h_pending, (size_t)4 * c->S * sizeof(uint32_t)));
+    if (e != hipSuccess) return bail(fail(c, e == hipErrorOutOfMemory ? WMBUS_ENOMEM : WMBUS_EDEVICE, "allocation failed: %s", hipGetErrorString(e)));
+
+    /* initial state = the reference's zero-initialised statics */
+    A(hipMemsetAsync(c->d_ema_carry, 0, rows * sizeof(float), c->stream));
+    A(hipMemsetAsync(c->d_st_carry[1], 0, rows * sizeof(WmClkState), c->stream));
+    {
+        std::vector<WmRlaState> init(rows, WmRlaState{0, 8 * 256, 0, 0u, 0u, 0u, 24, 24});   /* rtl_wmbus.c:628-637,717-726 */
+        A(hipMemcpyAsync(c->d_st_carry[0], init.data(), rows * sizeof(WmRlaState), hipMemcpyHostToDevice, c->stream));
+        A(hipStreamSynchronize(c->stream));
+    }
+    A(hipMemsetAsync(c->d_scalars, 0, SC_COUNT * sizeof(uint32_t), c->stream));
+    A(hipMemsetAsync(c->d_pending, 0, 4 * c->S * sizeof(uint32_t), c->stream));
+    hipLaunchKernelGGL(k_fill, dim3(c->S), dim3(256), 0, c->stream, c->d_in, c->in_stride, (uint32_t)c->in_stride, (uint8_t)128);
+    /* frequency-translation LUT, built with the host libm exactly like rtl_wmbus.c:974-993 */
+    {
+        const int fs_khz = (int)c->d * 800;
+        const size_t n_max = (size_t)(fs_khz / 25);
+        std::vector<float> lut(2 * 32 * WM_MAX_DECIM, 0.f);
+        for (size_t n = 0; n < n_max; n++) {
+            const double phi = (2. * M_PI * (25 * (double)n)) / fs_khz;
+            lut[n] = cosf(phi);
+            lut[32 * WM_MAX_DECIM + n] = -sinf(phi);
+        }
+        A(hipMemcpyAsync(c->d_lut, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        A(hipStreamSynchronize(c->stream));
+    }
+    if (e != hipSuccess) return bail(fail(c, WMBUS_EDEVICE, "initialisation failed: %s", hipGetErrorString(e)));
+
+    c->decs.resize((size_t)c->S * 4);
+    for (uint32_t s = 0; s < c->S; s++)
+        for (int ch = 0; ch < 2; ch++)
+            for (int al = 0; al < 2; al++) {
+                HostDecoder &hd = c->decs[((size_t)s * 2 + ch) * 2 + al];
+                wm_decoder_init(&hd.dec, ch ? WM_MODE_S1 : WM_MODE_T1C1);
+                hd.owed = 0;
+            }
+    *out = c;
+    return WMBUS_OK;
+}
+
+void *wmbus_device_input(wmbus_ctx *c, unsigned stream)
+{
+    if (!c || stream >= c->S) return nullptr;
+    return c->d_in + (size_t)stream * c->in_stride + WM_HIST_BYTES;
+}
+
+int wmbus_stage(wmbus_ctx *c, unsigned stream, const uint8_t *cu8, size_t nbytes)
+{
+    if (!c || stream >= c->S || !cu8) return WMBUS_EINVAL;
+    if (nbytes > c->cfg.max_push_bytes || nbytes % WMBUS_BLOCK_BYTES) return fail(c, WMBUS_EINVAL, "stage: nbytes must be a multiple of 4096 and <= max_push_bytes");
+    HIPCHK(c, hipMemcpyAsync(wmbus_device_input(c, stream), cu8, nbytes, hipMemcpyHostToDevice, c->stream));
+    return WMBUS_OK;
+}
+
+static int run_segments(wmbus_ctx *c, int algo, K2Args a, float *ms, unsigned *reruns)
+{
+    const WmPush &g = a.g;
+    const uint32_t lanes = 2u * g.nseg * g.S;
+    const uint32_t words = (algo == WMBUS_ALGO_RLA ? sizeof(WmRlaState) : sizeof(WmClkState)) / 4;
+    auto launch = [&](const uint32_t *list, uint32_t n) {
+        a.list = list; a.n_lanes = n;
+        if (algo == WMBUS_ALGO_RLA) hipLaunchKernelGGL(k2_rla, dim3((n + 63) / 64), dim3(64), 0, c->stream, a);
+        else hipLaunchKernelGGL(k2_clock, dim3((n + 63) / 64), dim3(64), 0, c->stream, a);
+    };
+    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    launch(nullptr, lanes);
+    for (unsigned round = 0;; round++) {
+        HIPCHK(c, hipMemsetAsync(c->d_scalars + SC_NLIST, 0, sizeof(uint32_t), c->stream));
+        hipLaunchKernelGGL(k2_verify, dim3((lanes + 255) / 256), dim3(256), 0, c->stream, g,
+                           (const uint32_t *)a.st_start, (const uint32_t *)a.st_final, words, c->d_list, c->d_scalars + SC_NLIST);
+        HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, SC_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        const uint32_t n = c->h_scalars[SC_NLIST];
+        if (n == 0) break;
+        if (round > g.nseg + 1) return fail(c, WMBUS_EDEVICE, "segment verification did not converge");
+        *reruns += n;
+        launch(c->d_list, n);
+    }
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev[1]));
+    HIPCHK(c, hipEventElapsedTime(ms, c->ev[0], c->ev[1]));
+    /* carry the exact end state into the next push */
+    const uint32_t rows = 2u * g.S;
+    hipLaunchKernelGGL(k_carry, dim3((rows + 255) / 256), dim3(256), 0, c->stream, (const uint32_t *)a.st_final,
+                       (uint32_t *)a.st_carry, words, rows, g.nseg_cap, g.nseg);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+int wmbus_process(wmbus_ctx *c, size_t nbytes)
+{
+    if (!c) return WMBUS_EINVAL;
+    if (nbytes == 0 || nbytes > c->cfg.max_push_bytes || nbytes % WMBUS_BLOCK_BYTES)
+        return fail(c, WMBUS_EINVAL, "process: nbytes must be a positive multiple of 4096 and <= max_push_bytes");
+    if (c->in_flight) return fail(c, WMBUS_EINVAL, "process: previous push not collected");
+    c->tim = wmbus_timing{};
+    const uint32_t n_new = (uint32_t)(nbytes / 2);
+    WmPush g{};
+    g.in = c->d_in; g.in_stride = c->in_stride; g.n0 = c->n0; g.m0 = c->n0 / c->d;
+    g.n_new = n_new; g.M = (uint32_t)((c->n0 + n_new) / c->d - g.m0);
+    g.Mcap = c->Mcap; g.d = c->d; g.S = c->S; g.lut_n = 32 * c->d;
+    g.lut_phase0 = (uint32_t)((13ull * (c->n0 % g.lut_n)) % g.lut_n);
+    g.flags = c->flags; g.seg_len = c->C; g.nseg = (g.M + c->C - 1) / c->C; g.nseg_cap = c->nseg_cap;
+    g.warm[0] = c->cfg.warmup_t1c1; g.warm[1] = c->cfg.warmup_s1; g.lookback = c->cfg.rla_lookback;
+    g.cap_t2 = c->cap_t2; g.cap_rl = c->cap_rl;
+    c->last = g; c->have_last = true;
+    c->n_hdr = c->n_words = 0;
+
+    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    if (g.M > 0) {
+        HIPCHK(c, hipMemsetAsync(c->d_scalars, 0, SC_COUNT * sizeof(uint32_t), c->stream));
+        /* K1 */
+        const uint32_t T = 256 * c->RF, ntiles = (g.M + T - 1) / T;
+        K1Args k1{g, c->d_dphi, c->d_rssi, c->d_lut, c->d_lut + 32 * WM_MAX_DECIM, c->d_ema_head, c->d_ema_tail, ntiles, c->d_scalars + SC_ERR};
+        HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+        int rc = c->RF == 8 ? launch_k1<8>(c, k1, ntiles) : c->RF == 4 ? launch_k1<4>(c, k1, ntiles) : launch_k1<2>(c, k1, ntiles);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k1_verify, dim3((2 * c->S + 63) / 64), dim3(64), 0, c->stream, c->d_ema_head, c->d_ema_tail,
+                           c->d_ema_carry, ntiles, 2 * c->S, c->d_scalars + SC_ERR);
+        HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+
+        /* K2: clock recovery + time2 framer (also produces the slicer bits the RLA needs) */
+        K2Args k2{};
+        k2.g = g; k2.dphi = c->d_dphi; k2.rssi = c->d_rssi; k2.bits = c->d_bits;
+        k2.hits = c->d_hits; k2.n_hits = c->d_scalars + SC_NHITS; k2.hits_cap = c->hits_cap; k2.err = c->d_scalars + SC_ERR;
+        {
+            K2Args a = k2; a.algo = WMBUS_ALGO_T2A;
+            a.chips = c->d_chips[1]; a.counts = c->d_counts[1];
+            a.st_start = c->d_st_start[1]; a.st_final = c->d_st_final[1]; a.st_carry = c->d_st_carry[1];
+            rc = run_segments(c, WMBUS_ALGO_T2A, a, &c->tim.clock_ms, &c->tim.clock_reruns);
+            if (rc) return rc;
+        }
+        if (c->flags & WM_F_RLA) {
+            K2Args a = k2; a.algo = WMBUS_ALGO_RLA;
+            a.chips = c->d_chips[0]; a.counts = c->d_counts[0];
+            a.st_start = c->d_st_start[0]; a.st_final = c->d_st_final[0]; a.st_carry = c->d_st_carry[0];
+            rc = run_segments(c, WMBUS_ALGO_RLA, a, &c->tim.rla_ms, &c->tim.rla_reruns);
+            if (rc) return rc;
+        } else {
+            HIPCHK(c, hipMemsetAsync(c->d_counts[0], 0, (size_t)2 * c->S * c->nseg_cap * sizeof(uint32_t), c->stream));
+        }
+
+        /* K3: bursts */
+        HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, SC_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        const uint32_t n_hits = std::min(c->h_scalars[SC_NHITS], c->hits_cap);
+        for (uint32_t s = 0; s < c->S; s++)
+            for (int ch = 0; ch < 2; ch++)
+                for (int al = 0; al < 2; al++)
+                    c->h_pending[(al * 2 + ch) * c->S + s] = c->decs[((size_t)s * 2 + ch) * 2 + al].owed;
+        HIPCHK(c, hipMemcpyAsync(c->d_pending, c->h_pending, 4 * c->S * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        K3Args k3{};
+        k3.g = g;
+        k3.chips[0] = c->d_chips[0]; k3.chips[1] = c->d_chips[1]; k3.counts[0] = c->d_counts[0]; k3.counts[1] = c->d_counts[1];
+        k3.hits = c->d_hits; k3.n_hits = c->d_scalars + SC_NHITS; k3.hits_cap = c->hits_cap; k3.pending = c->d_pending;
+        k3.hdr = c->d_hdr; k3.hdr_cap = c->hdr_cap; k3.words = c->d_words; k3.words_cap = c->words_cap;
+        k3.n_hdr = c->d_scalars + SC_NHDR; k3.n_words = c->d_scalars + SC_NWORDS; k3.err = c->d_scalars + SC_ERR;
+        hipLaunchKernelGGL(k3_bursts, dim3(4 * c->S + n_hits), dim3(64), 0, c->stream, k3);
+        HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, SC_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        const uint32_t err = c->h_scalars[SC_ERR];
+        if (err & WM_ERR_EMA) return fail(c, WMBUS_EDEVICE, "RSSI filter hand-off verification failed (raise WM_EMA_WARMUP)");
+        if (err & (WM_ERR_CHIP_OVERFLOW | WM_ERR_BURST_OVERFLOW)) return fail(c, WMBUS_EOVERFLOW, "chip/burst buffer overflow (err=%u)", err);
+        c->n_hdr = c->h_scalars[SC_NHDR]; c->n_words = c->h_scalars[SC_NWORDS];
+        if (c->n_hdr) HIPCHK(c, hipMemcpyAsync(c->h_hdr, c->d_hdr, (size_t)c->n_hdr * sizeof(WmBurstHdr), hipMemcpyDeviceToHost, c->stream));
+        if (c->n_words) HIPCHK(c, hipMemcpyAsync(c->h_words, c->d_words, (size_t)c->n_words * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
+    }
+    /* slide the input history: the next push sees the last 4096 staged bytes in front of it */
+    hipLaunchKernelGGL(k_roll_history, dim3(c->S), dim3(256), 0, c->stream, c->d_in, c->in_stride, (uint32_t)nbytes);
+    HIPCHK(c, hipGetLastError());
+    c->n0 += n_new;
+    c->in_flight = true;
+    return WMBUS_OK;
+}
+
+/* Run the persistent packet decoders of the (stream, chain, framer) groups in order[lo, hi). */
+static void decode_stream_range(wmbus_ctx *c, const std::vector<uint32_t> &order, size_t lo, size_t hi,
+                                std::vector<LineRec> &out, const char *ts_fixed)
+{
+    char line[1024], ts[64];
+    uint32_t seq = 0;
+    size_t i = lo;
+    while (i < hi) {
+        const WmBurstHdr &h0 = c->h_hdr[order[i]];
+        HostDecoder &hd = c->decs[((size_t)h0.stream * 2 + h0.chain) * 2 + h0.algo];
+        const char *tag = c->cfg.show_algorithm ? (h0.algo == WMBUS_ALGO_RLA ? "rla;" : "t2a;") : "";
+        uint64_t next_free = 0;                         /* first chip the decoder has not consumed */
+        bool cut = false;
+        size_t j = i;
+        for (; j < hi; j++) {
+            const WmBurstHdr &h = c->h_hdr[order[j]];
+            if (h.stream != h0.stream || h.chain != h0.chain || h.algo != h0.algo) break;
+            const bool cont = h.flags & 1u;
+            if (cont ? hd.owed == 0 : h.chip0 < next_free) continue;   /* the access code passed while the decoder was busy */
+            const uint32_t *w = c->h_words + h.word_off;
+            int st = cont ? WM_DEC_RECEIVING : WM_DEC_IDLE;
+            uint32_t k = 0;
+            for (; k < h.n_chips; k++) {
+                const uint32_t word = w[k];
+                const unsigned val = word & 7u, rssi = (word >> 3) & 0xFFu;
+                if ((val & 4u) && st == WM_DEC_RECEIVING) {   /* the run-length framer reset itself: telegram lost */
+                    wm_decoder_abort(&hd.dec);
+                    st = WM_DEC_IDLE;
+                    break;                                     /* this chip may start a burst of its own */
+                }
+                st = wm_decoder_chip(&hd.dec, val & 3u, rssi);
+                if (st == WM_DEC_DONE) {
+                    int ok = 0;
+                    if (ts_fixed) snprintf(ts, sizeof ts, "%s", ts_fixed); else wm_timestamp(ts, sizeof ts);
+                    const size_t n = wm_decoder_format(&hd.dec, tag, ts, rssi, line, sizeof line, &ok);
+                    LineRec r; r.sample = h.pos0 + (word >> 11); r.stream = h.stream; r.chain = h.chain; r.algo = h.algo;
+                    r.crc_ok = (uint8_t)ok; r.seq = seq++; r.text.assign(line, n);
+                    out.push_back(std::move(r));
+                    st = WM_DEC_IDLE;
+                }
+                if (st == WM_DEC_IDLE) { k++; break; }
+            }
+            next_free = (uint64_t)h.chip0 + k;
+            cut = st == WM_DEC_RECEIVING;
+            if (cut && h.n_chips != h.avail)                   /* device under-estimated the burst: a bug */
+                snprintf(c->err, sizeof c->err, "burst too short: stream %u chain %u algo %u chip %u", h.stream, h.chain, h.algo, h.chip0);
+            hd.owed = cut ? std::max(1u, wm_decoder_chips_owed(&hd.dec)) : 0u;
+        }
+        i = j;
+    }
+}
+
+int wmbus_collect(wmbus_ctx *c)
+{
+    if (!c) return WMBUS_EINVAL;
+    c->lines.clear(); c->text.clear();
+    if (!c->in_flight) return WMBUS_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->in_flight = false;
+    if (c->last.M > 0) {
+        float ms = 0;
+        hipEventElapsedTime(&ms, c->ev[3], c->ev[4]); c->tim.demod_ms = ms;
+        hipEventElapsedTime(&ms, c->ev[5], c->ev[6]); c->tim.gather_ms = ms;
+        hipEventElapsedTime(&ms, c->ev[6], c->ev[7]); c->tim.d2h_ms = ms;
+        hipEventElapsedTime(&ms, c->ev[2], c->ev[7]); c->tim.gpu_total_ms = ms;
+    }
+    c->tim.bursts = c->n_hdr;
+    const double t0 = now_ms();
+
+    std::vector<uint32_t> order(c->n_hdr);
+    for (uint32_t i = 0; i < c->n_hdr; i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+        const WmBurstHdr &a = c->h_hdr[x], &b = c->h_hdr[y];
+        if (a.stream != b.stream) return a.stream < b.stream;
+        if (a.chain != b.chain) return a.chain < b.chain;
+        if (a.algo != b.algo) return a.algo < b.algo;
+        if ((a.flags & 1u) != (b.flags & 1u)) return (a.flags & 1u) > (b.flags & 1u);   /* continuation first */
+        return a.chip0 < b.chip0;
+    });
+    /* drop exact duplicates (a re-run segment may have re-recorded a hit) */
+    order.erase(std::unique(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+        const WmBurstHdr &a = c->h_hdr[x], &b = c->h_hdr[y];
+        return a.stream == b.stream && a.chain == b.chain && a.algo == b.algo && a.flags == b.flags && a.chip0 == b.chip0;
+    }), order.end());
+    unsigned nt = c->cfg.host_threads ? c->cfg.host_threads : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    if (order.size() < 4096) nt = 1;
+    std::vector<std::vector<LineRec>> parts(nt);
+    const char *tsf = c->cfg.fixed_timestamp ? "TS" : nullptr;
+    if (nt == 1) decode_stream_range(c, order, 0, order.size(), parts[0], tsf);
+    else {
+        /* split at stream boundaries */
+        std::vector<size_t> cut(nt + 1, order.size());
+        cut[0] = 0;
+        for (unsigned t = 1; t < nt; t++) {
+            size_t p = order.size() * t / nt;
+            while (p < order.size() && p > 0 && c->h_hdr[order[p]].stream == c->h_hdr[order[p - 1]].stream) p++;
+            cut[t] = std::max(p, cut[t - 1]);
+        }
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++)
+            th.emplace_back([&, t] { decode_stream_range(c, order, cut[t], cut[t + 1], parts[t], tsf); });
+        for (auto &x : th) x.join();
+    }
+    /* stdout order of the reference: by completing sample, then T1/C1 before S1, run-length before time2 */
+    std::vector<LineRec> all;
+    for (auto &p : parts) for (auto &r : p) all.push_back(std::move(r));
+    std::stable_sort(all.begin(), all.end(), [](const LineRec &a, const LineRec &b) {
+        if (a.stream != b.stream) return a.stream < b.stream;
+        if (a.sample != b.sample) return a.sample < b.sample;
+        if (a.chain != b.chain) return a.chain < b.chain;
+        if (a.algo != b.algo) return a.algo < b.algo;
+        return a.seq < b.seq;
+    });
+    for (auto &r : all) {
+        wmbus_line l{};
+        l.stream = r.stream; l.chain = r.chain; l.algo = r.algo; l.crc_ok = r.crc_ok; l.sample = r.sample;
+        l.text_off = (uint32_t)c->text.size(); l.text_len = (uint32_t)r.text.size();
+        c->text += r.text;
+        c->lines.push_back(l);
+    }
+    c->tim.host_decode_ms = (float)(now_ms() - t0);
+    return c->err[0] && strstr(c->err, "burst too short") ? WMBUS_EDEVICE : WMBUS_OK;
+}
+
+size_t wmbus_lines(const wmbus_ctx *c, const wmbus_line **lines)
+{
+    if (!c) return 0;
+    if (lines) *lines = c->lines.data();
+    return c->lines.size();
+}
+
+const char *wmbus_lines_text(const wmbus_ctx *c, size_t *len)
+{
+    if (!c) return "";
+    if (len) *len = c->text.size();
+    return c->text.c_str();
+}
+
+int wmbus_get_timing(const wmbus_ctx *c, wmbus_timing *t)
+{
+    if (!c || !t) return WMBUS_EINVAL;
+    *t = c->tim;
+    return WMBUS_OK;
+}
+
+long wmbus_read_tap(wmbus_ctx *c, const char *what, int chain, unsigned stream, void *dst, size_t max_elems)
+{
+    if (!c || !what || !dst || chain < 0 || chain > 1 || stream >= c->S || !c->have_last) return WMBUS_EINVAL;
+    hipStreamSynchronize(c->stream);
+    const size_t n = std::min<size_t>(max_elems, c->last.M);
+    const size_t row = (size_t)chain * c->S + stream;
+    if (!strcmp(what, "dphi")) {
+        if (hipMemcpy(dst, c->d_dphi + row * c->Mcap, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return WMBUS_EDEVICE;
+    } else if (!strcmp(what, "rssi")) {
+        if (hipMemcpy(dst, c->d_rssi + row * c->Mcap, n, hipMemcpyDeviceToHost) != hipSuccess) return WMBUS_EDEVICE;
+    } else if (!strcmp(what, "bits")) {
+        std::vector<uint32_t> w((n + 31) / 32);
+        if (hipMemcpy(w.data(), c->d_bits + row * (c->Mcap / 32), w.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return WMBUS_EDEVICE;
+        for (size_t k = 0; k < n; k++) ((uint8_t *)dst)[k] = (w[k >> 5] >> (k & 31)) & 1u;
+    } else return WMBUS_EINVAL;
+    return (long)n;
+}
+
+long wmbus_read_chips(wmbus_ctx *c, int chain, int algo, unsigned stream, uint32_t *dst, uint64_t *pos, size_t max_elems)
+{
+    if (!c || chain < 0 || chain > 1 || algo < 0 || algo > 1 || stream >= c->S || !c->have_last || !dst) return WMBUS_EINVAL;
+    hipStreamSynchronize(c->stream);
+    uint32_t *d_dst = nullptr, *d_n = nullptr; uint64_t *d_pos = nullptr;
+    if (hipMalloc((void **)&d_dst, max_elems * 4) != hipSuccess || hipMalloc((void **)&d_pos, max_elems * 8) != hipSuccess ||
+        hipMalloc((void **)&d_n, 4) != hipSuccess) return WMBUS_ENOMEM;
+    hipLaunchKernelGGL(k4_flatten, dim3(1), dim3(1), 0, c->stream, c->last, c->d_chips[algo], c->d_counts[algo],
+                       algo == WMBUS_ALGO_RLA ? c->cap_rl : c->cap_t2, (uint32_t)chain, stream, d_dst, d_pos, (uint32_t)max_elems, d_n);
+    uint32_t n = 0;
+    hipStreamSynchronize(c->stream);
+    hipMemcpy(&n, d_n, 4, hipMemcpyDeviceToHost);
+    const size_t m = std::min<size_t>(n, max_elems);
+    hipMemcpy(dst, d_dst, m * 4, hipMemcpyDeviceToHost);
+    if (pos) hipMemcpy(pos, d_pos, m * 8, hipMemcpyDeviceToHost);
+    hipFree(d_dst); hipFree(d_pos); hipFree(d_n);
+    return (long)n;
+}
+
+}  // extern "C"

@@ -1,0 +1,98 @@
+/*
+ * wm_dev.h -- layouts shared by the HIP kernels (wm_kernels.hip) and the host pipeline
+ * (wm_api.hip).  See DESIGN.md for the data-flow picture.
+ *
+ * HBM layout (per context, S = n_streams, chain c in {T1C1, S1}, algo a in {RLA, T2A}):
+ *   in     u8   [S][HIST_BYTES + max_push_bytes + SLACK]   cu8; HIST = tail of the previous push
+ *   dphi   f32  [2][S][Mcap]      soft symbol (FIR output), one per decimated sample
+ *   rssi   u8   [2][S][Mcap]      (unsigned) of the filtered magnitude
+ *   bits   u32  [2][S][Mcap/32]   slicer output, bit j of word w = sample 32w+j
+ *   chips  u32  [2][2][S][nseg][cap_a]  per time segment; word = pos16<<16 | rssi<<8 | value
+ *   state arrays, burst arena (see structs below)
+ */
+#ifndef WM_DEV_H
+#define WM_DEV_H
+
+#include <stdint.h>
+
+#define WM_HIST_BYTES   4096u      /* input history kept in front of each push (2048 samples) */
+#define WM_IN_SLACK     256u       /* readable slack behind the staged bytes                  */
+#define WM_K1_HALO      48         /* decimated-sample halo: 45 FIR + 1 discriminator, 48 EMA  */
+#define WM_EMA_WARMUP   48
+#define WM_MAX_DECIM    32u
+
+#define WM_CHIP_VAL(w)   ((w) & 0xFFu)
+#define WM_CHIP_RSSI(w)  (((w) >> 8) & 0xFFu)
+#define WM_CHIP_POS(w)   ((w) >> 16)
+
+/* Sync words and window lengths (rtl_wmbus.c:97-103; longest frames t1_c1_packet_decoder.h:95). */
+#define WM_SYNC_T1C1      0x543Du
+#define WM_SYNC_T1C1_MASK 0xFFFFu
+#define WM_SYNC_S1        0x547696u
+#define WM_SYNC_S1_MASK   0xFFFFFFu
+#define WM_MAXCHIPS_T1C1  (12u * 290u + 1u)
+#define WM_MAXCHIPS_S1    (16u * 290u + 1u)
+
+/* Clock-recovery lane state (12 words): IIR history (iir.h:36-45, h1/h2 per section), DC
+ * remover (rtl_wmbus.c:497-515), clock lock (rtl_wmbus.c:1043-1044), time2 shift register. */
+struct WmClkState {
+    float    h[6];
+    float    dc_x, dc_y;
+    uint32_t clk;          /* bit0 = previous clock high, bits 2:1 = clock_lock (0..3) */
+    uint32_t sr;           /* time2 chip shift register, masked to the sync length     */
+    uint32_t pad[2];
+};
+
+/* Run-length framer lane state (8 words), rtl_wmbus.c:617-637 / 705-726. */
+struct WmRlaState {
+    int32_t  run, bitlen, cum;
+    uint32_t state;        /* bit0 = deglitched level, bit1 = reset pending (ours) */
+    uint32_t raw;          /* raw bit window, masked (6 / 4 bits)                  */
+    uint32_t sr;           /* chip shift register, masked                          */
+    int32_t  spb0, spb1;   /* S1 samples-per-bit trackers                          */
+};
+
+/* Per-push geometry handed to every kernel by value. */
+struct WmPush {
+    const uint8_t *in;       /* base of stream 0's buffer (history first)             */
+    uint64_t in_stride;      /* bytes between streams                                 */
+    uint64_t n0;             /* global input-sample index of the first new sample     */
+    uint64_t m0;             /* global decimated index of the first new decimated one */
+    uint32_t n_new;          /* new input samples this push                           */
+    uint32_t M;              /* new decimated samples this push                       */
+    uint32_t Mcap;           /* row pitch of dphi/rssi (elements), multiple of 128     */
+    uint32_t d;              /* decimation                                            */
+    uint32_t S;              /* streams                                               */
+    uint32_t lut_n;          /* 32*d                                                  */
+    uint32_t lut_phase0;     /* (13*n0) mod lut_n                                     */
+    uint32_t flags;          /* WM_F_*                                                */
+    uint32_t seg_len;        /* C                                                     */
+    uint32_t nseg;           /* ceil(M / C)                                           */
+    uint32_t nseg_cap;       /* segment pitch of the state / count arrays             */
+    uint32_t warm[2];        /* IIR warm-up per chain                                 */
+    uint32_t lookback;       /* RLA speculative lookback                              */
+    uint32_t cap_t2, cap_rl; /* chips per segment region                              */
+};
+
+enum {
+    WM_F_SHIFT = 1, WM_F_ACCURATE = 2, WM_F_DC = 4, WM_F_T1C1 = 8, WM_F_S1 = 16,
+    WM_F_RLA = 32, WM_F_T2A = 64
+};
+
+/* error word bits (device -> host) */
+enum { WM_ERR_EMA = 1, WM_ERR_CHIP_OVERFLOW = 2, WM_ERR_BURST_OVERFLOW = 4 };
+
+/* Burst = the chips a packet decoder needs after one access-code hit. */
+struct WmBurstHdr {
+    uint32_t stream;
+    uint8_t  chain, algo;
+    uint16_t flags;          /* bit0: continuation of a burst cut by the previous push */
+    uint32_t chip0;          /* index of the first chip in this push's chip stream     */
+    uint32_t n_chips;
+    uint64_t pos0;           /* global decimated index of the first chip               */
+    uint32_t word_off;       /* offset of the chip words in the arena (u32 units)      */
+    uint32_t avail;          /* chips from chip0 to the end of this push's chip stream   */
+};
+/* burst chip word: [31:11] sample delta from pos0, [10:3] rssi, [2:0] value */
+
+#endif

@@ -1,0 +1,679 @@
+/*
+ * wm_kernels.hip -- gfx950 kernels for the rtl-wmbus hot path.
+ *
+ *   k1_demod     time-parallel front end: cu8 -> [+-325 kHz shift] -> integer boxcars ->
+ *                decimate -> polar discriminator (exact fdlibm atan2f) -> FIR low-pass ->
+ *                soft symbol; |s| -> EMA -> RSSI byte.          (rtl_wmbus.c:1310-1352,
+ *                517-586, 369-392, 475-495, 1066-1067)
+ *   k1_verify    certifies the EMA hand-offs between tiles.
+ *   k2_clock     lane = (chain, stream, time segment): DC remover, slicer, squared-signal IIR
+ *                band-pass, clock lock, time2 framer.            (rtl_wmbus.c:497-515, 1059,
+ *                336-365, 1089-1111, 806-852)
+ *   k2_rla       lane = (chain, stream, time segment): run-length framer with deglitch and
+ *                bit-length tracking.                            (rtl_wmbus.c:617-803)
+ *   k2_verify    compares each segment's start state with its predecessor's end state; a
+ *                segment whose speculative start was wrong is re-run from the true state.
+ *   k3_*         access-code hit search and burst extraction for the host packet decoders.
+ *
+ * Exactness: every float operation the reference performs is performed here in the same order
+ * with separate roundings (wm_exact.h; the file is also built with -ffp-contract=off).  The
+ * recurrences (EMA, DC, IIR, run-length state) are evaluated sequentially inside a lane; time
+ * parallelism comes from starting lanes early (warm-up / look-back) and PROVING, by bitwise state
+ * comparison at the hand-off, that the lane had converged onto the sequential trajectory.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "wm_dev.h"
+#include "wm_exact.h"
+
+typedef short wm_s2 __attribute__((ext_vector_type(2)));
+
+/* ---------------------------------------------------------------------------------------------
+ * Filter constants (rtl_wmbus.c:372, 384, 338-341, 353-356) as decimal literals, converted by the
+ * compiler to the same floats the reference's arrays hold.
+ * ------------------------------------------------------------------------------------------- */
+__device__ static constexpr float FIR_T[11] = {
+    -0.00456638213f, -0.002571450348f, 0.02689425925f, 0.1141330398f, 0.2264456422f, 0.2793297826f,
+    0.2264456422f, 0.1141330398f, 0.02689425925f, -0.002571450348f, -0.00456638213f};
+__device__ static constexpr float FIR_S[46] = {
+    -0.000649081282f, -0.0009491938209f, -0.001361601657f, -0.001910785234f, -0.002570133495f,
+    -0.003251218426f, -0.003801634695f, -0.004012672882f, -0.003636803575f, -0.002413585945f,
+    -0.0001013597693f, 0.003488892085f, 0.008461671287f, 0.01481127545f, 0.02240598045f,
+    0.03098477999f, 0.0401679839f, 0.04948137286f, 0.05839197924f, 0.06635211627f, 0.07284719662f,
+    0.07744230649f, 0.07982251613f, 0.07982251613f, 0.07744230649f, 0.07284719662f, 0.06635211627f,
+    0.05839197924f, 0.04948137286f, 0.0401679839f, 0.03098477999f, 0.02240598045f, 0.01481127545f,
+    0.008461671287f, 0.003488892085f, -0.0001013597693f, -0.002413585945f, -0.003636803575f,
+    -0.004012672882f, -0.003801634695f, -0.003251218426f, -0.002570133495f, -0.001910785234f,
+    -0.001361601657f, -0.0009491938209f, -0.000649081282f};
+
+/* =============================================================================================
+ * K1: demodulation tile kernel
+ * ===========================================================================================*/
+struct K1Args {
+    WmPush g;
+    float *dphi;             /* [2][S][Mcap] */
+    uint8_t *rssi;           /* [2][S][Mcap] */
+    const float *lut_cos;    /* [lut_n]  cosf table, built on the host with the host libm */
+    const float *lut_msin;   /* [lut_n]  -sinf table                                      */
+    float *ema_head;         /* [2][S][ntiles] EMA after warm-up (= value at tile_start-1) */
+    float *ema_tail;         /* [2][S][ntiles] EMA after the tile's last valid sample      */
+    uint32_t ntiles;
+    uint32_t *err;
+};
+
+template <int RF, bool SHIFT>
+__global__ __launch_bounds__(256) void k1_demod(K1Args a)
+{
+    constexpr int T = 256 * RF;                       /* decimated samples per tile       */
+    constexpr int NA = T + WM_K1_HALO;                /* samples needing i/q              */
+    constexpr int RA = (NA + 255) / 256;              /* stage-A samples per thread       */
+    constexpr int RE = 2 * RF;                        /* EMA run per thread               */
+    constexpr int YROW = NA + 8;                      /* padded row of the float arrays   */
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const WmPush &g = a.g;
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x, stream = blockIdx.y;
+    const int d = (int)g.d;
+    const int ts = tile * T;                          /* first decimated sample (push-relative) */
+    const int tn = min(T, (int)g.M - ts);             /* valid samples in this tile        */
+    const bool chT = g.flags & WM_F_T1C1, chS = g.flags & WM_F_S1;
+
+    /* ---- stage 0: stage the boxcar inputs in LDS as packed int16 (i,q) ------------------- */
+    /* relative input index (to the first new sample) of the oldest sample needed:
+     * boxcar-16 ending at decimated sample (ts - HALO - 1).                                  */
+    const long r_lo = ((long)(g.m0 + (uint64_t)ts) - (WM_K1_HALO)) * d - 16 - (long)g.n0;
+    const long r_al = r_lo & ~7L;                     /* 16-byte aligned start             */
+    const int off = (int)(r_lo - r_al);
+    const int count = NA * d + 16 + off;              /* samples staged                    */
+    const int nchunk = (count + 7) >> 3;
+    wm_s2 *sT = (wm_s2 *)smem;
+    wm_s2 *sS = SHIFT ? sT + ((nchunk * 8 + 3) & ~3) : sT;
+    const uint8_t *base = g.in + (uint64_t)stream * g.in_stride + WM_HIST_BYTES;
+
+    for (int c = tid; c < nchunk; c += 256) {
+        const long r = r_al + 8L * c;
+        const uint4 v = *(const uint4 *)(base + 2 * r);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t li = 0;
+        if (SHIFT) {
+            /* LUT index of global sample n: (13 n) mod lut_n, rtl_wmbus.c:1006-1010 */
+            const int L = (int)g.lut_n;
+            int rm = (int)(r % L); if (rm < 0) rm += L;
+            li = (g.lut_phase0 + 13u * (uint32_t)rm) % (uint32_t)L;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t iq = (w[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
+            const uint32_t bi = iq & 0xFFu, bq = iq >> 8;
+            if (!SHIFT) {
+                wm_s2 x; x.x = (short)wm_quantise(bi); x.y = (short)wm_quantise(bq);
+                sT[8 * c + k] = x;
+            } else {
+                const float fi = wm_sub((float)bi, 127.5f), fq = wm_sub((float)bq, 127.5f);
+                const float x = a.lut_cos[li], z = a.lut_msin[li];
+                li += 13u; if (li >= g.lut_n) li -= g.lut_n;
+                const float ix = wm_mul(fi, x), qx = wm_mul(fq, x), iz = wm_mul(fi, z), qz = wm_mul(fq, z);
+                wm_s2 t, s;
+                t.x = (short)(int)wm_sub(ix, qz); t.y = (short)(int)wm_add(qx, iz);
+                s.x = (short)(int)wm_add(ix, qz); s.y = (short)(int)wm_sub(qx, iz);
+                sT[8 * c + k] = t; sS[8 * c + k] = s;
+            }
+        }
+    }
+    __syncthreads();
+
+    /* ---- stage A: boxcars (sliding packed-int16 sums), discriminator, magnitude ------------ */
+    float drT[RA], drS[RA], mgT[RA], mgS[RA];
+    {
+        const int a0 = RA * tid;                      /* index into [0, NA)                */
+        /* LDS index of decimated sample a: off + a*d + d + 15; start one
+         * decimated sample earlier: the discriminator needs s[a0-1].                        */
+        int l = off + (a0 - 1) * d + d + 15;
+        const bool live = a0 < NA;
+        wm_s2 sumT = {0, 0}, sumS = {0, 0};
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) sumT += sT[l - k];
+#pragma unroll
+            for (int k = 0; k < 16; k++) sumS += sS[l - k];
+        }
+        float piT = (float)sumT.x * 0.125f, pqT = (float)sumT.y * 0.125f;
+        float piS = (float)sumS.x * 0.0625f, pqS = (float)sumS.y * 0.0625f;
+#pragma unroll
+        for (int j = 0; j < RA; j++) {
+            drT[j] = drS[j] = mgT[j] = mgS[j] = 0.0f;
+            if (live && a0 + j < NA) {
+                for (int s = 0; s < d; s++) {
+                    l++;
+                    sumT += sT[l] - sT[l - 8];
+                    sumS += sS[l] - sS[l - 16];
+                }
+                if (chT) {
+                    const float i = (float)sumT.x * 0.125f, q = (float)sumT.y * 0.125f;
+                    drT[j] = (g.flags & WM_F_ACCURATE) ? wm_discriminator(i, q, piT, pqT)
+                                                       : wm_discriminator_fast(i, q, piT, pqT);
+                    mgT[j] = wm_sqrt(wm_add(wm_mul(i, i), wm_mul(q, q)));
+                    piT = i; pqT = q;
+                }
+                if (chS) {
+                    const float i = (float)sumS.x * 0.0625f, q = (float)sumS.y * 0.0625f;
+                    drS[j] = (g.flags & WM_F_ACCURATE) ? wm_discriminator(i, q, piS, pqS)
+                                                       : wm_discriminator_fast(i, q, piS, pqS);
+                    mgS[j] = wm_sqrt(wm_add(wm_mul(i, i), wm_mul(q, q)));
+                    piS = i; pqS = q;
+                }
+            }
+        }
+    }
+    __syncthreads();                                  /* everyone is done with sT/sS       */
+
+    /* float arrays overlay the staging area; element a lives at position a + 1 so that the
+     * 46-tap windows start 16-byte aligned (a = 48 + RF*tid - 45 -> position 4 + RF*tid).   */
+    float *yDrT = (float *)smem, *yDrS = yDrT + YROW, *yMgT = yDrS + YROW, *yMgS = yMgT + YROW;
+    float *sFin = yMgS + YROW;                        /* [2][128] EMA finals               */
+    float *sHead = sFin + 256;                        /* [2][128] EMA after warm-up        */
+    {
+        const int a0 = RA * tid;
+#pragma unroll
+        for (int j = 0; j < RA; j++)
+            if (a0 + j < NA) {
+                yDrT[a0 + j + 1] = drT[j]; yDrS[a0 + j + 1] = drS[j];
+                yMgT[a0 + j + 1] = mgT[j]; yMgS[a0 + j + 1] = mgS[j];
+            }
+    }
+    __syncthreads();
+
+    /* ---- stage B1: FIR low-pass, y[n] = sum_k b[k] x[n-k], k ascending (fir.h:48-72) -------- */
+    {
+        const int m0l = RF * tid;                     /* first output of this thread       */
+        const uint64_t row = (uint64_t)stream * g.Mcap + (uint64_t)ts + m0l;
+        if (chT && m0l < tn) {
+            float w[RF + 10];
+#pragma unroll
+            for (int k = 0; k < RF + 10; k++) w[k] = yDrT[WM_K1_HALO + m0l - 10 + k + 1];
+            float acc[RF];
+#pragma unroll
+            for (int j = 0; j < RF; j++) {
+                float s = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 11; k++) s = wm_add(s, wm_mul(FIR_T[k], w[10 + j - k]));
+                acc[j] = s;
+            }
+            float *o = a.dphi + row;
+#pragma unroll
+            for (int j = 0; j < RF; j++) o[j] = acc[j];
+        }
+        if (chS && m0l < tn) {
+            float w[RF + 45];
+#pragma unroll
+            for (int k = 0; k < RF + 45; k++) w[k] = yDrS[WM_K1_HALO + m0l - 45 + k + 1];
+            float acc[RF];
+#pragma unroll
+            for (int j = 0; j < RF; j++) {
+                float s = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 46; k++) s = wm_add(s, wm_mul(FIR_S[k], w[45 + j - k]));
+                acc[j] = s;
+            }
+            float *o = a.dphi + (uint64_t)g.S * g.Mcap + row;
+#pragma unroll
+            for (int j = 0; j < RF; j++) o[j] = acc[j];
+        }
+    }
+
+    /* ---- stage B2: RSSI = EMA(|s|), alpha = 0.6789 (rtl_wmbus.c:475-495) --------------------- */
+    {
+        const int ch = tid >> 7, e = tid & 127;
+        const bool on = ch ? chS : chT;
+        const float *mg = ch ? yMgS : yMgT;
+        const float al = 0.6789f, be = wm_sub(1.0f, 0.6789f);
+        const int m0l = RE * e;
+        float ema = 0.0f, tail = 0.0f;
+        if (on) {
+#pragma unroll 8
+            for (int k = 0; k < WM_EMA_WARMUP; k++)
+                ema = wm_add(wm_mul(al, mg[m0l + k + 1]), wm_mul(be, ema));
+        }
+        const float head = ema;
+        uint32_t pk[(RE + 3) / 4] = {};
+        if (on) {
+#pragma unroll
+            for (int k = 0; k < RE; k++) {
+                ema = wm_add(wm_mul(al, mg[WM_K1_HALO + m0l + k + 1]), wm_mul(be, ema));
+                pk[k >> 2] |= ((uint32_t)ema & 0xFFu) << (8 * (k & 3));
+                if (m0l + k == tn - 1) tail = ema;
+            }
+            if (m0l < tn) {
+                uint32_t *o = (uint32_t *)(a.rssi + ((uint64_t)ch * g.S + stream) * g.Mcap + ts + m0l);
+#pragma unroll
+                for (int k = 0; k < (RE + 3) / 4; k++) o[k] = pk[k];
+            }
+        }
+        sFin[tid] = ema; sHead[tid] = head;
+        __syncthreads();
+        if (on) {
+            /* certify: my warm-up must have landed exactly on my predecessor's trajectory */
+            if (e > 0 && m0l < tn && wm_f2u(head) != wm_f2u(sFin[tid - 1])) atomicOr(a.err, WM_ERR_EMA);
+            const uint64_t ti = ((uint64_t)ch * g.S + stream) * a.ntiles + tile;
+            if (e == 0) a.ema_head[ti] = head;
+            if (m0l <= tn - 1 && tn - 1 < m0l + RE) a.ema_tail[ti] = tail;
+        }
+    }
+}
+
+/* head[tile] must equal tail[tile-1] (or the value carried from the previous push). */
+__global__ void k1_verify(const float *head, const float *tail, float *carry, uint32_t ntiles,
+                          uint32_t rows, uint32_t *err)
+{
+    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;   /* chain*S + stream */
+    if (row >= rows) return;
+    float prev = carry[row];
+    bool bad = false;
+    for (uint32_t t = 0; t < ntiles; t++) {
+        bad |= wm_f2u(head[(uint64_t)row * ntiles + t]) != wm_f2u(prev);
+        prev = tail[(uint64_t)row * ntiles + t];
+    }
+    carry[row] = prev;
+    if (bad) atomicOr(err, WM_ERR_EMA);
+}
+
+/* =============================================================================================
+ * K2: sequential lanes over time segments
+ * ===========================================================================================*/
+struct K2Args {
+    WmPush g;
+    const float *dphi;
+    const uint8_t *rssi;
+    uint32_t *bits;            /* [2][S][Mcap/32]                                          */
+    uint32_t *chips;           /* base of this algo's regions: [2][S][nseg_cap][cap]       */
+    uint32_t *counts;          /* [2][S][nseg_cap]                                          */
+    void *st_start;            /* state each segment's main loop started from               */
+    void *st_final;            /* state after the segment's last sample                     */
+    void *st_carry;            /* [2][S] exact state carried from the previous push         */
+    const uint32_t *list;      /* re-run list of lane ids, or nullptr                       */
+    uint32_t n_lanes;
+    uint32_t algo;             /* WMBUS_ALGO_* of this launch (tags the hit records)        */
+    uint2 *hits;               /* access-code hits: {lane | algo<<31, chip index in region}  */
+    uint32_t *n_hits; uint32_t hits_cap;
+    uint32_t *err;
+};
+
+__device__ __forceinline__ void record_hit(const K2Args &a, uint32_t lane, uint32_t k)
+{
+    const uint32_t i = atomicAdd(a.n_hits, 1u);
+    if (i < a.hits_cap) a.hits[i] = make_uint2(lane | (a.algo << 31), k);
+    else atomicOr(a.err, WM_ERR_BURST_OVERFLOW);
+}
+
+__device__ __forceinline__ void lane_decode(const K2Args &a, uint32_t lane, uint32_t &ch, uint32_t &stream, uint32_t &seg)
+{
+    /* lane = (ch * nseg + seg) * S + stream : neighbouring lanes = neighbouring streams */
+    stream = lane % a.g.S;
+    const uint32_t r = lane / a.g.S;
+    seg = r % a.g.nseg;
+    ch = r / a.g.nseg;
+}
+
+struct IirCoef { float a1[3], a2[3], b1[3], b2[3]; };
+
+__device__ __forceinline__ IirCoef iir_coef(uint32_t ch)
+{
+    IirCoef c;
+    if (ch == 0) { /* rtl_wmbus.c:340-341 */
+        c.b1[0] = 1.999994649f; c.b2[0] = 0.9999946492f; c.b1[1] = -1.99999482f; c.b2[1] = 0.9999948196f;
+        c.b1[2] = 1.703868036e-07f; c.b2[2] = -1.000010531f;
+        c.a1[0] = -1.387139203f; c.a2[0] = 0.9921518712f; c.a1[1] = -1.403492665f; c.a2[1] = 0.9845934971f;
+        c.a1[2] = -1.430055639f; c.a2[2] = 0.9923856172f;
+    } else {       /* rtl_wmbus.c:355-356 */
+        c.b1[0] = 1.999994187f; c.b2[0] = 0.9999941867f; c.b1[1] = -1.999994026f; c.b2[1] = 0.9999940262f;
+        c.b1[2] = -1.605750097e-07f; c.b2[2] = -1.000011787f;
+        c.a1[0] = -1.92151475f; c.a2[0] = 0.9918135499f; c.a1[1] = -1.922481015f; c.a2[1] = 0.984593497f;
+        c.a1[2] = -1.937432099f; c.a2[2] = 0.9927241336f;
+    }
+    return c;
+}
+
+/* One sample through DC remover + squarer + 3 biquads; returns the clock level (iir.h:57-74). */
+__device__ __forceinline__ bool clk_step(WmClkState &s, const IirCoef &c, bool dc, float x, float &soft)
+{
+    if (dc) { /* rtl_wmbus.c:501/511: (1+a)/2 * (x - x_old) + a * y_old, a = 0.999f */
+        const float al = 0.999f, k = wm_div(wm_add(1.0f, al), 2.0f);
+        const float y = wm_add(wm_mul(k, wm_sub(x, s.dc_x)), wm_mul(al, s.dc_y));
+        s.dc_x = x; s.dc_y = y; x = y;
+    }
+    soft = x;
+    float v = wm_mul(x, x);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float h1 = s.h[2 * k], h2 = s.h[2 * k + 1];
+        const float h0 = wm_sub(v, wm_add(wm_mul(c.a1[k], h1), wm_mul(c.a2[k], h2)));
+        v = wm_add(wm_add(h0, wm_mul(c.b1[k], h1)), wm_mul(c.b2[k], h2));   /* b0 == 1 */
+        s.h[2 * k + 1] = h1; s.h[2 * k] = h0;
+    }
+    return wm_mul(v, 1.874981046e-06f) >= 0.0f;
+}
+
+__global__ __launch_bounds__(64) void k2_clock(K2Args a)
+{
+    uint32_t lane = blockIdx.x * 64 + threadIdx.x;
+    if (lane >= a.n_lanes) return;
+    const bool rerun = a.list != nullptr;
+    if (rerun) lane = a.list[lane];
+    const WmPush &g = a.g;
+    uint32_t ch, stream, seg;
+    lane_decode(a, lane, ch, stream, seg);
+    if (!(g.flags & (ch ? WM_F_S1 : WM_F_T1C1))) return;
+
+    const uint64_t row = (uint64_t)ch * g.S + stream;
+    const uint64_t sidx = row * g.nseg_cap + seg;
+    const uint32_t mb = seg * g.seg_len, me = min(g.M, mb + g.seg_len);
+    WmClkState *stS = (WmClkState *)a.st_start, *stF = (WmClkState *)a.st_final, *stC = (WmClkState *)a.st_carry;
+
+    WmClkState s;
+    uint32_t m;
+    if (rerun) { s = seg ? stF[sidx - 1] : stC[row]; m = mb; }
+    else {
+        const uint32_t w = g.warm[ch];
+        if (mb <= w) { s = stC[row]; m = 0; }            /* exact: run from the push start  */
+        else { s = WmClkState{}; m = mb - w; }           /* speculative cold start          */
+    }
+    const IirCoef c = iir_coef(ch);
+    const bool dc = g.flags & WM_F_DC;
+    const float *x = a.dphi + row * g.Mcap;
+    const uint8_t *rs = a.rssi + row * g.Mcap;
+    const uint32_t syncw = ch ? WM_SYNC_S1 : WM_SYNC_T1C1, syncm = ch ? WM_SYNC_S1_MASK : WM_SYNC_T1C1_MASK;
+
+    /* clock lock + time2 framer, rtl_wmbus.c:1092-1111 and :818-828 */
+    auto step = [&](float xin, uint32_t mm, bool emit, uint32_t &bitw, uint32_t *out, uint32_t &n_out) {
+        float soft;
+        const bool high = clk_step(s, c, dc, xin, soft);
+        const uint32_t bit = soft >= 0.0f;
+        uint32_t lock = s.clk >> 1;
+        const bool old_high = s.clk & 1u;
+        if (high && !old_high) lock = 1;
+        else if (high) {
+            if (lock < 2) lock++;
+            else if (lock == 2) {
+                lock = 3;
+                s.sr = ((s.sr << 1) | bit) & syncm;
+                if (emit && (g.flags & WM_F_T2A)) {
+                    const uint32_t val = bit | (s.sr == syncw ? 2u : 0u);
+                    if (n_out < g.cap_t2) out[n_out] = ((mm - mb) << 16) | ((uint32_t)rs[mm] << 8) | val;
+                    if (val & 2u) record_hit(a, lane, n_out);
+                    n_out++;
+                }
+            }
+        }
+        s.clk = (lock << 1) | (high ? 1u : 0u);
+        bitw |= bit << (mm & 31u);
+    };
+
+    uint32_t n_out = 0, bitw = 0;
+    uint32_t *out = a.chips + sidx * g.cap_t2;
+    /* warm-up: [m, mb) -- no output */
+    for (; m < mb; m += 4) {
+        const float4 v = *(const float4 *)(x + m);
+        step(v.x, m, false, bitw, out, n_out); step(v.y, m + 1, false, bitw, out, n_out);
+        step(v.z, m + 2, false, bitw, out, n_out); step(v.w, m + 3, false, bitw, out, n_out);
+    }
+    stS[sidx] = s;
+    uint32_t *bw = a.bits + row * (g.Mcap / 32);
+    bitw = 0;
+    for (m = mb; m < me; m += 4) {
+        const float4 v = *(const float4 *)(x + m);
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (m + k < me) step(vv[k], m + k, true, bitw, out, n_out);
+        if (((m + 4) & 31u) == 0 || m + 4 >= me) { bw[m >> 5] = bitw; bitw = 0; }
+    }
+    stF[sidx] = s;
+    a.counts[sidx] = n_out;
+    if (n_out > g.cap_t2) atomicOr(a.err, WM_ERR_CHIP_OVERFLOW);
+}
+
+/* Run-length framer lane (rtl_wmbus.c:640-702 S1, :729-803 T1/C1). */
+__global__ __launch_bounds__(64) void k2_rla(K2Args a)
+{
+    uint32_t lane = blockIdx.x * 64 + threadIdx.x;
+    if (lane >= a.n_lanes) return;
+    const bool rerun = a.list != nullptr;
+    if (rerun) lane = a.list[lane];
+    const WmPush &g = a.g;
+    uint32_t ch, stream, seg;
+    lane_decode(a, lane, ch, stream, seg);
+    if (!(g.flags & (ch ? WM_F_S1 : WM_F_T1C1))) return;
+
+    const uint64_t row = (uint64_t)ch * g.S + stream;
+    const uint64_t sidx = row * g.nseg_cap + seg;
+    const uint32_t mb = seg * g.seg_len, me = min(g.M, mb + g.seg_len);
+    WmRlaState *stS = (WmRlaState *)a.st_start, *stF = (WmRlaState *)a.st_final, *stC = (WmRlaState *)a.st_carry;
+    const WmRlaState reset = {0, 8 * 256, 0, 2u, 0u, 0u, 24, 24};   /* :628-637 / :717-726, reset pending */
+
+    WmRlaState s;
+    uint32_t m;
+    if (rerun) { s = seg ? stF[sidx - 1] : stC[row]; m = mb; }
+    else if (mb <= g.lookback) { s = stC[row]; m = 0; }
+    else { s = reset; m = mb - g.lookback; }
+
+    const uint32_t *bw = a.bits + row * (g.Mcap / 32);
+    const uint8_t *rs = a.rssi + row * g.Mcap;
+    uint32_t *out = a.chips + sidx * g.cap_rl;
+    uint32_t n_out = 0;
+    const bool s1 = ch != 0;
+    const uint32_t syncw = s1 ? WM_SYNC_S1 : WM_SYNC_T1C1, syncm = s1 ? WM_SYNC_S1_MASK : WM_SYNC_T1C1_MASK;
+
+    auto emit_chips = [&](int unit, int half, uint32_t mm, bool emit) -> int {
+        int n = 0;
+        const uint32_t level = s.state & 1u;
+        const uint32_t rssi = rs[mm];
+        while (s.run > half) {
+            s.run -= unit;
+            s.sr = ((s.sr << 1) | level) & syncm;
+            if (emit) {
+                const uint32_t val = level | (s.sr == syncw ? 2u : 0u) | ((s.state & 2u) ? 4u : 0u);
+                if (n_out < g.cap_rl) out[n_out] = ((mm - mb) << 16) | (rssi << 8) | val;
+                if (val & 2u) record_hit(a, lane, n_out);
+                n_out++;
+            }
+            s.state &= ~2u;                               /* reset marker consumed by this chip */
+            n++;
+        }
+        return n;
+    };
+
+    auto step = [&](uint32_t bit, uint32_t mm, bool emit) {
+        uint32_t st;
+        if (!s1) { s.raw = ((s.raw << 1) | bit) & 0x3Fu; st = __popc(s.raw) >= 3; }        /* :733, LUT :126-144 */
+        else { s.raw = ((s.raw << 1) | bit) & 0xFu; st = (0xFEEAu >> s.raw) & 1u; }          /* LUT :149-154 */
+        if ((s.state & 1u) == st) { s.run++; return; }
+        bool rst = false;
+        if (!s1) {
+            if (s.run < 5) rst = true;                                                       /* :742 */
+            else {
+                s.run *= 256;
+                const int half = s.bitlen / 2;
+                if (s.run <= half) rst = true;                                               /* :756 */
+                else {
+                    const int n = emit_chips(s.bitlen, half, mm, emit);
+                    s.cum += s.run;
+                    s.bitlen += (s.run + s.cum / 16) / (32 * n);                             /* :792-796 */
+                }
+            }
+        } else {
+            const int spb = (s.spb0 + s.spb1) / 2;
+            if (spb <= 12 || spb >= 36) rst = true;                                          /* :659 */
+            else {
+                const int half = spb / 2, run0 = s.run;
+                if (run0 <= half) rst = true;                                                /* :671 */
+                else {
+                    const int n = emit_chips(spb, half, mm, emit);
+                    if (s.state & 1u) s.spb1 = run0 / n; else s.spb0 = run0 / n;             /* :698 */
+                }
+            }
+        }
+        if (rst) s = reset;
+        s.state = (s.state & 2u) | st;
+        s.run = 1;
+    };
+
+    for (; m < mb; m++) step((bw[m >> 5] >> (m & 31u)) & 1u, m, false);
+    stS[sidx] = s;
+    for (m = mb; m < me; m++) step((bw[m >> 5] >> (m & 31u)) & 1u, m, true);
+    stF[sidx] = s;
+    a.counts[sidx] = n_out;
+    if (n_out > g.cap_rl) atomicOr(a.err, WM_ERR_CHIP_OVERFLOW);
+}
+
+/* start[seg] must equal final[seg-1]; mismatching lanes are appended to `list`. */
+__global__ void k2_verify(WmPush g, const uint32_t *st_start, const uint32_t *st_final, uint32_t words,
+                          uint32_t *list, uint32_t *n_list)
+{
+    const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= 2u * g.nseg * g.S) return;
+    const uint32_t stream = lane % g.S, r = lane / g.S, seg = r % g.nseg, ch = r / g.nseg;
+    if (!(g.flags & (ch ? WM_F_S1 : WM_F_T1C1)) || seg == 0) return;
+    const uint64_t sidx = ((uint64_t)ch * g.S + stream) * g.nseg_cap + seg;
+    const uint32_t *p = st_start + sidx * words, *q = st_final + (sidx - 1) * words;
+    bool same = true;
+    for (uint32_t k = 0; k < words; k++) same &= p[k] == q[k];
+    if (!same) list[atomicAdd(n_list, 1u)] = lane;
+}
+
+/* =============================================================================================
+ * K3: access-code hits -> bursts for the host packet decoders
+ * ===========================================================================================*/
+struct K3Args {
+    WmPush g;
+    const uint32_t *chips[2];    /* per algo: [2][S][nseg_cap][cap]                          */
+    const uint32_t *counts[2];   /* per algo: [2][S][nseg_cap]                               */
+    const uint2 *hits; const uint32_t *n_hits; uint32_t hits_cap;
+    const uint32_t *pending;     /* [2 algo][2 chain][S]: chips still owed to a busy decoder  */
+    WmBurstHdr *hdr; uint32_t hdr_cap;
+    uint32_t *words; uint32_t words_cap;
+    uint32_t *n_hdr, *n_words;
+    uint32_t *err;
+};
+
+__device__ static const uint8_t D3OF6[64] = {
+    255,255,255,255,255,255,255,255,255,255,255,3,255,1,2,255,255,255,255,7,255,255,0,255,255,5,6,255,4,255,255,255,
+    255,255,255,11,255,9,10,255,255,15,255,255,8,255,255,255,255,13,14,255,12,255,255,255,255,255,255,255,255,255,255,255};
+
+__device__ __forceinline__ uint32_t full_len_a(uint32_t L) { return 1u + L + 2u * (1u + (L > 9u ? (L - 9u + 15u) / 16u : 0u)); }
+
+/* Chips after the access-code chip that a decoder consumes before it returns to idle, ignoring
+ * RSSI aborts and framer resets (those only shorten it).  hb = the next 24 chips, first chip in
+ * bit 23; nb = how many of them exist.  Mirrors the length logic of
+ * t1_c1_packet_decoder.h:298-349,399-438 and s1_packet_decoder.h:152-197. */
+__device__ uint32_t burst_need(uint32_t chain, uint32_t hb, uint32_t nb)
+{
+    if (chain == 0) {
+        if (nb < 12) return WM_MAXCHIPS_T1C1;
+        const uint32_t hi = D3OF6[(hb >> 18) & 63u], lo = D3OF6[(hb >> 12) & 63u];
+        if (hi != 255u && lo != 255u) return 12u * full_len_a((hi << 4) | lo);
+        const uint32_t mode = hb >> 12;
+        if (mode != 0x54Cu && mode != 0x543u) return 12u;
+        if (nb < 24) return WM_MAXCHIPS_T1C1;
+        if (((hb >> 8) & 15u) != 0xDu) return 16u;
+        const uint32_t L = hb & 255u;
+        return 24u + 8u * ((mode == 0x543u ? 1u + L : full_len_a(L)) - 1u);
+    }
+    if (nb < 16) return WM_MAXCHIPS_S1;
+    uint32_t L = 0;
+    for (int j = 0; j < 8; j++) {
+        const uint32_t pair = (hb >> (22 - 2 * j)) & 3u;
+        if (pair == 0u || pair == 3u) return 2u * (uint32_t)j + 2u;
+        L = (L << 1) | (pair == 1u ? 1u : 0u);
+    }
+    return 16u * full_len_a(L);
+}
+
+/* One wave per hit (or per pending continuation). */
+__global__ __launch_bounds__(64) void k3_bursts(K3Args a)
+{
+    const WmPush &g = a.g;
+    const uint32_t n_hits = min(*a.n_hits, a.hits_cap);
+    const uint32_t item = blockIdx.x, ln = threadIdx.x;
+    uint32_t algo, ch, stream, seg, k, cont = 0, want;
+    if (item < 4u * g.S) {                       /* continuation slots come first            */
+        algo = item / (2u * g.S); ch = (item / g.S) & 1u; stream = item % g.S;
+        want = a.pending[item];
+        if (want == 0u) return;
+        seg = 0; k = 0; cont = 1;
+    } else {
+        if (item - 4u * g.S >= n_hits) return;
+        const uint2 h = a.hits[item - 4u * g.S];
+        algo = h.x >> 31;
+        const uint32_t lane = h.x & 0x7FFFFFFFu;
+        stream = lane % g.S; const uint32_t r = lane / g.S; seg = r % g.nseg; ch = r / g.nseg;
+        k = h.y; want = 0;
+    }
+    const uint32_t cap = algo == 0 ? g.cap_rl : g.cap_t2;
+    const uint64_t row = (uint64_t)ch * g.S + stream;
+    const uint32_t *cnt = a.counts[algo] + row * g.nseg_cap;
+    const uint32_t *base = a.chips[algo] + row * g.nseg_cap * (uint64_t)cap;
+    if (!cont) {                                 /* stale record of a re-run segment?         */
+        if (k >= min(cnt[seg], cap) || !(base[(uint64_t)seg * cap + k] & 2u)) return;
+    }
+    /* chips before / from the hit in this push's chip stream */
+    uint32_t before = 0, total = 0;
+    for (uint32_t s = 0; s < g.nseg; s++) { const uint32_t c = min(cnt[s], cap); if (s < seg) before += c; total += c; }
+    const uint32_t chip0 = before + k;
+    if (chip0 >= total) return;
+    const uint32_t avail = total - chip0;        /* chips from the hit to the end of the push */
+
+    auto locate = [&](uint32_t j, uint32_t &sg, uint32_t &kk) {   /* chip0 + j -> (segment, index) */
+        sg = seg; kk = k + j;
+        while (sg < g.nseg) { const uint32_t c = min(cnt[sg], cap); if (kk < c) break; kk -= c; sg++; }
+    };
+
+    uint32_t n;
+    if (cont) n = min(want, avail);
+    else {
+        uint32_t bit = 0;
+        if (ln < 24u && 1u + ln < avail) { uint32_t sg, kk; locate(1u + ln, sg, kk); bit = base[(uint64_t)sg * cap + kk] & 1u; }
+        const unsigned long long m = __ballot(bit);
+        uint32_t hb = 0;
+        for (int j = 0; j < 24; j++) hb |= (uint32_t)((m >> j) & 1ull) << (23 - j);
+        n = min(burst_need(ch, hb, min(24u, avail - 1u)) + 1u, avail);
+    }
+    uint32_t hslot = 0, woff = 0;
+    if (ln == 0) { hslot = atomicAdd(a.n_hdr, 1u); woff = atomicAdd(a.n_words, n); }
+    hslot = __shfl(hslot, 0); woff = __shfl(woff, 0);
+    if (hslot >= a.hdr_cap || woff + n > a.words_cap) { if (ln == 0) atomicOr(a.err, WM_ERR_BURST_OVERFLOW); return; }
+    uint32_t sg0, k0; locate(0, sg0, k0);
+    const uint64_t pos0 = g.m0 + (uint64_t)sg0 * g.seg_len + WM_CHIP_POS(base[(uint64_t)sg0 * cap + k0]);
+    for (uint32_t j = ln; j < n; j += 64u) {
+        uint32_t sg, kk; locate(j, sg, kk);
+        const uint32_t w = base[(uint64_t)sg * cap + kk];
+        const uint64_t pos = g.m0 + (uint64_t)sg * g.seg_len + WM_CHIP_POS(w);
+        a.words[woff + j] = ((uint32_t)(pos - pos0) << 11) | (WM_CHIP_RSSI(w) << 3) | (WM_CHIP_VAL(w) & 7u);
+    }
+    if (ln == 0) {
+        WmBurstHdr h;
+        h.stream = stream; h.chain = (uint8_t)ch; h.algo = (uint8_t)algo; h.flags = (uint16_t)cont;
+        h.chip0 = chip0; h.n_chips = n; h.pos0 = pos0; h.word_off = woff; h.avail = avail;
+        a.hdr[hslot] = h;
+    }
+}
+
+/* Debug/parity helper: flatten one (chain, algo, stream) chip stream. */
+__global__ void k4_flatten(WmPush g, const uint32_t *chips, const uint32_t *counts, uint32_t cap,
+                           uint32_t ch, uint32_t stream, uint32_t *dst, uint64_t *pos, uint32_t max_out, uint32_t *n_out)
+{
+    if (blockIdx.x || threadIdx.x) return;
+    const uint64_t row = (uint64_t)ch * g.S + stream;
+    uint32_t n = 0;
+    for (uint32_t s = 0; s < g.nseg; s++) {
+        const uint32_t c = min(counts[row * g.nseg_cap + s], cap);
+        for (uint32_t k = 0; k < c; k++, n++)
+            if (n < max_out) {
+                const uint32_t w = chips[(row * g.nseg_cap + s) * (uint64_t)cap + k];
+                dst[n] = w;
+                if (pos) pos[n] = g.m0 + (uint64_t)s * g.seg_len + WM_CHIP_POS(w);
+            }
+    }
+    *n_out = n;
+}
