@@ -599,6 +599,7 @@ static void chain_step(wmo_ctx *c, chain_state *ch)
     ch->pi = i; ch->pq = q;
 
     float dphi = fir_step(ch, dphi_raw);
+    const float dphi_fir = dphi;
     if (c->o.remove_dc) { /* rtl_wmbus.c:497-515, alpha = 0.999f */
         const float alpha = 0.999f;
         const float y = (1.f + alpha) / 2.f * (dphi - ch->dc_x) + alpha * ch->dc_y;
@@ -615,6 +616,7 @@ static void chain_step(wmo_ctx *c, chain_state *ch)
         if (t->iq[k]) { t->iq[k][2 * m] = i; t->iq[k][2 * m + 1] = q; }
         if (t->dphi_raw[k]) t->dphi_raw[k][m] = dphi_raw;
         if (t->dphi[k]) t->dphi[k][m] = dphi;
+        if (t->dphi_fir[k]) t->dphi_fir[k][m] = dphi_fir;
         if (t->rssi[k]) t->rssi[k][m] = ch->ema;
         if (t->bit[k]) t->bit[k][m] = (uint8_t)bit;
     }

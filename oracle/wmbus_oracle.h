@@ -62,6 +62,7 @@ typedef struct wmo_taps {
     float   *iq[2];          /* interleaved i,q after boxcar+decimation (2*cap floats) */
     float   *dphi_raw[2];    /* discriminator output                                  */
     float   *dphi[2];        /* after FIR (+ DC removal with -o): the soft symbol      */
+    float   *dphi_fir[2];    /* FIR output before the optional DC removal              */
     float   *rssi[2];        /* filtered magnitude (float, before truncation)          */
     float   *clk[2];         /* IIR band-pass output (after gain)                      */
     uint8_t *bit[2];         /* slicer output                                          */

@@ -42,7 +42,8 @@ CHIP_DTYPE = np.dtype([("sample", "<u4"), ("chain", "u1"), ("algo", "u1"), ("val
 
 class Taps(ctypes.Structure):
     _fields_ = [("cap", ctypes.c_size_t), ("iq", ctypes.c_void_p * 2), ("dphi_raw", ctypes.c_void_p * 2),
-                ("dphi", ctypes.c_void_p * 2), ("rssi", ctypes.c_void_p * 2), ("clk", ctypes.c_void_p * 2),
+                ("dphi", ctypes.c_void_p * 2), ("dphi_fir", ctypes.c_void_p * 2), ("rssi", ctypes.c_void_p * 2),
+                ("clk", ctypes.c_void_p * 2),
                 ("bit", ctypes.c_void_p * 2), ("chips", ctypes.c_void_p), ("chips_cap", ctypes.c_size_t),
                 ("chips_len", ctypes.c_size_t)]
 
@@ -109,7 +110,7 @@ def run(cu8, opts, taps=False, chips=False):
         t.cap = m_cap
         if taps:
             for name, dt, mult in [("iq", np.float32, 2), ("dphi_raw", np.float32, 1), ("dphi", np.float32, 1),
-                                   ("rssi", np.float32, 1), ("clk", np.float32, 1), ("bit", np.uint8, 1)]:
+                                   ("dphi_fir", np.float32, 1), ("rssi", np.float32, 1), ("clk", np.float32, 1), ("bit", np.uint8, 1)]:
                 arrs = [np.zeros(m_cap * mult, dt) for _ in range(2)]
                 keep.append(arrs)
                 out[name] = arrs
@@ -127,7 +128,7 @@ def run(cu8, opts, taps=False, chips=False):
     out["text"] = ctypes.string_at(p, n.value).decode() if n.value else ""
     out["m"] = int(L.wmo_decimated_count(ctx))
     if taps:
-        for k in ("iq", "dphi_raw", "dphi", "rssi", "clk", "bit"):
+        for k in ("iq", "dphi_raw", "dphi", "dphi_fir", "rssi", "clk", "bit"):
             mult = 2 if k == "iq" else 1
             out[k] = [a[: out["m"] * mult] for a in out[k]]
     if chips:

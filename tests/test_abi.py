@@ -1,0 +1,63 @@
+"""The C-ABI library loads on a CPU-only box, exports what include/wmbus_hip.h declares, and
+refuses to run without a HIP device (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "wmbus_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(wmbus_[a-z_]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported(wm):
+    L = wm.lib()
+    names = declared_functions()
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(L, n), n
+    assert sorted(wm.EXPORTS) == names
+
+
+def test_struct_sizes_match_ctypes(wm):
+    # keeps the ctypes mirror honest: compile a tiny C program printing the sizes
+    import subprocess, tempfile
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "s.c")
+        open(c, "w").write('#include <stdio.h>\n#include "wmbus_hip.h"\nint main(void){printf("%zu %zu %zu\\n",'
+                           'sizeof(wmbus_cfg),sizeof(wmbus_line),sizeof(wmbus_timing));return 0;}\n')
+        exe = os.path.join(d, "s")
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-o", exe, c], check=True)
+        sizes = list(map(int, subprocess.run([exe], capture_output=True, text=True).stdout.split()))
+    assert sizes == [ctypes.sizeof(wm.Cfg), ctypes.sizeof(wm.Line), ctypes.sizeof(wm.Timing)]
+
+
+def test_no_cpu_fallback_without_device(wm):
+    if wm.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(wm.WmbusError, match="no HIP device|failed"):
+        wm.Receiver(n_streams=1)
+
+
+def test_cli_usage_and_exit_codes(wm):
+    import subprocess
+    # unknown option (the reference's getopt string has no 'h'): usage on stdout, exit 1
+    p = subprocess.run([wm.CLI_PATH, "-h"], capture_output=True, text=True, stdin=subprocess.DEVNULL)
+    assert p.returncode == 1 and "Usage" in p.stdout and "-p [T,S]" in p.stdout
+    p = subprocess.run([wm.CLI_PATH, "-V"], capture_output=True, text=True, stdin=subprocess.DEVNULL)
+    assert p.returncode == 0 and p.stdout.startswith("rtl_wmbus:")
+    p = subprocess.run([wm.CLI_PATH, "-r", "1"], capture_output=True, text=True, stdin=subprocess.DEVNULL)
+    assert p.returncode == 1
+
+
+def test_synth_is_deterministic(wm):
+    a, fa = wm.synth_capture(seed=1234, n_samples=1 << 16, kinds=15, frames_per_s=200.0)
+    b, fb = wm.synth_capture(seed=1234, n_samples=1 << 16, kinds=15, frames_per_s=200.0)
+    c, _ = wm.synth_capture(seed=1235, n_samples=1 << 16, kinds=15, frames_per_s=200.0)
+    assert np.array_equal(a, b) and fa == fb and not np.array_equal(a, c)

@@ -1,0 +1,164 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the committed golden output of
+the reference and against the oracle -- datagram text byte-for-byte, soft symbols / RSSI / slicer
+bits / chip streams bit-for-bit (tolerance 0: every float op is rounded like the reference's)."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from cases import BUNDLED_CASES, SYNTH_CASES, flags_to_kwargs, flags_to_oracle_opts, synth_case_capture
+from conftest import GOLDEN, SAMPLES
+
+pytestmark = pytest.mark.gpu
+
+BUNDLED = json.load(open(os.path.join(GOLDEN, "bundled.json")))
+SYNTH = json.load(open(os.path.join(GOLDEN, "synthetic.json")))
+SOFT_SYMBOL_TOLERANCE = 0.0   # |delta_phi_gpu - delta_phi_reference|; the path is bit-exact
+
+
+def compare_taps(rx, ref, stream=0, chains=(0, 1)):
+    m = ref["m"]
+    for ch in chains:
+        d = rx.read_tap("dphi", ch, stream, m)       # FIR output (the DC remover of -o runs in the clock kernel)
+        assert np.abs(d - ref["dphi_fir"][ch]).max(initial=0.0) <= SOFT_SYMBOL_TOLERANCE
+        assert np.array_equal(d.view(np.uint32), ref["dphi_fir"][ch].view(np.uint32))
+        assert np.array_equal(rx.read_tap("rssi", ch, stream, m), ref["rssi"][ch].astype(np.uint32).astype(np.uint8))
+        assert np.array_equal(rx.read_tap("bits", ch, stream, m), ref["bit"][ch])
+
+
+def compare_chips(rx, ref, stream=0, chains=(0, 1), algos=(0, 1)):
+    for ch in chains:
+        for al in algos:
+            w, pos = rx.read_chips(ch, al, stream)
+            oc = ref["chips"][(ref["chips"]["chain"] == ch) & (ref["chips"]["algo"] == al)]
+            assert len(w) == len(oc), (ch, al)
+            assert np.array_equal(w & 0xFF, oc["value"]) and np.array_equal((w >> 8) & 0xFF, oc["rssi"])
+            assert np.array_equal(pos, oc["sample"])
+
+
+@pytest.mark.parametrize("name,flags", BUNDLED_CASES, ids=[f"{n[14:22]}:{' '.join(f)}" for n, f in BUNDLED_CASES])
+def test_bundled_captures_match_reference_golden(wm, name, flags):
+    cu8 = np.fromfile(os.path.join(SAMPLES, name), np.uint8)
+    with wm.Receiver(n_streams=1, max_push_bytes=4 << 20, **flags_to_kwargs(flags)) as rx:
+        assert rx.run(cu8)[0] == BUNDLED[f"{name}|{' '.join(flags)}"]
+
+
+@pytest.mark.parametrize("case", SYNTH_CASES, ids=[c["id"] for c in SYNTH_CASES])
+def test_synthetic_captures_match_reference_golden_and_oracle(wm, oracle, case):
+    cu8, _ = synth_case_capture(wm, case)
+    kw = flags_to_kwargs(case["flags"])
+    ref = oracle.run(cu8, flags_to_oracle_opts(oracle, case["flags"]), taps=True, chips=True)
+    with wm.Receiver(n_streams=1, max_push_bytes=cu8.size, **kw) as rx:
+        text = rx.run(cu8)[0]
+        chains = [c for c, on in ((0, kw.get("t1c1", True)), (1, kw.get("s1", True))) if on]
+        algos = [a for a, on in ((0, kw.get("rla", True)), (1, kw.get("time2", True))) if on]
+        compare_taps(rx, ref, chains=chains)
+        compare_chips(rx, ref, chains=chains, algos=algos)
+    assert text == SYNTH[case["id"]]
+    assert text == ref["text"]
+
+
+@pytest.mark.parametrize("seg_len,w0,w1,lb", [(4096, 1024, 1024, 64), (8192, 4096, 8192, 256), (65536, 24576, 49152, 1024)])
+def test_result_independent_of_segmentation(wm, oracle, samples, seg_len, w0, w1, lb):
+    """Short warm-ups force hand-off verification failures: the re-run path must restore exactness."""
+    cu8 = samples["samples2"]
+    ref = oracle.run(cu8, flags_to_oracle_opts(oracle, ["-v"]), taps=True, chips=True)
+    with wm.Receiver(n_streams=1, max_push_bytes=cu8.size, seg_len=seg_len, warmup_t1c1=w0, warmup_s1=w1, rla_lookback=lb) as rx:
+        text = rx.run(cu8)[0]
+        tim = rx.timing()
+        compare_chips(rx, ref)
+    assert text == ref["text"]
+    if seg_len == 4096:
+        assert tim["clock_reruns"] > 0 and tim["rla_reruns"] > 0   # the slow path really ran
+
+
+@pytest.mark.parametrize("push_bytes", [4096, 8192 * 5, 1 << 18, 1 << 20])
+def test_streaming_pushes_equal_one_shot(wm, oracle, push_bytes):
+    """State (filters, framers, decoders mid-telegram) is carried across pushes exactly."""
+    cu8, _ = wm.synth_capture(seed=77, n_samples=(1 << 19) if push_bytes < 65536 else (1 << 20), kinds=15,
+                              frames_per_s=80.0, amplitude=40.0)
+    if push_bytes == 4096:
+        cu8 = cu8[: 1 << 18]
+    ref = oracle.run(cu8, flags_to_oracle_opts(oracle, ["-v"]))["text"]
+    with wm.Receiver(n_streams=1, max_push_bytes=1 << 20) as rx:
+        assert rx.run(cu8, push_bytes=push_bytes)[0] == ref
+
+
+def test_decimation_phase_carries_across_pushes(wm, oracle):
+    cu8, _ = wm.synth_capture(seed=78, n_samples=1 << 19, fs_khz=2400, kinds=15, frames_per_s=80.0)
+    ref = oracle.run(cu8, flags_to_oracle_opts(oracle, ["-d", "3", "-v"]))["text"]
+    with wm.Receiver(n_streams=1, max_push_bytes=1 << 20, decimation=3) as rx:
+        assert rx.run(cu8, push_bytes=4096 * 7)[0] == ref     # 2048*7 samples: not a multiple of 3
+
+
+def test_many_streams_in_one_batch(wm, oracle):
+    n_streams, n = 48, 1 << 18
+    caps = [wm.synth_capture(seed=900 + s, n_samples=n, kinds=15, frames_per_s=100.0, amplitude=[60, 25, 9][s % 3])[0]
+            for s in range(n_streams)]
+    with wm.Receiver(n_streams=n_streams, max_push_bytes=2 * n, seg_len=16384, warmup_t1c1=8192, warmup_s1=16384) as rx:
+        texts = rx.run(caps)
+        for s in (0, 17, 47):
+            ref = oracle.run(caps[s], flags_to_oracle_opts(oracle, ["-v"]), taps=True, chips=True)
+            compare_taps(rx, ref, stream=s)
+            compare_chips(rx, ref, stream=s)
+    for s in range(n_streams):
+        assert texts[s] == oracle.run(caps[s], flags_to_oracle_opts(oracle, ["-v"]))["text"], s
+
+
+def test_edge_inputs(wm, oracle):
+    rng = np.random.default_rng(5)
+    cases = {
+        "all_zero_bytes": np.zeros(1 << 17, np.uint8),
+        "all_128": np.full(1 << 17, 128, np.uint8),
+        "full_scale_noise": rng.integers(0, 256, 1 << 18, dtype=np.uint8),
+        "square_wave": np.tile(np.array([255, 0, 0, 255], np.uint8), 1 << 16),
+        "one_block": rng.integers(100, 156, 4096, dtype=np.uint8),
+    }
+    for name, cu8 in cases.items():
+        for flags in (["-v"], ["-s", "-o", "-v"]):
+            ref = oracle.run(cu8, flags_to_oracle_opts(oracle, flags), taps=True, chips=True)
+            with wm.Receiver(n_streams=1, max_push_bytes=1 << 18, **flags_to_kwargs(flags)) as rx:
+                assert rx.run(cu8)[0] == ref["text"], (name, flags)
+                compare_taps(rx, ref)
+                compare_chips(rx, ref)
+
+
+def test_partial_tail_and_empty_input(wm, samples):
+    cu8 = samples["samples2"]
+    with wm.Receiver(n_streams=1, max_push_bytes=4 << 20) as rx:
+        a = rx.run(cu8[: 300 * 4096 + 4095])[0]
+    with wm.Receiver(n_streams=1, max_push_bytes=4 << 20) as rx:
+        assert rx.run(cu8[: 300 * 4096])[0] == a
+        assert rx.run(cu8[:100]) == [""]
+
+
+def test_cli_is_a_drop_in(wm, samples):
+    """stdin cu8 -> stdout lines through the plain-C CLI, same switches as the reference."""
+    env = dict(os.environ, WMBUS_FIXED_TS="1")
+    for name, flags in (BUNDLED_CASES[0], BUNDLED_CASES[1], BUNDLED_CASES[6], BUNDLED_CASES[12]):
+        cu8 = np.fromfile(os.path.join(SAMPLES, name), np.uint8)
+        p = subprocess.run([wm.CLI_PATH] + flags + ["-B", str(1 << 19)], input=cu8.tobytes(), capture_output=True, env=env)
+        assert p.returncode == 0, p.stderr
+        assert p.stdout.decode() == BUNDLED[f"{name}|{' '.join(flags)}"]
+
+
+def test_full_size_batch_properties(wm):
+    """BASELINE-size streams (2^22 samples) x 32: every complete strong burst comes out CRC-ok, nothing
+    CRC-ok comes out that was not sent, and the result does not depend on the segmentation."""
+    n_streams, n = 32, 1 << 22
+    caps, sent = [], []
+    for s in range(n_streams):
+        c, fr = wm.synth_capture(seed=0xC0FFEE + s, n_samples=n, kinds=7, frames_per_s=20.0)
+        caps.append(c); sent.append(fr)
+    outs = []
+    for seg in (65536, 16384):
+        with wm.Receiver(n_streams=n_streams, max_push_bytes=2 * n, seg_len=seg) as rx:
+            outs.append(rx.run(caps))
+    assert outs[0] == outs[1]
+    for s in range(n_streams):
+        good = {l.split(";")[-1][2:] for l in outs[0][s].splitlines() if l.split(";")[2] == "1"}
+        tx = {f["telegram"].hex() for f in sent[s]}
+        assert good <= tx
+        assert all(f["telegram"].hex() in good for f in sent[s] if f["complete"])
