@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py -- cu8 IQ -> datagrams throughput of the MI355X back end (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[3], per GPU): 1024 independent synthetic 1.6 MS/s cu8 captures of
+2^22 IQ samples each (SURVEY.md 8(d) recipe: noise + T1/C1 bursts, ~20 bursts/s), resident in HBM
+before the timed region.  One "step" = one pass of the whole hot path over that batch: demodulation,
+clock recovery, both framers, burst extraction, D2H of the bursts and the host packet decoders
+(datagram text produced).  With N > 1 every rank owns its own 1024 captures on its own GPU
+(file-per-GPU sharding, no data-path collective): weak scaling; torch.distributed (RCCL) is used
+only for the barrier and the max-over-ranks of the elapsed time.
+
+The JSON line also carries
+  roofline     -- for the dominant kernel (k1_demod): algorithmic bytes (2 B per input IQ sample)
+                  per launch / its HIP-event duration measured on the library's own stream,
+                  against 8 TB/s HBM; `traffic` = HBM bytes per launch from the committed
+                  rocprofv3 PMC pass (profiles/), null if that file is absent;
+  cpu_baseline -- the unmodified reference (oracle/_ref/rtl_wmbus) timed on this host's cores on a
+                  bounded sample of the same captures (rank 0, N = 1 only).
+"""
+import argparse
+import concurrent.futures as cf
+import importlib
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy rate)
+BYTES_PER_SAMPLE = 2            # one u8 I + one u8 Q, read once
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--streams", type=int, default=1024, help="captures per GPU")
+    ap.add_argument("--samples", type=int, default=1 << 22, help="IQ samples per capture per step")
+    ap.add_argument("--seg-len", type=int, default=0)
+    ap.add_argument("--rla-seg-len", type=int, default=0)
+    ap.add_argument("--warmup-s1", type=int, default=0)
+    ap.add_argument("--warmup-t1c1", type=int, default=0)
+    ap.add_argument("--contexts", type=int, default=2, help="receiver contexts per GPU (GPU / host-decode overlap)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(caps, n_samples):
+    """Reference binary, one process per core, each over whole captures; bounded to ~15 s."""
+    import oracle_ffi as O
+    exe, kind = (O.REF_BIN, "reference") if os.path.exists(O.REF_BIN) else (O.ORACLE_CLI, "port")
+    if not os.path.exists(exe):
+        return None
+    cores = min(os.cpu_count() or 1, 64)
+    # single-core probe to size the sample
+    t = time.perf_counter()
+    subprocess.run([exe], input=caps[0].tobytes(), stdout=subprocess.DEVNULL, check=True)
+    one = time.perf_counter() - t
+    per_worker = max(1, min(64, int(12.0 / max(one, 1e-3))))
+    jobs = [caps[(w * per_worker + k) % len(caps)] for w in range(cores) for k in range(per_worker)]
+
+    def work(idx):
+        for k in range(per_worker):
+            subprocess.run([exe], input=jobs[idx * per_worker + k].tobytes(), stdout=subprocess.DEVNULL, check=True)
+
+    t = time.perf_counter()
+    with cf.ThreadPoolExecutor(cores) as ex:
+        list(ex.map(work, range(cores)))
+    dt = time.perf_counter() - t
+    total = cores * per_worker * n_samples
+    return {"value": round(total / dt / 1e6, 2), "unit": "Msamples/s", "cores": cores, "kind": kind,
+            "single_core_msamples_s": round(n_samples / one / 1e6, 2),
+            "sample": f"{cores} processes x {per_worker} captures of {n_samples} IQ samples "
+                      f"({exe.split('/')[-1]} -O3, default switches), {dt:.1f} s wall"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    dist = None
+    if world > 1:
+        import torch                      # before the HIP library: one HIP runtime per process
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    wm = importlib.import_module("rtl-wmbus_amd")
+    if wm.device_count() < 1:
+        raise SystemExit("bench.py: no HIP device (the back end has no CPU fallback)")
+
+    S, n = a.streams, a.samples
+    nctx = max(1, min(a.contexts, S))
+    per_ctx = [S // nctx + (1 if i < S % nctx else 0) for i in range(nctx)]
+    push_bytes = 2 * n
+
+    # ---- synthetic captures (host, multi-threaded), then resident in HBM -------------------------
+    t0 = time.perf_counter()
+    caps = [None] * S
+
+    def gen(s):
+        caps[s] = wm.synth_capture(seed=0xC0FFEE + rank * S + s, n_samples=n, kinds=wm.T1 | wm.C1A | wm.C1B,
+                                   frames_per_s=20.0)[0]
+
+    with cf.ThreadPoolExecutor(min(os.cpu_count() or 1, 64)) as ex:
+        list(ex.map(gen, range(S)))
+    t_gen = time.perf_counter() - t0
+    rxs, base = [], 0
+    for i in range(nctx):
+        rx = wm.Receiver(n_streams=per_ctx[i], max_push_bytes=push_bytes, device=local, seg_len=a.seg_len, rla_seg_len=a.rla_seg_len,
+                         warmup_s1=a.warmup_s1, warmup_t1c1=a.warmup_t1c1, show_algorithm=True, fixed_timestamp=True)
+        for s in range(per_ctx[i]):
+            rx.stage(s, caps[base + s])
+        rxs.append(rx)
+        base += per_ctx[i]
+
+    pool = cf.ThreadPoolExecutor(nctx)
+
+    def one(rx):
+        rx.process(push_bytes)
+        rx.collect()
+        return rx.lines_count(), rx.timing()
+
+    def step():
+        """One pass over every capture of this GPU; contexts overlap GPU work with host decode."""
+        res = [one(rxs[0])] if nctx == 1 else list(pool.map(one, rxs))
+        return sum(r[0] for r in res), [r[1] for r in res]
+
+    for _ in range(a.warmup):
+        step()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+            import torch
+            torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    lines_total, demod_ms, k1_launches, tim_acc = 0, 0.0, 0, []
+    for _ in range(a.steps):
+        ln, tims = step()
+        lines_total += ln
+        for tm in tims:
+            demod_ms += tm["demod_ms"]; k1_launches += 1
+        tim_acc.append(tims)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_samples = world * S * n * a.steps
+    value = total_samples / elapsed / 1e6
+    # roofline of the dominant kernel: one launch processes per_ctx streams x n samples
+    samples_per_launch = S * n / nctx
+    k1_avg_s = demod_ms / max(1, k1_launches) / 1e3
+    achieved = BYTES_PER_SAMPLE * samples_per_launch / k1_avg_s / 1e9 if k1_avg_s > 0 else 0.0
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tf):
+        try:
+            traffic = json.load(open(tf)).get("k1_demod_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        last = tim_acc[-1]
+        out = {
+            "metric": "Msamples/s cu8 IQ->datagrams, 1024x1.6MS/s streams; %HBM roofline",
+            "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{S} synthetic 1.6 MS/s cu8 captures x {n} IQ samples per GPU, T1+C1 bursts, "
+                                   f"default switches (T1/C1 + S1 chains, time2 + run-length framers), HBM-resident input",
+                       "streams_per_gpu": S, "samples_per_stream": n, "contexts_per_gpu": nctx,
+                       "parallelism": f"file-per-GPU x{world}, no collective"},
+            "hbm_roofline_pct_whole_job": round(100.0 * BYTES_PER_SAMPLE * value * 1e6 / world / 1e9 / HBM_PEAK_GBPS, 3),
+            "datagrams_per_step": lines_total // max(1, a.steps),
+            "roofline": {"bound": "hbm", "kernel": "k1_demod", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": int(BYTES_PER_SAMPLE * samples_per_launch),
+                         "avg_launch_ms": round(k1_avg_s * 1e3, 3)},
+            "stage_ms_last_step": [{k: round(v, 3) if isinstance(v, float) else v for k, v in t.items()} for t in last],
+            "setup_s": {"generate": round(t_gen, 1)},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(caps, n)
+        if not a.no_check:
+            import oracle_ffi as O
+            ok = True
+            rx = rxs[0]
+            # fresh receiver for a strict end-to-end check of two captures against the oracle
+            with wm.Receiver(n_streams=2, max_push_bytes=push_bytes, device=local, seg_len=a.seg_len) as chk:
+                got = chk.run([caps[0], caps[1]])
+            for s in (0, 1):
+                ok &= got[s] == O.run(caps[s], O.make_opts())["text"]
+            out["parity_check"] = "2 captures identical to the oracle" if ok else "MISMATCH"
+        print(json.dumps(out), flush=True)
+    for rx in rxs:
+        rx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

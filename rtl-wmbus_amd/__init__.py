@@ -39,7 +39,8 @@ class Cfg(ctypes.Structure):
                 ("remove_dc", ctypes.c_int), ("t1c1_enabled", ctypes.c_int), ("s1_enabled", ctypes.c_int),
                 ("rla_enabled", ctypes.c_int), ("time2_enabled", ctypes.c_int), ("show_algorithm", ctypes.c_int),
                 ("fixed_timestamp", ctypes.c_int), ("n_streams", ctypes.c_uint), ("device", ctypes.c_int),
-                ("max_push_bytes", ctypes.c_size_t), ("seg_len", ctypes.c_uint), ("warmup_t1c1", ctypes.c_uint),
+                ("max_push_bytes", ctypes.c_size_t), ("seg_len", ctypes.c_uint), ("rla_seg_len", ctypes.c_uint),
+                ("warmup_t1c1", ctypes.c_uint),
                 ("warmup_s1", ctypes.c_uint), ("rla_lookback", ctypes.c_uint), ("host_threads", ctypes.c_uint),
                 ("keep_taps", ctypes.c_int)]
 
@@ -108,7 +109,7 @@ class Receiver:
 
     def __init__(self, n_streams=1, max_push_bytes=4 << 20, decimation=2, simultaneous=False, accurate_atan=True,
                  remove_dc=False, t1c1=True, s1=True, rla=True, time2=True, show_algorithm=True, device=0,
-                 seg_len=0, warmup_t1c1=0, warmup_s1=0, rla_lookback=0, host_threads=0, fixed_timestamp=True):
+                 seg_len=0, rla_seg_len=0, warmup_t1c1=0, warmup_s1=0, rla_lookback=0, host_threads=0, fixed_timestamp=True):
         L = lib()
         c = Cfg()
         L.wmbus_default_cfg(ctypes.byref(c))
@@ -116,7 +117,8 @@ class Receiver:
         c.t1c1_enabled, c.s1_enabled, c.rla_enabled, c.time2_enabled = int(t1c1), int(s1), int(rla), int(time2)
         c.show_algorithm, c.fixed_timestamp = int(show_algorithm), int(fixed_timestamp)
         c.n_streams, c.device, c.max_push_bytes = n_streams, device, max_push_bytes
-        c.seg_len, c.warmup_t1c1, c.warmup_s1, c.rla_lookback, c.host_threads = seg_len, warmup_t1c1, warmup_s1, rla_lookback, host_threads
+        c.seg_len, c.rla_seg_len, c.warmup_t1c1, c.warmup_s1 = seg_len, rla_seg_len, warmup_t1c1, warmup_s1
+        c.rla_lookback, c.host_threads = rla_lookback, host_threads
         c.keep_taps = 1
         self.cfg = c
         self.n_streams = n_streams
@@ -172,6 +174,9 @@ class Receiver:
         text = ctypes.string_at(t, sz.value) if sz.value else b""
         return [dict(stream=p[i].stream, chain=p[i].chain, algo=p[i].algo, crc_ok=p[i].crc_ok, sample=p[i].sample,
                      text=text[p[i].text_off:p[i].text_off + p[i].text_len].decode()) for i in range(n)]
+
+    def lines_count(self):
+        return int(lib().wmbus_lines(self._h, None))
 
     def timing(self):
         t = Timing()

@@ -43,8 +43,8 @@ struct wmbus_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
     /* geometry */
-    uint32_t d = 2, S = 1, C = 65536, Mcap = 0, nseg_cap = 0, ntiles_cap = 0, RF = 8;
-    uint32_t cap_t2 = 0, cap_rl = 0, flags = 0;
+    uint32_t d = 2, S = 1, C[2] = {8192, 32768}, Mcap = 0, nseg_cap[2] = {0, 0}, ntiles_cap = 0, RF = 8;
+    uint32_t cap[2] = {0, 0}, flags = 0;
     uint64_t in_stride = 0, n0 = 0;
     size_t staged = 0;
     /* device buffers */
@@ -189,23 +189,28 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
     if (hipSetDevice(cfg->device) != hipSuccess) return bail(fail(c, WMBUS_EDEVICE, "hipSetDevice(%d) failed", cfg->device));
 
     c->d = cfg->decimation; c->S = cfg->n_streams;
-    c->C = cfg->seg_len ? cfg->seg_len : 65536u;
-    if (c->C < 1024u || c->C > 65536u || (c->C & (c->C - 1))) return bail(fail(c, WMBUS_EINVAL, "seg_len must be a power of two in [1024, 65536]"));
-    c->cfg.warmup_t1c1 = cfg->warmup_t1c1 ? (cfg->warmup_t1c1 + 3u) & ~3u : 24576u;
-    c->cfg.warmup_s1 = cfg->warmup_s1 ? (cfg->warmup_s1 + 3u) & ~3u : 49152u;
-    c->cfg.rla_lookback = cfg->rla_lookback ? cfg->rla_lookback : 1024u;
+    c->C[1] = cfg->seg_len ? cfg->seg_len : 32768u;
+    c->C[0] = cfg->rla_seg_len ? cfg->rla_seg_len : 8192u;
+    for (int a = 0; a < 2; a++)
+        if (c->C[a] < 1024u || c->C[a] > 65536u || (c->C[a] & (c->C[a] - 1)))
+            return bail(fail(c, WMBUS_EINVAL, "seg_len / rla_seg_len must be powers of two in [1024, 65536]"));
+    c->cfg.warmup_t1c1 = cfg->warmup_t1c1 ? (cfg->warmup_t1c1 + 31u) & ~31u : 24576u;   /* whole 32-sample blocks */
+    c->cfg.warmup_s1 = cfg->warmup_s1 ? (cfg->warmup_s1 + 31u) & ~31u : 49152u;
+    c->cfg.rla_lookback = cfg->rla_lookback ? (cfg->rla_lookback + 31u) & ~31u : 1024u;
     c->flags = (cfg->simultaneous ? WM_F_SHIFT : 0) | (cfg->accurate_atan ? WM_F_ACCURATE : 0) | (cfg->remove_dc ? WM_F_DC : 0) |
                (cfg->t1c1_enabled ? WM_F_T1C1 : 0) | (cfg->s1_enabled ? WM_F_S1 : 0) | (cfg->rla_enabled ? WM_F_RLA : 0) |
                (cfg->time2_enabled ? WM_F_T2A : 0);
     /* tile: 2048 decimated samples up to d = 2, fewer for larger d so the staging fits in LDS */
-    c->RF = c->d <= 2 ? 8 : c->d <= 5 ? 4 : 2;
+    c->RF = c->d <= 5 ? 4 : 2;   /* RF = 8 needs 190 VGPRs (2 waves/SIMD) and measured 1.8x slower */
+    if (const char *e = getenv("WMBUS_K1_RF")) { const int v = atoi(e); if (v == 8 || v == 4 || v == 2) c->RF = (uint32_t)v; }
     const uint32_t T = 256 * c->RF;
     const uint64_t max_samples = cfg->max_push_bytes / 2;
     c->Mcap = (uint32_t)(((max_samples / c->d + 1 + 8) + 127) / 128 * 128);
     c->Mcap = (c->Mcap + T - 1) / T * T;                 /* whole tiles: partial tiles still store full runs */
-    c->nseg_cap = (c->Mcap + c->C - 1) / c->C;
+    for (int a = 0; a < 2; a++) c->nseg_cap[a] = (c->Mcap + c->C[a] - 1) / c->C[a];
     c->ntiles_cap = c->Mcap / T;
-    c->cap_t2 = c->C / 4 + 8; c->cap_rl = c->C / 2 + 8;
+    c->cap[1] = c->C[1] / 4 + 8;   /* time2: the lock logic needs >= 4 samples per chip */
+    c->cap[0] = c->C[0] + 8;       /* run-length: bit length tracking may shrink the chip period towards one sample */
     c->in_stride = (WM_HIST_BYTES + cfg->max_push_bytes + WM_IN_SLACK + 255) / 256 * 256;
 
     const uint64_t rows = 2ull * c->S;
@@ -221,16 +226,15 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
     A(dalloc(&c->d_ema_head, (size_t)rows * c->ntiles_cap));
     A(dalloc(&c->d_ema_tail, (size_t)rows * c->ntiles_cap));
     A(dalloc(&c->d_ema_carry, (size_t)rows));
-    const size_t caps[2] = {c->cap_rl, c->cap_t2};
     const size_t stw[2] = {sizeof(WmRlaState), sizeof(WmClkState)};
     for (int a = 0; a < 2; a++) {
-        A(dalloc(&c->d_chips[a], (size_t)rows * c->nseg_cap * caps[a]));
-        A(dalloc(&c->d_counts[a], (size_t)rows * c->nseg_cap));
-        A(hipMalloc(&c->d_st_start[a], (size_t)rows * c->nseg_cap * stw[a]));
-        A(hipMalloc(&c->d_st_final[a], (size_t)rows * c->nseg_cap * stw[a]));
+        A(dalloc(&c->d_chips[a], (size_t)rows * c->nseg_cap[a] * c->cap[a]));
+        A(dalloc(&c->d_counts[a], (size_t)rows * c->nseg_cap[a]));
+        A(hipMalloc(&c->d_st_start[a], (size_t)rows * c->nseg_cap[a] * stw[a]));
+        A(hipMalloc(&c->d_st_final[a], (size_t)rows * c->nseg_cap[a] * stw[a]));
         A(hipMalloc(&c->d_st_carry[a], (size_t)rows * stw[a]));
     }
-    A(dalloc(&c->d_list, (size_t)rows * c->nseg_cap));
+    A(dalloc(&c->d_list, (size_t)rows * std::max(c->nseg_cap[0], c->nseg_cap[1])));
     A(dalloc(&c->d_scalars, (size_t)SC_COUNT));
     const uint64_t dec_total = (uint64_t)c->S * c->Mcap;
     c->hdr_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(65536, dec_total / 1024), 1u << 24);
@@ -301,24 +305,25 @@ int wmbus_stage(wmbus_ctx *c, unsigned stream, const uint8_t *cu8, size_t nbytes
 static int run_segments(wmbus_ctx *c, int algo, K2Args a, float *ms, unsigned *reruns)
 {
     const WmPush &g = a.g;
-    const uint32_t lanes = 2u * g.nseg * g.S;
+    const uint32_t lanes = 2u * g.nseg[algo] * g.S;
     const uint32_t words = (algo == WMBUS_ALGO_RLA ? sizeof(WmRlaState) : sizeof(WmClkState)) / 4;
     auto launch = [&](const uint32_t *list, uint32_t n) {
         a.list = list; a.n_lanes = n;
         if (algo == WMBUS_ALGO_RLA) hipLaunchKernelGGL(k2_rla, dim3((n + 63) / 64), dim3(64), 0, c->stream, a);
-        else hipLaunchKernelGGL(k2_clock, dim3((n + 63) / 64), dim3(64), 0, c->stream, a);
+        else if (c->flags & WM_F_DC) hipLaunchKernelGGL(k2_clock<true>, dim3((n + 63) / 64), dim3(64), 0, c->stream, a);
+        else hipLaunchKernelGGL(k2_clock<false>, dim3((n + 63) / 64), dim3(64), 0, c->stream, a);
     };
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     launch(nullptr, lanes);
     for (unsigned round = 0;; round++) {
         HIPCHK(c, hipMemsetAsync(c->d_scalars + SC_NLIST, 0, sizeof(uint32_t), c->stream));
-        hipLaunchKernelGGL(k2_verify, dim3((lanes + 255) / 256), dim3(256), 0, c->stream, g,
+        hipLaunchKernelGGL(k2_verify, dim3((lanes + 255) / 256), dim3(256), 0, c->stream, g, (uint32_t)algo,
                            (const uint32_t *)a.st_start, (const uint32_t *)a.st_final, words, c->d_list, c->d_scalars + SC_NLIST);
         HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, SC_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         const uint32_t n = c->h_scalars[SC_NLIST];
         if (n == 0) break;
-        if (round > g.nseg + 1) return fail(c, WMBUS_EDEVICE, "segment verification did not converge");
+        if (round > g.nseg[algo] + 1) return fail(c, WMBUS_EDEVICE, "segment verification did not converge");
         *reruns += n;
         launch(c->d_list, n);
     }
@@ -328,7 +333,7 @@ static int run_segments(wmbus_ctx *c, int algo, K2Args a, float *ms, unsigned *r
     /* carry the exact end state into the next push */
     const uint32_t rows = 2u * g.S;
     hipLaunchKernelGGL(k_carry, dim3((rows + 255) / 256), dim3(256), 0, c->stream, (const uint32_t *)a.st_final,
-                       (uint32_t *)a.st_carry, words, rows, g.nseg_cap, g.nseg);
+                       (uint32_t *)a.st_carry, words, rows, g.nseg_cap[algo], g.nseg[algo]);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -346,9 +351,11 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
     g.n_new = n_new; g.M = (uint32_t)((c->n0 + n_new) / c->d - g.m0);
     g.Mcap = c->Mcap; g.d = c->d; g.S = c->S; g.lut_n = 32 * c->d;
     g.lut_phase0 = (uint32_t)((13ull * (c->n0 % g.lut_n)) % g.lut_n);
-    g.flags = c->flags; g.seg_len = c->C; g.nseg = (g.M + c->C - 1) / c->C; g.nseg_cap = c->nseg_cap;
+    g.flags = c->flags;
+    for (int al = 0; al < 2; al++) {
+        g.seg_len[al] = c->C[al]; g.nseg[al] = (g.M + c->C[al] - 1) / c->C[al]; g.nseg_cap[al] = c->nseg_cap[al]; g.cap[al] = c->cap[al];
+    }
     g.warm[0] = c->cfg.warmup_t1c1; g.warm[1] = c->cfg.warmup_s1; g.lookback = c->cfg.rla_lookback;
-    g.cap_t2 = c->cap_t2; g.cap_rl = c->cap_rl;
     c->last = g; c->have_last = true;
     c->n_hdr = c->n_words = 0;
 
@@ -383,7 +390,7 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
             rc = run_segments(c, WMBUS_ALGO_RLA, a, &c->tim.rla_ms, &c->tim.rla_reruns);
             if (rc) return rc;
         } else {
-            HIPCHK(c, hipMemsetAsync(c->d_counts[0], 0, (size_t)2 * c->S * c->nseg_cap * sizeof(uint32_t), c->stream));
+            HIPCHK(c, hipMemsetAsync(c->d_counts[0], 0, (size_t)2 * c->S * c->nseg_cap[0] * sizeof(uint32_t), c->stream));
         }
 
         /* K3: bursts */
@@ -592,8 +599,8 @@ long wmbus_read_chips(wmbus_ctx *c, int chain, int algo, unsigned stream, uint32
     uint32_t *d_dst = nullptr, *d_n = nullptr; uint64_t *d_pos = nullptr;
     if (hipMalloc((void **)&d_dst, max_elems * 4) != hipSuccess || hipMalloc((void **)&d_pos, max_elems * 8) != hipSuccess ||
         hipMalloc((void **)&d_n, 4) != hipSuccess) return WMBUS_ENOMEM;
-    hipLaunchKernelGGL(k4_flatten, dim3(1), dim3(1), 0, c->stream, c->last, c->d_chips[algo], c->d_counts[algo],
-                       algo == WMBUS_ALGO_RLA ? c->cap_rl : c->cap_t2, (uint32_t)chain, stream, d_dst, d_pos, (uint32_t)max_elems, d_n);
+    hipLaunchKernelGGL(k4_flatten, dim3(1), dim3(1), 0, c->stream, c->last, (uint32_t)algo, c->d_chips[algo], c->d_counts[algo],
+                       c->cap[algo], (uint32_t)chain, stream, d_dst, d_pos, (uint32_t)max_elems, d_n);
     uint32_t n = 0;
     hipStreamSynchronize(c->stream);
     hipMemcpy(&n, d_n, 4, hipMemcpyDeviceToHost);

@@ -38,7 +38,7 @@
 struct WmClkState {
     float    h[6];
     float    dc_x, dc_y;
-    uint32_t clk;          /* bit0 = previous clock high, bits 2:1 = clock_lock (0..3) */
+    uint32_t clk;          /* the last three clock levels, newest in bit 0              */
     uint32_t sr;           /* time2 chip shift register, masked to the sync length     */
     uint32_t pad[2];
 };
@@ -66,12 +66,14 @@ struct WmPush {
     uint32_t lut_n;          /* 32*d                                                  */
     uint32_t lut_phase0;     /* (13*n0) mod lut_n                                     */
     uint32_t flags;          /* WM_F_*                                                */
-    uint32_t seg_len;        /* C                                                     */
-    uint32_t nseg;           /* ceil(M / C)                                           */
-    uint32_t nseg_cap;       /* segment pitch of the state / count arrays             */
+    /* time segmentation, indexed by framer (0 = run-length, 1 = clock/time2): the two kernels
+     * want different segment lengths (cheap look-back vs. long IIR warm-up) */
+    uint32_t seg_len[2];     /* C                                                     */
+    uint32_t nseg[2];        /* ceil(M / C)                                           */
+    uint32_t nseg_cap[2];    /* segment pitch of the state / count arrays             */
+    uint32_t cap[2];         /* chips per segment region                              */
     uint32_t warm[2];        /* IIR warm-up per chain                                 */
     uint32_t lookback;       /* RLA speculative lookback                              */
-    uint32_t cap_t2, cap_rl; /* chips per segment region                              */
 };
 
 enum {

@@ -307,13 +307,13 @@ __device__ __forceinline__ void record_hit(const K2Args &a, uint32_t lane, uint3
     else atomicOr(a.err, WM_ERR_BURST_OVERFLOW);
 }
 
-__device__ __forceinline__ void lane_decode(const K2Args &a, uint32_t lane, uint32_t &ch, uint32_t &stream, uint32_t &seg)
+__device__ __forceinline__ void lane_decode(const WmPush &g, uint32_t algo, uint32_t lane, uint32_t &ch, uint32_t &stream, uint32_t &seg)
 {
     /* lane = (ch * nseg + seg) * S + stream : neighbouring lanes = neighbouring streams */
-    stream = lane % a.g.S;
-    const uint32_t r = lane / a.g.S;
-    seg = r % a.g.nseg;
-    ch = r / a.g.nseg;
+    stream = lane % g.S;
+    const uint32_t r = lane / g.S;
+    seg = r % g.nseg[algo];
+    ch = r / g.nseg[algo];
 }
 
 struct IirCoef { float a1[3], a2[3], b1[3], b2[3]; };
@@ -355,20 +355,41 @@ __device__ __forceinline__ bool clk_step(WmClkState &s, const IirCoef &c, bool d
     return wm_mul(v, 1.874981046e-06f) >= 0.0f;
 }
 
+/* Exact truncating signed division for |a| < 2^24, 0 < b < 2^12 via one float reciprocal and a
+ * +-1 fix-up (the hardware integer divide is ~40 instructions and sits on the serial path). */
+__device__ __forceinline__ int wm_sdiv(int a, int b)
+{
+    const unsigned ua = (unsigned)(a < 0 ? -a : a);
+    if (ua >= (1u << 24) || (unsigned)b >= (1u << 12)) return a / b;
+    unsigned q = (unsigned)((float)ua * __frcp_rn((float)b));
+    const int r = (int)ua - (int)(q * (unsigned)b);
+    if (r < 0) q--; else if (r >= b) q++;
+    return a < 0 ? -(int)q : (int)q;
+}
+
+#define WM_RSSI_ROW 9            /* u32 words per lane in the LDS rssi staging (32 bytes + pad)  */
+
+/* Clock-recovery lane.  The reference's lock counter (rtl_wmbus.c:1092-1111: rising edge -> 1,
+ * still high -> 2, third high sample -> take the bit) is equivalent to "sample at n iff the clock
+ * levels at n-3..n are L,H,H,H" (checked exhaustively over all level sequences);
+ * the lane state keeps the last three levels. */
+template <bool DC>
 __global__ __launch_bounds__(64) void k2_clock(K2Args a)
 {
+    __shared__ uint32_t s_rssi[64 * WM_RSSI_ROW];
     uint32_t lane = blockIdx.x * 64 + threadIdx.x;
     if (lane >= a.n_lanes) return;
     const bool rerun = a.list != nullptr;
     if (rerun) lane = a.list[lane];
     const WmPush &g = a.g;
     uint32_t ch, stream, seg;
-    lane_decode(a, lane, ch, stream, seg);
+    lane_decode(g, 1, lane, ch, stream, seg);
     if (!(g.flags & (ch ? WM_F_S1 : WM_F_T1C1))) return;
 
     const uint64_t row = (uint64_t)ch * g.S + stream;
-    const uint64_t sidx = row * g.nseg_cap + seg;
-    const uint32_t mb = seg * g.seg_len, me = min(g.M, mb + g.seg_len);
+    const uint64_t sidx = row * g.nseg_cap[1] + seg;
+    const uint32_t mb = seg * g.seg_len[1], me = min(g.M, mb + g.seg_len[1]);
+    const uint32_t cap_t2 = g.cap[1];
     WmClkState *stS = (WmClkState *)a.st_start, *stF = (WmClkState *)a.st_final, *stC = (WmClkState *)a.st_carry;
 
     WmClkState s;
@@ -380,75 +401,106 @@ __global__ __launch_bounds__(64) void k2_clock(K2Args a)
         else { s = WmClkState{}; m = mb - w; }           /* speculative cold start          */
     }
     const IirCoef c = iir_coef(ch);
-    const bool dc = g.flags & WM_F_DC;
+    const bool t2a = g.flags & WM_F_T2A;
     const float *x = a.dphi + row * g.Mcap;
     const uint8_t *rs = a.rssi + row * g.Mcap;
     const uint32_t syncw = ch ? WM_SYNC_S1 : WM_SYNC_T1C1, syncm = ch ? WM_SYNC_S1_MASK : WM_SYNC_T1C1_MASK;
+    uint32_t *out = a.chips + sidx * cap_t2;
+    uint32_t *bw = a.bits + row * (g.Mcap / 32);
+    uint32_t *my_rssi = s_rssi + threadIdx.x * WM_RSSI_ROW;
+    uint32_t n_out = 0;
 
-    /* clock lock + time2 framer, rtl_wmbus.c:1092-1111 and :818-828 */
-    auto step = [&](float xin, uint32_t mm, bool emit, uint32_t &bitw, uint32_t *out, uint32_t &n_out) {
-        float soft;
-        const bool high = clk_step(s, c, dc, xin, soft);
-        const uint32_t bit = soft >= 0.0f;
-        uint32_t lock = s.clk >> 1;
-        const bool old_high = s.clk & 1u;
-        if (high && !old_high) lock = 1;
-        else if (high) {
-            if (lock < 2) lock++;
-            else if (lock == 2) {
-                lock = 3;
-                s.sr = ((s.sr << 1) | bit) & syncm;
-                if (emit && (g.flags & WM_F_T2A)) {
-                    const uint32_t val = bit | (s.sr == syncw ? 2u : 0u);
-                    if (n_out < g.cap_t2) out[n_out] = ((mm - mb) << 16) | ((uint32_t)rs[mm] << 8) | val;
-                    if (val & 2u) record_hit(a, lane, n_out);
-                    n_out++;
-                }
+    /* chips of one 32-sample block: walk the set bits of the sample mask */
+    auto emit_block = [&](uint32_t m0, uint32_t smask, uint32_t bitw, bool emit) {
+        while (smask) {
+            const uint32_t k = (uint32_t)__ffs((int)smask) - 1u;
+            smask &= smask - 1u;
+            const uint32_t bit = (bitw >> k) & 1u;
+            s.sr = ((s.sr << 1) | bit) & syncm;                       /* rtl_wmbus.c:818-828 */
+            if (emit && t2a) {
+                const uint32_t val = bit | (s.sr == syncw ? 2u : 0u);
+                const uint32_t rssi = ((const uint8_t *)my_rssi)[k];
+                if (n_out < cap_t2) out[n_out] = ((m0 + k - mb) << 16) | (rssi << 8) | val;
+                if (val & 2u) record_hit(a, lane, n_out);
+                n_out++;
             }
         }
-        s.clk = (lock << 1) | (high ? 1u : 0u);
-        bitw |= bit << (mm & 31u);
     };
 
-    uint32_t n_out = 0, bitw = 0;
-    uint32_t *out = a.chips + sidx * g.cap_t2;
-    /* warm-up: [m, mb) -- no output */
-    for (; m < mb; m += 4) {
-        const float4 v = *(const float4 *)(x + m);
-        step(v.x, m, false, bitw, out, n_out); step(v.y, m + 1, false, bitw, out, n_out);
-        step(v.z, m + 2, false, bitw, out, n_out); step(v.w, m + 3, false, bitw, out, n_out);
-    }
-    stS[sidx] = s;
-    uint32_t *bw = a.bits + row * (g.Mcap / 32);
-    bitw = 0;
-    for (m = mb; m < me; m += 4) {
-        const float4 v = *(const float4 *)(x + m);
-        const float vv[4] = {v.x, v.y, v.z, v.w};
+    /* Full 32-sample blocks; the next block's soft symbols and RSSI bytes are fetched while the
+     * current one is processed (each lane walks its own row: nothing else hides HBM latency). */
+    const uint32_t me_full = mb + ((me - mb) & ~31u);
+    float4 cur[8], nxt[8];
+    uint4 r0, r1, nr0 = {}, nr1 = {};
 #pragma unroll
-        for (int k = 0; k < 4; k++)
-            if (m + k < me) step(vv[k], m + k, true, bitw, out, n_out);
-        if (((m + 4) & 31u) == 0 || m + 4 >= me) { bw[m >> 5] = bitw; bitw = 0; }
+    for (int k = 0; k < 8; k++) cur[k] = *(const float4 *)(x + m + 4 * k);
+    r0 = *(const uint4 *)(rs + m); r1 = *(const uint4 *)(rs + m + 16);
+    for (; m < me_full; m += 32) {
+        if (m + 32 < me_full) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) nxt[k] = *(const float4 *)(x + m + 32 + 4 * k);
+            nr0 = *(const uint4 *)(rs + m + 32); nr1 = *(const uint4 *)(rs + m + 48);
+        }
+        const bool emit = m >= mb;
+        if (m == mb) stS[sidx] = s;                      /* state the main loop starts from */
+        if (emit) {
+            my_rssi[0] = r0.x; my_rssi[1] = r0.y; my_rssi[2] = r0.z; my_rssi[3] = r0.w;
+            my_rssi[4] = r1.x; my_rssi[5] = r1.y; my_rssi[6] = r1.z; my_rssi[7] = r1.w;
+        }
+        uint32_t bitw = 0, smask = 0, hist = s.clk;
+#pragma unroll
+        for (int k = 0; k < 32; k++) {
+            const float xin = k & 2 ? (k & 1 ? cur[k >> 2].w : cur[k >> 2].z) : (k & 1 ? cur[k >> 2].y : cur[k >> 2].x);
+            float soft;
+            const uint32_t high = clk_step(s, c, DC, xin, soft);
+            hist = ((hist << 1) | high) & 0xFu;
+            bitw |= (uint32_t)(soft >= 0.0f) << k;                   /* slicer, rtl_wmbus.c:1059 */
+            smask |= (uint32_t)(hist == 7u) << k;
+        }
+        s.clk = hist & 7u;
+        if (emit) bw[m >> 5] = bitw;
+        emit_block(m, smask, bitw, emit);
+#pragma unroll
+        for (int k = 0; k < 8; k++) cur[k] = nxt[k];
+        r0 = nr0; r1 = nr1;
+    }
+    if (m == mb) stS[sidx] = s;                          /* segment shorter than one block */
+    if (m < me) {                                        /* ragged tail of the last segment */
+        uint32_t bitw = 0, smask = 0, hist = s.clk;
+        for (uint32_t k = 0; m + k < me; k++) {
+            float soft;
+            const uint32_t high = clk_step(s, c, DC, x[m + k], soft);
+            hist = ((hist << 1) | high) & 0xFu;
+            bitw |= (uint32_t)(soft >= 0.0f) << k;
+            smask |= (uint32_t)(hist == 7u) << k;
+            ((uint8_t *)my_rssi)[k] = rs[m + k];
+        }
+        s.clk = hist & 7u;
+        bw[m >> 5] = bitw;
+        emit_block(m, smask, bitw, true);
     }
     stF[sidx] = s;
     a.counts[sidx] = n_out;
-    if (n_out > g.cap_t2) atomicOr(a.err, WM_ERR_CHIP_OVERFLOW);
+    if (n_out > cap_t2) atomicOr(a.err, WM_ERR_CHIP_OVERFLOW);
 }
 
 /* Run-length framer lane (rtl_wmbus.c:640-702 S1, :729-803 T1/C1). */
 __global__ __launch_bounds__(64) void k2_rla(K2Args a)
 {
+    __shared__ uint32_t s_rssi[64 * WM_RSSI_ROW];
     uint32_t lane = blockIdx.x * 64 + threadIdx.x;
     if (lane >= a.n_lanes) return;
     const bool rerun = a.list != nullptr;
     if (rerun) lane = a.list[lane];
     const WmPush &g = a.g;
     uint32_t ch, stream, seg;
-    lane_decode(a, lane, ch, stream, seg);
+    lane_decode(g, 0, lane, ch, stream, seg);
     if (!(g.flags & (ch ? WM_F_S1 : WM_F_T1C1))) return;
 
     const uint64_t row = (uint64_t)ch * g.S + stream;
-    const uint64_t sidx = row * g.nseg_cap + seg;
-    const uint32_t mb = seg * g.seg_len, me = min(g.M, mb + g.seg_len);
+    const uint64_t sidx = row * g.nseg_cap[0] + seg;
+    const uint32_t mb = seg * g.seg_len[0], me = min(g.M, mb + g.seg_len[0]);
+    const uint32_t cap_rl = g.cap[0];
     WmRlaState *stS = (WmRlaState *)a.st_start, *stF = (WmRlaState *)a.st_final, *stC = (WmRlaState *)a.st_carry;
     const WmRlaState reset = {0, 8 * 256, 0, 2u, 0u, 0u, 24, 24};   /* :628-637 / :717-726, reset pending */
 
@@ -460,82 +512,85 @@ __global__ __launch_bounds__(64) void k2_rla(K2Args a)
 
     const uint32_t *bw = a.bits + row * (g.Mcap / 32);
     const uint8_t *rs = a.rssi + row * g.Mcap;
-    uint32_t *out = a.chips + sidx * g.cap_rl;
+    uint32_t *out = a.chips + sidx * cap_rl;
+    uint32_t *my_rssi = s_rssi + threadIdx.x * WM_RSSI_ROW;
     uint32_t n_out = 0;
     const bool s1 = ch != 0;
     const uint32_t syncw = s1 ? WM_SYNC_S1 : WM_SYNC_T1C1, syncm = s1 ? WM_SYNC_S1_MASK : WM_SYNC_T1C1_MASK;
 
-    auto emit_chips = [&](int unit, int half, uint32_t mm, bool emit) -> int {
-        int n = 0;
-        const uint32_t level = s.state & 1u;
-        const uint32_t rssi = rs[mm];
-        while (s.run > half) {
-            s.run -= unit;
-            s.sr = ((s.sr << 1) | level) & syncm;
-            if (emit) {
-                const uint32_t val = level | (s.sr == syncw ? 2u : 0u) | ((s.state & 2u) ? 4u : 0u);
-                if (n_out < g.cap_rl) out[n_out] = ((mm - mb) << 16) | (rssi << 8) | val;
-                if (val & 2u) record_hit(a, lane, n_out);
-                n_out++;
+    uint32_t word = bw[m >> 5], nword = 0;
+    uint4 r0 = *(const uint4 *)(rs + m), r1 = *(const uint4 *)(rs + m + 16), nr0 = {}, nr1 = {};
+    for (; m < me; m += 32) {
+        const bool more = m + 32 < me;
+        if (more) { nword = bw[(m >> 5) + 1]; nr0 = *(const uint4 *)(rs + m + 32); nr1 = *(const uint4 *)(rs + m + 48); }
+        const bool emit = m >= mb;
+        if (m == mb) stS[sidx] = s;
+        my_rssi[0] = r0.x; my_rssi[1] = r0.y; my_rssi[2] = r0.z; my_rssi[3] = r0.w;
+        my_rssi[4] = r1.x; my_rssi[5] = r1.y; my_rssi[6] = r1.z; my_rssi[7] = r1.w;
+        const uint32_t kend = min(32u, me - m);
+        for (uint32_t k = 0; k < kend; k++) {
+            const uint32_t bit = (word >> k) & 1u;
+            uint32_t st;
+            if (!s1) { s.raw = ((s.raw << 1) | bit) & 0x3Fu; st = __popc(s.raw) >= 3; }        /* :733, LUT :126-144 */
+            else { s.raw = ((s.raw << 1) | bit) & 0xFu; st = (0xFEEAu >> s.raw) & 1u; }          /* LUT :149-154 */
+            if ((s.state & 1u) == st) { s.run++; continue; }
+            /* edge */
+            int unit = 0, half = 0, run0 = s.run;
+            bool rst;
+            if (!s1) {
+                rst = s.run < 5;                                                             /* :742 */
+                if (!rst) { s.run *= 256; unit = s.bitlen; half = unit / 2; rst = s.run <= half; }   /* :752-756 */
+            } else {
+                unit = (s.spb0 + s.spb1) / 2;
+                rst = unit <= 12 || unit >= 36;                                              /* :659 */
+                if (!rst) { half = unit / 2; rst = run0 <= half; }                           /* :671 */
             }
-            s.state &= ~2u;                               /* reset marker consumed by this chip */
-            n++;
-        }
-        return n;
-    };
-
-    auto step = [&](uint32_t bit, uint32_t mm, bool emit) {
-        uint32_t st;
-        if (!s1) { s.raw = ((s.raw << 1) | bit) & 0x3Fu; st = __popc(s.raw) >= 3; }        /* :733, LUT :126-144 */
-        else { s.raw = ((s.raw << 1) | bit) & 0xFu; st = (0xFEEAu >> s.raw) & 1u; }          /* LUT :149-154 */
-        if ((s.state & 1u) == st) { s.run++; return; }
-        bool rst = false;
-        if (!s1) {
-            if (s.run < 5) rst = true;                                                       /* :742 */
+            if (rst) s = reset;
             else {
-                s.run *= 256;
-                const int half = s.bitlen / 2;
-                if (s.run <= half) rst = true;                                               /* :756 */
-                else {
-                    const int n = emit_chips(s.bitlen, half, mm, emit);
+                const uint32_t level = s.state & 1u;
+                const uint32_t rssi = ((const uint8_t *)my_rssi)[k];
+                int n = 0;
+                while (s.run > half) {                                                       /* :765-779 / :680-694 */
+                    s.run -= unit;
+                    s.sr = ((s.sr << 1) | level) & syncm;
+                    if (emit) {
+                        const uint32_t val = level | (s.sr == syncw ? 2u : 0u) | ((s.state & 2u) ? 4u : 0u);
+                        if (n_out < cap_rl) out[n_out] = ((m + k - mb) << 16) | (rssi << 8) | val;
+                        if (val & 2u) record_hit(a, lane, n_out);
+                        n_out++;
+                    }
+                    s.state &= ~2u;                        /* reset marker travels with the first chip */
+                    n++;
+                }
+                if (!s1) {
                     s.cum += s.run;
-                    s.bitlen += (s.run + s.cum / 16) / (32 * n);                             /* :792-796 */
+                    s.bitlen += wm_sdiv(s.run + s.cum / 16, 32 * n);                         /* :792-796 */
+                } else {
+                    const int v = wm_sdiv(run0, n);                                          /* :698 */
+                    if (level) s.spb1 = v; else s.spb0 = v;
                 }
             }
-        } else {
-            const int spb = (s.spb0 + s.spb1) / 2;
-            if (spb <= 12 || spb >= 36) rst = true;                                          /* :659 */
-            else {
-                const int half = spb / 2, run0 = s.run;
-                if (run0 <= half) rst = true;                                                /* :671 */
-                else {
-                    const int n = emit_chips(spb, half, mm, emit);
-                    if (s.state & 1u) s.spb1 = run0 / n; else s.spb0 = run0 / n;             /* :698 */
-                }
-            }
+            s.state = (s.state & 2u) | st;
+            s.run = 1;
         }
-        if (rst) s = reset;
-        s.state = (s.state & 2u) | st;
-        s.run = 1;
-    };
-
-    for (; m < mb; m++) step((bw[m >> 5] >> (m & 31u)) & 1u, m, false);
-    stS[sidx] = s;
-    for (m = mb; m < me; m++) step((bw[m >> 5] >> (m & 31u)) & 1u, m, true);
+        word = nword; r0 = nr0; r1 = nr1;
+    }
+    if (mb >= me) stS[sidx] = s;
     stF[sidx] = s;
     a.counts[sidx] = n_out;
-    if (n_out > g.cap_rl) atomicOr(a.err, WM_ERR_CHIP_OVERFLOW);
+    if (n_out > cap_rl) atomicOr(a.err, WM_ERR_CHIP_OVERFLOW);
 }
 
 /* start[seg] must equal final[seg-1]; mismatching lanes are appended to `list`. */
-__global__ void k2_verify(WmPush g, const uint32_t *st_start, const uint32_t *st_final, uint32_t words,
+__global__ void k2_verify(WmPush g, uint32_t algo, const uint32_t *st_start, const uint32_t *st_final, uint32_t words,
                           uint32_t *list, uint32_t *n_list)
 {
     const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lane >= 2u * g.nseg * g.S) return;
-    const uint32_t stream = lane % g.S, r = lane / g.S, seg = r % g.nseg, ch = r / g.nseg;
+    if (lane >= 2u * g.nseg[algo] * g.S) return;
+    uint32_t ch, stream, seg;
+    lane_decode(g, algo, lane, ch, stream, seg);
     if (!(g.flags & (ch ? WM_F_S1 : WM_F_T1C1)) || seg == 0) return;
-    const uint64_t sidx = ((uint64_t)ch * g.S + stream) * g.nseg_cap + seg;
+    const uint64_t sidx = ((uint64_t)ch * g.S + stream) * g.nseg_cap[algo] + seg;
     const uint32_t *p = st_start + sidx * words, *q = st_final + (sidx - 1) * words;
     bool same = true;
     for (uint32_t k = 0; k < words; k++) same &= p[k] == q[k];
@@ -606,27 +661,26 @@ __global__ __launch_bounds__(64) void k3_bursts(K3Args a)
         if (item - 4u * g.S >= n_hits) return;
         const uint2 h = a.hits[item - 4u * g.S];
         algo = h.x >> 31;
-        const uint32_t lane = h.x & 0x7FFFFFFFu;
-        stream = lane % g.S; const uint32_t r = lane / g.S; seg = r % g.nseg; ch = r / g.nseg;
+        lane_decode(g, algo, h.x & 0x7FFFFFFFu, ch, stream, seg);
         k = h.y; want = 0;
     }
-    const uint32_t cap = algo == 0 ? g.cap_rl : g.cap_t2;
+    const uint32_t cap = g.cap[algo], nseg = g.nseg[algo], seg_len = g.seg_len[algo];
     const uint64_t row = (uint64_t)ch * g.S + stream;
-    const uint32_t *cnt = a.counts[algo] + row * g.nseg_cap;
-    const uint32_t *base = a.chips[algo] + row * g.nseg_cap * (uint64_t)cap;
+    const uint32_t *cnt = a.counts[algo] + row * g.nseg_cap[algo];
+    const uint32_t *base = a.chips[algo] + row * g.nseg_cap[algo] * (uint64_t)cap;
     if (!cont) {                                 /* stale record of a re-run segment?         */
         if (k >= min(cnt[seg], cap) || !(base[(uint64_t)seg * cap + k] & 2u)) return;
     }
     /* chips before / from the hit in this push's chip stream */
     uint32_t before = 0, total = 0;
-    for (uint32_t s = 0; s < g.nseg; s++) { const uint32_t c = min(cnt[s], cap); if (s < seg) before += c; total += c; }
+    for (uint32_t s = 0; s < nseg; s++) { const uint32_t c = min(cnt[s], cap); if (s < seg) before += c; total += c; }
     const uint32_t chip0 = before + k;
     if (chip0 >= total) return;
     const uint32_t avail = total - chip0;        /* chips from the hit to the end of the push */
 
     auto locate = [&](uint32_t j, uint32_t &sg, uint32_t &kk) {   /* chip0 + j -> (segment, index) */
         sg = seg; kk = k + j;
-        while (sg < g.nseg) { const uint32_t c = min(cnt[sg], cap); if (kk < c) break; kk -= c; sg++; }
+        while (sg < nseg) { const uint32_t c = min(cnt[sg], cap); if (kk < c) break; kk -= c; sg++; }
     };
 
     uint32_t n;
@@ -644,11 +698,11 @@ __global__ __launch_bounds__(64) void k3_bursts(K3Args a)
     hslot = __shfl(hslot, 0); woff = __shfl(woff, 0);
     if (hslot >= a.hdr_cap || woff + n > a.words_cap) { if (ln == 0) atomicOr(a.err, WM_ERR_BURST_OVERFLOW); return; }
     uint32_t sg0, k0; locate(0, sg0, k0);
-    const uint64_t pos0 = g.m0 + (uint64_t)sg0 * g.seg_len + WM_CHIP_POS(base[(uint64_t)sg0 * cap + k0]);
+    const uint64_t pos0 = g.m0 + (uint64_t)sg0 * seg_len + WM_CHIP_POS(base[(uint64_t)sg0 * cap + k0]);
     for (uint32_t j = ln; j < n; j += 64u) {
         uint32_t sg, kk; locate(j, sg, kk);
         const uint32_t w = base[(uint64_t)sg * cap + kk];
-        const uint64_t pos = g.m0 + (uint64_t)sg * g.seg_len + WM_CHIP_POS(w);
+        const uint64_t pos = g.m0 + (uint64_t)sg * seg_len + WM_CHIP_POS(w);
         a.words[woff + j] = ((uint32_t)(pos - pos0) << 11) | (WM_CHIP_RSSI(w) << 3) | (WM_CHIP_VAL(w) & 7u);
     }
     if (ln == 0) {
@@ -660,19 +714,19 @@ __global__ __launch_bounds__(64) void k3_bursts(K3Args a)
 }
 
 /* Debug/parity helper: flatten one (chain, algo, stream) chip stream. */
-__global__ void k4_flatten(WmPush g, const uint32_t *chips, const uint32_t *counts, uint32_t cap,
+__global__ void k4_flatten(WmPush g, uint32_t algo, const uint32_t *chips, const uint32_t *counts, uint32_t cap,
                            uint32_t ch, uint32_t stream, uint32_t *dst, uint64_t *pos, uint32_t max_out, uint32_t *n_out)
 {
     if (blockIdx.x || threadIdx.x) return;
     const uint64_t row = (uint64_t)ch * g.S + stream;
     uint32_t n = 0;
-    for (uint32_t s = 0; s < g.nseg; s++) {
-        const uint32_t c = min(counts[row * g.nseg_cap + s], cap);
+    for (uint32_t s = 0; s < g.nseg[algo]; s++) {
+        const uint32_t c = min(counts[row * g.nseg_cap[algo] + s], cap);
         for (uint32_t k = 0; k < c; k++, n++)
             if (n < max_out) {
-                const uint32_t w = chips[(row * g.nseg_cap + s) * (uint64_t)cap + k];
+                const uint32_t w = chips[(row * g.nseg_cap[algo] + s) * (uint64_t)cap + k];
                 dst[n] = w;
-                if (pos) pos[n] = g.m0 + (uint64_t)s * g.seg_len + WM_CHIP_POS(w);
+                if (pos) pos[n] = g.m0 + (uint64_t)s * g.seg_len[algo] + WM_CHIP_POS(w);
             }
     }
     *n_out = n;

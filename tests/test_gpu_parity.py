@@ -65,7 +65,8 @@ def test_result_independent_of_segmentation(wm, oracle, samples, seg_len, w0, w1
     """Short warm-ups force hand-off verification failures: the re-run path must restore exactness."""
     cu8 = samples["samples2"]
     ref = oracle.run(cu8, flags_to_oracle_opts(oracle, ["-v"]), taps=True, chips=True)
-    with wm.Receiver(n_streams=1, max_push_bytes=cu8.size, seg_len=seg_len, warmup_t1c1=w0, warmup_s1=w1, rla_lookback=lb) as rx:
+    with wm.Receiver(n_streams=1, max_push_bytes=cu8.size, seg_len=seg_len, rla_seg_len=max(1024, seg_len // 4),
+                     warmup_t1c1=w0, warmup_s1=w1, rla_lookback=lb) as rx:
         text = rx.run(cu8)[0]
         tim = rx.timing()
         compare_chips(rx, ref)
@@ -154,7 +155,7 @@ def test_full_size_batch_properties(wm):
         caps.append(c); sent.append(fr)
     outs = []
     for seg in (65536, 16384):
-        with wm.Receiver(n_streams=n_streams, max_push_bytes=2 * n, seg_len=seg) as rx:
+        with wm.Receiver(n_streams=n_streams, max_push_bytes=2 * n, seg_len=seg, rla_seg_len=seg // 8) as rx:
             outs.append(rx.run(caps))
     assert outs[0] == outs[1]
     for s in range(n_streams):

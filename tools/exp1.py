@@ -1,0 +1,25 @@
+import importlib, sys, time, os, json, numpy as np
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+wm = importlib.import_module("rtl-wmbus_amd")
+S, n = int(sys.argv[1]), int(sys.argv[2])
+caps = [wm.synth_capture(seed=0xC0FFEE + s, n_samples=n, kinds=7, frames_per_s=20.0)[0] for s in range(min(S, 64))]
+def run(label, **kw):
+    env = kw.pop("env", {})
+    for k, v in env.items(): os.environ[k] = v
+    rx = wm.Receiver(n_streams=S, max_push_bytes=2 * n, **kw)
+    for s in range(S): rx.stage(s, caps[s % len(caps)])
+    best = None
+    for it in range(3):
+        t = time.perf_counter(); rx.process(2 * n); rx.collect(); dt = time.perf_counter() - t
+        tm = rx.timing(); tm["wall_ms"] = dt * 1e3
+        if best is None or dt * 1e3 < best["wall_ms"]: best = tm
+    rx.close()
+    for k in env: os.environ.pop(k)
+    print(label, {k: (round(v, 2) if isinstance(v, float) else v) for k, v in best.items()}, "Gs/s", round(S * n / best["wall_ms"] / 1e6, 1), flush=True)
+run("default")
+run("k1_rf4", env={"WMBUS_K1_RF": "4"})
+run("k1_rf2", env={"WMBUS_K1_RF": "2"})
+for c in (65536, 32768, 16384): run(f"clk_seg{c}", seg_len=c)
+for c in (16384, 8192, 4096, 2048): run(f"rla_seg{c}", rla_seg_len=c)
+run("w_s1_32k", warmup_s1=32768)
+run("w_16k_32k", warmup_t1c1=16384, warmup_s1=32768)
