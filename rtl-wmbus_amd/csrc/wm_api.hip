@@ -111,7 +111,7 @@ template <int RF> size_t k1_smem(uint32_t d, bool shift)
 {
     constexpr int T = 256 * RF, NA = T + WM_K1_HALO;
     const size_t stage = ((size_t)(NA * d + 16 + 8 + 7) / 8 * 8 + 4) * 4 * (shift ? 2 : 1);
-    const size_t y = (size_t)(NA + 8) * 4 * 4 + 512 * 4;
+    const size_t y = ((size_t)((NA + 8) + (NA + 8) / RF + 4) * 2 + (size_t)((NA + 8) + (NA + 8) / (2 * RF) + 4) * 2 + 512) * 4;
     return std::max(stage, y) + 64;
 }
 

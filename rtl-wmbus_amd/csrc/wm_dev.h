@@ -47,7 +47,7 @@ struct WmClkState {
 struct WmRlaState {
     int32_t  run, bitlen, cum;
     uint32_t state;        /* bit0 = deglitched level, bit1 = reset pending (ours) */
-    uint32_t raw;          /* raw bit window, masked (6 / 4 bits)                  */
+    uint32_t raw;          /* last five raw slicer bits in time order (bit 4 = newest) */
     uint32_t sr;           /* chip shift register, masked                          */
     int32_t  spb0, spb1;   /* S1 samples-per-bit trackers                          */
 };

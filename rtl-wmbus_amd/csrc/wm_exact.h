@@ -45,80 +45,70 @@ WM_HD float wm_div(float a, float b) { return a / b; }
 WM_HD float wm_sqrt(float a) { return sqrtf(a); }
 #endif
 
-/* fdlibm atanf for x >= 0 (the only case atan2f needs), constants given by bit pattern. */
-WM_HD float wm_atanf_pos(float x)
-{
-    const uint32_t ix = wm_f2u(x) & 0x7fffffffu;
-    const float atanhi3 = wm_u2f(0x3fc90fdau), atanlo3 = wm_u2f(0x33a22168u);
-    if (ix >= 0x4c000000u) return wm_add(atanhi3, atanlo3);      /* |x| >= 2^25 */
-    int id;
-    if (ix < 0x3ee00000u) {                                      /* |x| < 0.4375 */
-        if (ix < 0x31000000u) return x;                          /* |x| < 2^-29 */
-        id = -1;
-    } else if (ix < 0x3f980000u) {                               /* |x| < 1.1875 */
-        if (ix < 0x3f300000u) { id = 0; x = wm_div(wm_sub(wm_mul(2.0f, x), 1.0f), wm_add(2.0f, x)); }
-        else                  { id = 1; x = wm_div(wm_sub(x, 1.0f), wm_add(x, 1.0f)); }
-    } else {
-        if (ix < 0x401c0000u) { id = 2; x = wm_div(wm_sub(x, 1.5f), wm_add(1.0f, wm_mul(1.5f, x))); }
-        else                  { id = 3; x = wm_div(-1.0f, x); }
-    }
-    const float aT0 = wm_u2f(0x3eaaaaabu), aT1 = wm_u2f(0xbe4ccccdu), aT2 = wm_u2f(0x3e124925u),
-                aT3 = wm_u2f(0xbde38e38u), aT4 = wm_u2f(0x3dba2e6eu), aT5 = wm_u2f(0xbd9d8795u),
-                aT6 = wm_u2f(0x3d886b35u), aT7 = wm_u2f(0xbd6ef16bu), aT8 = wm_u2f(0x3d4bda59u),
-                aT9 = wm_u2f(0xbd15a221u), aT10 = wm_u2f(0x3c8569d7u);
-    const float z = wm_mul(x, x);
-    const float w = wm_mul(z, z);
-    float s1 = wm_add(aT8, wm_mul(w, aT10));
-    s1 = wm_add(aT6, wm_mul(w, s1));
-    s1 = wm_add(aT4, wm_mul(w, s1));
-    s1 = wm_add(aT2, wm_mul(w, s1));
-    s1 = wm_add(aT0, wm_mul(w, s1));
-    s1 = wm_mul(z, s1);
-    float s2 = wm_add(aT7, wm_mul(w, aT9));
-    s2 = wm_add(aT5, wm_mul(w, s2));
-    s2 = wm_add(aT3, wm_mul(w, s2));
-    s2 = wm_add(aT1, wm_mul(w, s2));
-    s2 = wm_mul(w, s2);
-    const float p = wm_mul(x, wm_add(s1, s2));
-    if (id < 0) return wm_sub(x, p);
-    float hi, lo;
-    switch (id) {
-    case 0:  hi = wm_u2f(0x3eed6338u); lo = wm_u2f(0x31ac3769u); break;
-    case 1:  hi = wm_u2f(0x3f490fdau); lo = wm_u2f(0x33222168u); break;
-    case 2:  hi = wm_u2f(0x3f7b985eu); lo = wm_u2f(0x33140fb4u); break;
-    default: hi = atanhi3;             lo = atanlo3;             break;
-    }
-    return wm_sub(hi, wm_sub(wm_sub(p, lo), x));
-}
+/* fdlibm atan2f (glibc 2.35 e_atan2f.c + s_atanf.c) for finite arguments, restated WITHOUT
+ * branches: on a 64-lane wavefront the five argument-reduction ranges and the special cases
+ * would otherwise all execute serially.  Every range's (numerator, denominator) pair is formed
+ * and one division is selected in; the operations that reach the result are, value for value,
+ * the ones the branchy original performs for that range:
+ *   |t| <  7/16        r = t                (t/1 is exact)             atan = r - r*(s1+s2)
+ *   7/16 .. 11/16      r = (2t-1)/(2+t)     hi/lo = atan(0.5)          atan = hi - ((r*(s1+s2) - lo) - r)
+ *   11/16 .. 19/16     r = (t-1)/(t+1)      atan(1.0)
+ *   19/16 .. 39/16     r = (t-1.5)/(1+1.5t) atan(1.5)
+ *   >= 39/16           r = -1/t             atan(inf)
+ * NaN/Inf cannot occur (the discriminator's operands are small exact rationals).
+ * The x == 1.0 shortcut of e_atan2f.c (atanf(y)) yields the same bits as the general path
+ * (y/1 is exact and atanf is odd), so it needs no case of its own. */
+WM_HD float wm_sel(int c, float a, float b) { return c ? a : b; }
 
-/* fdlibm atan2f for finite arguments (NaN/Inf cannot occur: the discriminator's operands are
- * small exact rationals). */
 WM_HD float wm_atan2f(float y, float x)
 {
     const uint32_t hx = wm_f2u(x), hy = wm_f2u(y);
     const uint32_t ix = hx & 0x7fffffffu, iy = hy & 0x7fffffffu;
     const float pi = wm_u2f(0x40490fdbu), pi_o_2 = wm_u2f(0x3fc90fdbu), pi_lo = wm_u2f(0xb3bbbd2eu);
     const uint32_t m = ((hy >> 31) & 1u) | ((hx >> 30) & 2u);
-    if (hx == 0x3f800000u) {                                      /* x == 1.0: atanf(y) */
-        const float a = wm_atanf_pos(wm_u2f(iy));
-        return (hy >> 31) ? -a : a;
-    }
-    if (iy == 0u) {                                               /* y == +-0 */
-        if (m < 2u) return y;
-        return m == 2u ? pi : -pi;                                /* pi +- tiny rounds to pi */
-    }
-    if (ix == 0u) return (hy >> 31) ? -pi_o_2 : pi_o_2;           /* x == +-0 */
+
+    const float t = wm_u2f(wm_f2u(wm_div(y, x)) & 0x7fffffffu);       /* fabsf(y/x) */
+    const uint32_t it = wm_f2u(t);
+    const int r0 = it < 0x3ee00000u, r1 = it < 0x3f300000u, r2 = it < 0x3f980000u, r3 = it < 0x401c0000u;
+    const float num = wm_sel(r0, t, wm_sel(r1, wm_sub(wm_mul(2.0f, t), 1.0f),
+                      wm_sel(r2, wm_sub(t, 1.0f), wm_sel(r3, wm_sub(t, 1.5f), -1.0f))));
+    const float den = wm_sel(r0, 1.0f, wm_sel(r1, wm_add(2.0f, t),
+                      wm_sel(r2, wm_add(t, 1.0f), wm_sel(r3, wm_add(1.0f, wm_mul(1.5f, t)), t))));
+    const float hi = wm_sel(r1, wm_u2f(0x3eed6338u), wm_sel(r2, wm_u2f(0x3f490fdau), wm_sel(r3, wm_u2f(0x3f7b985eu), wm_u2f(0x3fc90fdau))));
+    const float lo = wm_sel(r1, wm_u2f(0x31ac3769u), wm_sel(r2, wm_u2f(0x33222168u), wm_sel(r3, wm_u2f(0x33140fb4u), wm_u2f(0x33a22168u))));
+    const float r = wm_div(num, den);
+
+    const float aT0 = wm_u2f(0x3eaaaaabu), aT1 = wm_u2f(0xbe4ccccdu), aT2 = wm_u2f(0x3e124925u),
+                aT3 = wm_u2f(0xbde38e38u), aT4 = wm_u2f(0x3dba2e6eu), aT5 = wm_u2f(0xbd9d8795u),
+                aT6 = wm_u2f(0x3d886b35u), aT7 = wm_u2f(0xbd6ef16bu), aT8 = wm_u2f(0x3d4bda59u),
+                aT9 = wm_u2f(0xbd15a221u), aT10 = wm_u2f(0x3c8569d7u);
+    const float z2 = wm_mul(r, r);
+    const float w = wm_mul(z2, z2);
+    float s1 = wm_add(aT8, wm_mul(w, aT10));
+    s1 = wm_add(aT6, wm_mul(w, s1));
+    s1 = wm_add(aT4, wm_mul(w, s1));
+    s1 = wm_add(aT2, wm_mul(w, s1));
+    s1 = wm_add(aT0, wm_mul(w, s1));
+    s1 = wm_mul(z2, s1);
+    float s2 = wm_add(aT7, wm_mul(w, aT9));
+    s2 = wm_add(aT5, wm_mul(w, s2));
+    s2 = wm_add(aT3, wm_mul(w, s2));
+    s2 = wm_add(aT1, wm_mul(w, s2));
+    s2 = wm_mul(w, s2);
+    const float p = wm_mul(r, wm_add(s1, s2));
+    float z = wm_sel(r0, wm_sub(r, p), wm_sub(hi, wm_sub(wm_sub(p, lo), r)));
+    z = wm_sel(it < 0x31000000u, t, z);                                   /* |t| < 2^-29: atanf(t) = t   */
+    z = wm_sel(it >= 0x4c000000u, wm_add(wm_u2f(0x3fc90fdau), wm_u2f(0x33a22168u)), z);   /* |t| >= 2^25 */
+    /* e_atan2f.c: exponent gap shortcuts (unreachable for our operands, kept for completeness) */
     const int k = ((int)iy - (int)ix) >> 23;
-    float z;
-    if (k > 60) z = wm_add(pi_o_2, wm_mul(0.5f, pi_lo));
-    else if ((hx >> 31) && k < -60) z = 0.0f;
-    else z = wm_atanf_pos(wm_u2f(wm_f2u(wm_div(y, x)) & 0x7fffffffu));
-    switch (m) {
-    case 0:  return z;
-    case 1:  return wm_u2f(wm_f2u(z) ^ 0x80000000u);
-    case 2:  return wm_sub(pi, wm_sub(z, pi_lo));
-    default: return wm_sub(wm_sub(z, pi_lo), pi);
-    }
+    z = wm_sel(k > 60, wm_add(pi_o_2, wm_mul(0.5f, pi_lo)), wm_sel((hx >> 31) && k < -60, 0.0f, z));
+
+    const float zl = wm_sub(z, pi_lo);
+    float res = wm_sel(m == 0u, z, wm_sel(m == 1u, wm_u2f(wm_f2u(z) ^ 0x80000000u),
+                wm_sel(m == 2u, wm_sub(pi, zl), wm_sub(zl, pi))));
+    res = wm_sel(ix == 0u, (hy >> 31) ? -pi_o_2 : pi_o_2, res);             /* x == +-0            */
+    res = wm_sel(iy == 0u, m < 2u ? y : (m == 2u ? pi : -pi), res);         /* y == +-0 comes first */
+    return res;
 }
 
 /* Polar discriminator (rtl_wmbus.c:517-534 / 553-570): y = s * conj(s_prev), cargf(y)/pi.

@@ -69,7 +69,11 @@ __global__ __launch_bounds__(256) void k1_demod(K1Args a)
     constexpr int NA = T + WM_K1_HALO;                /* samples needing i/q              */
     constexpr int RA = (NA + 255) / 256;              /* stage-A samples per thread       */
     constexpr int RE = 2 * RF;                        /* EMA run per thread               */
-    constexpr int YROW = NA + 8;                      /* padded row of the float arrays   */
+    /* LDS float rows are SKEWED so that the strided per-lane windows below are bank-conflict
+     * free: discriminator row, element a at P(a) = (a+1) + (a+1)/RF (lane stride RF+1 words);
+     * magnitude row, element a at Q(a) = a + a/RE (lane stride RE+1 words).                   */
+    constexpr int YROW_D = (NA + 8) + (NA + 8) / RF + 4;
+    constexpr int YROW_M = (NA + 8) + (NA + 8) / RE + 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const WmPush &g = a.g;
@@ -171,16 +175,18 @@ __global__ __launch_bounds__(256) void k1_demod(K1Args a)
 
     /* float arrays overlay the staging area; element a lives at position a + 1 so that the
      * 46-tap windows start 16-byte aligned (a = 48 + RF*tid - 45 -> position 4 + RF*tid).   */
-    float *yDrT = (float *)smem, *yDrS = yDrT + YROW, *yMgT = yDrS + YROW, *yMgS = yMgT + YROW;
-    float *sFin = yMgS + YROW;                        /* [2][128] EMA finals               */
+    float *yDrT = (float *)smem, *yDrS = yDrT + YROW_D, *yMgT = yDrS + YROW_D, *yMgS = yMgT + YROW_M;
+    float *sFin = yMgS + YROW_M;                      /* [2][128] EMA finals               */
     float *sHead = sFin + 256;                        /* [2][128] EMA after warm-up        */
+    auto P = [](int a) { return (a + 1) + (a + 1) / RF; };
+    auto Q = [](int a) { return a + a / RE; };
     {
         const int a0 = RA * tid;
 #pragma unroll
         for (int j = 0; j < RA; j++)
             if (a0 + j < NA) {
-                yDrT[a0 + j + 1] = drT[j]; yDrS[a0 + j + 1] = drS[j];
-                yMgT[a0 + j + 1] = mgT[j]; yMgS[a0 + j + 1] = mgS[j];
+                yDrT[P(a0 + j)] = drT[j]; yDrS[P(a0 + j)] = drS[j];
+                yMgT[Q(a0 + j)] = mgT[j]; yMgS[Q(a0 + j)] = mgS[j];
             }
     }
     __syncthreads();
@@ -192,7 +198,7 @@ __global__ __launch_bounds__(256) void k1_demod(K1Args a)
         if (chT && m0l < tn) {
             float w[RF + 10];
 #pragma unroll
-            for (int k = 0; k < RF + 10; k++) w[k] = yDrT[WM_K1_HALO + m0l - 10 + k + 1];
+            for (int k = 0; k < RF + 10; k++) w[k] = yDrT[P(WM_K1_HALO + m0l - 10 + k)];
             float acc[RF];
 #pragma unroll
             for (int j = 0; j < RF; j++) {
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(256) void k1_demod(K1Args a)
         if (chS && m0l < tn) {
             float w[RF + 45];
 #pragma unroll
-            for (int k = 0; k < RF + 45; k++) w[k] = yDrS[WM_K1_HALO + m0l - 45 + k + 1];
+            for (int k = 0; k < RF + 45; k++) w[k] = yDrS[P(WM_K1_HALO + m0l - 45 + k)];
             float acc[RF];
 #pragma unroll
             for (int j = 0; j < RF; j++) {
@@ -234,14 +240,14 @@ __global__ __launch_bounds__(256) void k1_demod(K1Args a)
         if (on) {
 #pragma unroll 8
             for (int k = 0; k < WM_EMA_WARMUP; k++)
-                ema = wm_add(wm_mul(al, mg[m0l + k + 1]), wm_mul(be, ema));
+                ema = wm_add(wm_mul(al, mg[Q(m0l + k)]), wm_mul(be, ema));
         }
         const float head = ema;
         uint32_t pk[(RE + 3) / 4] = {};
         if (on) {
 #pragma unroll
             for (int k = 0; k < RE; k++) {
-                ema = wm_add(wm_mul(al, mg[WM_K1_HALO + m0l + k + 1]), wm_mul(be, ema));
+                ema = wm_add(wm_mul(al, mg[Q(WM_K1_HALO + m0l + k)]), wm_mul(be, ema));
                 pk[k >> 2] |= ((uint32_t)ema & 0xFFu) << (8 * (k & 3));
                 if (m0l + k == tn - 1) tail = ema;
             }
@@ -484,7 +490,30 @@ __global__ __launch_bounds__(64) void k2_clock(K2Args a)
     if (n_out > cap_t2) atomicOr(a.err, WM_ERR_CHIP_OVERFLOW);
 }
 
-/* Run-length framer lane (rtl_wmbus.c:640-702 S1, :729-803 T1/C1). */
+/* Deglitch filter for a whole 32-sample block, bit-parallel.  W holds raw slicer bits in time
+ * order: bit 5+k = sample k of the block, bits 0..4 = the five samples before it.
+ *   T1/C1 (rtl_wmbus.c:126-144,733): level = popcount(last 6 raw bits) >= 3, by a bit-sliced adder;
+ *   S1    (rtl_wmbus.c:149-154,644): LUT 0101011101111111 = newest | majority(previous three).
+ * Returns bit k = deglitched level at sample k. */
+__device__ __forceinline__ uint32_t deglitch_block(uint64_t W, bool s1)
+{
+    const uint64_t a0 = W, a1 = W << 1, a2 = W << 2, a3 = W << 3;
+    uint64_t D;
+    if (s1) D = a0 | (a1 & a2) | (a1 & a3) | (a2 & a3);
+    else {
+        const uint64_t a4 = W << 4, a5 = W << 5;
+        const uint64_t x1 = a0 ^ a1, s_1 = x1 ^ a2, c_1 = (a0 & a1) | (a2 & x1);
+        const uint64_t x2 = a3 ^ a4, s_2 = x2 ^ a5, c_2 = (a3 & a4) | (a5 & x2);
+        D = (c_1 & c_2) | ((c_1 ^ c_2) & (s_1 | s_2));          /* s1+s2+2(c1+c2) >= 3 */
+    }
+    return (uint32_t)(D >> 5);
+}
+
+/* Run-length framer lane (rtl_wmbus.c:640-702 S1, :729-803 T1/C1), edge-driven: the per-sample
+ * work (shift, deglitch, compare, count) is done for 32 samples at once with bit operations and
+ * the lane only iterates over the EDGES of the deglitched signal.  A framer reset clears the raw
+ * history (rtl_wmbus.c:632,723), so after one the remaining levels of the block are recomputed
+ * from the masked history.  WmRlaState.raw keeps the last five raw bits in time order. */
 __global__ __launch_bounds__(64) void k2_rla(K2Args a)
 {
     __shared__ uint32_t s_rssi[64 * WM_RSSI_ROW];
@@ -517,25 +546,29 @@ __global__ __launch_bounds__(64) void k2_rla(K2Args a)
     uint32_t n_out = 0;
     const bool s1 = ch != 0;
     const uint32_t syncw = s1 ? WM_SYNC_S1 : WM_SYNC_T1C1, syncm = s1 ? WM_SYNC_S1_MASK : WM_SYNC_T1C1_MASK;
+    const uint32_t hist_mask = s1 ? 0x1Cu : 0x1Fu;       /* S1 looks back 3 samples, T1/C1 5      */
 
     uint32_t word = bw[m >> 5], nword = 0;
     uint4 r0 = *(const uint4 *)(rs + m), r1 = *(const uint4 *)(rs + m + 16), nr0 = {}, nr1 = {};
     for (; m < me; m += 32) {
-        const bool more = m + 32 < me;
-        if (more) { nword = bw[(m >> 5) + 1]; nr0 = *(const uint4 *)(rs + m + 32); nr1 = *(const uint4 *)(rs + m + 48); }
+        if (m + 32 < me) { nword = bw[(m >> 5) + 1]; nr0 = *(const uint4 *)(rs + m + 32); nr1 = *(const uint4 *)(rs + m + 48); }
         const bool emit = m >= mb;
         if (m == mb) stS[sidx] = s;
         my_rssi[0] = r0.x; my_rssi[1] = r0.y; my_rssi[2] = r0.z; my_rssi[3] = r0.w;
         my_rssi[4] = r1.x; my_rssi[5] = r1.y; my_rssi[6] = r1.z; my_rssi[7] = r1.w;
         const uint32_t kend = min(32u, me - m);
-        for (uint32_t k = 0; k < kend; k++) {
-            const uint32_t bit = (word >> k) & 1u;
-            uint32_t st;
-            if (!s1) { s.raw = ((s.raw << 1) | bit) & 0x3Fu; st = __popc(s.raw) >= 3; }        /* :733, LUT :126-144 */
-            else { s.raw = ((s.raw << 1) | bit) & 0xFu; st = (0xFEEAu >> s.raw) & 1u; }          /* LUT :149-154 */
-            if ((s.state & 1u) == st) { s.run++; continue; }
-            /* edge */
-            int unit = 0, half = 0, run0 = s.run;
+        const uint32_t valid = kend == 32u ? 0xFFFFFFFFu : ((1u << kend) - 1u);
+        uint64_t W = ((uint64_t)(word & valid) << 5) | (s.raw & hist_mask);
+        uint32_t D = deglitch_block(W, s1);
+        uint32_t k0 = 0;
+        while (k0 < kend) {
+            const uint32_t level = s.state & 1u;
+            const uint32_t x = (level ? ~D : D) & valid & (0xFFFFFFFFu << k0);
+            if (!x) { s.run += (int)(kend - k0); break; }
+            const uint32_t k = (uint32_t)__ffs((int)x) - 1u;          /* first sample whose level differs */
+            s.run += (int)(k - k0);
+            int unit = 0, half = 0;
+            const int run0 = s.run;
             bool rst;
             if (!s1) {
                 rst = s.run < 5;                                                             /* :742 */
@@ -545,9 +578,11 @@ __global__ __launch_bounds__(64) void k2_rla(K2Args a)
                 rst = unit <= 12 || unit >= 36;                                              /* :659 */
                 if (!rst) { half = unit / 2; rst = run0 <= half; }                           /* :671 */
             }
-            if (rst) s = reset;
-            else {
-                const uint32_t level = s.state & 1u;
+            if (rst) {
+                s = reset;
+                W &= ~((2ull << (5u + k)) - 1ull);       /* raw history cleared, incl. sample k */
+                D = deglitch_block(W, s1);
+            } else {
                 const uint32_t rssi = ((const uint8_t *)my_rssi)[k];
                 int n = 0;
                 while (s.run > half) {                                                       /* :765-779 / :680-694 */
@@ -570,9 +605,11 @@ __global__ __launch_bounds__(64) void k2_rla(K2Args a)
                     if (level) s.spb1 = v; else s.spb0 = v;
                 }
             }
-            s.state = (s.state & 2u) | st;
+            s.state = (s.state & 2u) | (level ^ 1u);
             s.run = 1;
+            k0 = k + 1u;
         }
+        s.raw = (uint32_t)(W >> kend) & hist_mask;        /* the five newest raw bits, time order */
         word = nword; r0 = nr0; r1 = nr1;
     }
     if (mb >= me) stS[sidx] = s;
