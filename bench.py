@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--rla-seg-len", type=int, default=0)
     ap.add_argument("--warmup-s1", type=int, default=0)
     ap.add_argument("--warmup-t1c1", type=int, default=0)
-    ap.add_argument("--contexts", type=int, default=2, help="receiver contexts per GPU (GPU / host-decode overlap)")
+    ap.add_argument("--contexts", type=int, default=4, help="receiver contexts per GPU (GPU / host-decode overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     return ap.parse_args()
@@ -87,15 +87,9 @@ def cpu_baseline(caps, n_samples):
 
 def main():
     a = parse()
-    rank = int(os.environ.get("RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
-    dist = None
-    if world > 1:
-        import torch                      # before the HIP library: one HIP runtime per process
-        import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    shard = importlib.import_module("rtl-wmbus_amd.shard")
+    rank, world, local = shard.rank_env()
+    dist = shard.init(world, local)       # imports torch BEFORE the HIP library: one HIP runtime per process
     wm = importlib.import_module("rtl-wmbus_amd")
     if wm.device_count() < 1:
         raise SystemExit("bench.py: no HIP device (the back end has no CPU fallback)")
@@ -110,13 +104,14 @@ def main():
     caps = [None] * S
 
     def gen(s):
-        caps[s] = wm.synth_capture(seed=0xC0FFEE + rank * S + s, n_samples=n, kinds=wm.T1 | wm.C1A | wm.C1B,
+        caps[s] = wm.synth_capture(seed=shard.capture_seed(rank, S, s), n_samples=n, kinds=wm.T1 | wm.C1A | wm.C1B,
                                    frames_per_s=20.0)[0]
 
     with cf.ThreadPoolExecutor(min(os.cpu_count() or 1, 64)) as ex:
         list(ex.map(gen, range(S)))
     t_gen = time.perf_counter() - t0
     rxs, base = [], 0
+    t_h2d = time.perf_counter()
     for i in range(nctx):
         rx = wm.Receiver(n_streams=per_ctx[i], max_push_bytes=push_bytes, device=local, seg_len=a.seg_len, rla_seg_len=a.rla_seg_len,
                          warmup_s1=a.warmup_s1, warmup_t1c1=a.warmup_t1c1, show_algorithm=True, fixed_timestamp=True)
@@ -124,6 +119,7 @@ def main():
             rx.stage(s, caps[base + s])
         rxs.append(rx)
         base += per_ctx[i]
+    t_h2d = time.perf_counter() - t_h2d      # includes buffer allocation; pageable host memory
 
     pool = cf.ThreadPoolExecutor(nctx)
 
@@ -141,10 +137,7 @@ def main():
         step()
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
-            import torch
-            torch.cuda.synchronize()
+        shard.barrier(dist)
 
     barrier()
     t0 = time.perf_counter()
@@ -157,11 +150,8 @@ def main():
         tim_acc.append(tims)
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = shard.max_over_ranks(dist, elapsed)
+    lines_total = int(shard.sum_over_ranks(dist, lines_total))
 
     total_samples = world * S * n * a.steps
     value = total_samples / elapsed / 1e6
@@ -173,7 +163,7 @@ def main():
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tf):
         try:
-            traffic = json.load(open(tf)).get("k1_demod_hbm_bytes_per_launch")
+            traffic = int(json.load(open(tf))["k1_demod_hbm_bytes_per_input_sample"] * samples_per_launch)
         except Exception:
             traffic = None
 
@@ -195,7 +185,7 @@ def main():
                          "algorithmic_bytes_per_launch": int(BYTES_PER_SAMPLE * samples_per_launch),
                          "avg_launch_ms": round(k1_avg_s * 1e3, 3)},
             "stage_ms_last_step": [{k: round(v, 3) if isinstance(v, float) else v for k, v in t.items()} for t in last],
-            "setup_s": {"generate": round(t_gen, 1)},
+            "setup_s": {"generate": round(t_gen, 1), "alloc_and_h2d": round(t_h2d, 1)},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(caps, n)
