@@ -124,6 +124,13 @@ long wmbus_read_tap(wmbus_ctx *ctx, const char *what, int chain, unsigned stream
 long wmbus_read_chips(wmbus_ctx *ctx, int chain, int algo, unsigned stream,
                       uint32_t *dst, uint64_t *pos, size_t max_elems);
 
+/* Device self-test of the exact scalar arithmetic the kernels use (correctly rounded sqrt and
+ * divide, the restated glibc atan2f, the polar discriminator rtl_wmbus.c:517-534) on n operand
+ * pairs: o_sqrt = sqrt(|a|), o_div = a/b, o_atan2 = atan2f(a, b),
+ * o_disc[i] = discriminator(i=a[i], q=b[i], i'=b[i+1], q'=a[i+1]). */
+int  wmbus_selftest_math(int device, const float *a, const float *b, float *o_sqrt, float *o_div,
+                         float *o_atan2, float *o_disc, size_t n);
+
 /* Number of visible HIP devices (0 if none). */
 int  wmbus_device_count(void);
 

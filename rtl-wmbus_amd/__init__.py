@@ -64,7 +64,7 @@ class Timing(ctypes.Structure):
 
 EXPORTS = ["wmbus_default_cfg", "wmbus_open", "wmbus_close", "wmbus_last_error", "wmbus_stage", "wmbus_device_input",
            "wmbus_process", "wmbus_collect", "wmbus_lines", "wmbus_lines_text", "wmbus_get_timing", "wmbus_read_tap",
-           "wmbus_read_chips", "wmbus_device_count"]
+           "wmbus_read_chips", "wmbus_device_count", "wmbus_selftest_math"]
 
 _lib = None
 
@@ -91,12 +91,23 @@ def lib():
         L.wmbus_read_tap.argtypes = [vp, ctypes.c_char_p, ctypes.c_int, u, vp, sz]; L.wmbus_read_tap.restype = ctypes.c_long
         L.wmbus_read_chips.argtypes = [vp, ctypes.c_int, ctypes.c_int, u, vp, vp, sz]; L.wmbus_read_chips.restype = ctypes.c_long
         L.wmbus_device_count.restype = ctypes.c_int
+        L.wmbus_selftest_math.argtypes = [ctypes.c_int] + [vp] * 6 + [sz]
         _lib = L
     return _lib
 
 
 def device_count():
     return int(lib().wmbus_device_count())
+
+
+def selftest_math(a, b, device=0):
+    """Device sqrt / divide / atan2f / discriminator of wm_exact.h on float32 arrays a, b."""
+    a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+    outs = [np.empty_like(a) for _ in range(4)]
+    rc = lib().wmbus_selftest_math(device, a.ctypes.data, b.ctypes.data, *[o.ctypes.data for o in outs], a.size)
+    if rc:
+        raise WmbusError(f"selftest_math failed: {rc}")
+    return dict(sqrt=outs[0], div=outs[1], atan2=outs[2], disc=outs[3])
 
 
 class Receiver:

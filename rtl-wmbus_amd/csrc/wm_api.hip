@@ -131,6 +131,16 @@ template <int RF> int launch_k1(wmbus_ctx *c, const K1Args &a, uint32_t ntiles)
     return 0;
 }
 
+__global__ void k_selftest(const float *a, const float *b, float *o_sqrt, float *o_div, float *o_atan2, float *o_disc, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    o_sqrt[i] = wm_sqrt(fabsf(a[i]));
+    o_div[i] = wm_div(a[i], b[i]);
+    o_atan2[i] = wm_atan2f(a[i], b[i]);
+    o_disc[i] = wm_discriminator(a[i], b[i], b[(i + 1) % n], a[(i + 1) % n]);
+}
+
 double now_ms()
 {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -609,6 +619,24 @@ long wmbus_read_chips(wmbus_ctx *c, int chain, int algo, unsigned stream, uint32
     if (pos) hipMemcpy(pos, d_pos, m * 8, hipMemcpyDeviceToHost);
     hipFree(d_dst); hipFree(d_pos); hipFree(d_n);
     return (long)n;
+}
+
+/* Runs the device versions of the exact scalar helpers (wm_exact.h) over n operand pairs so a
+ * test can compare them with the host's IEEE / libm results bit for bit. */
+int wmbus_selftest_math(int device, const float *a, const float *b, float *o_sqrt, float *o_div, float *o_atan2,
+                        float *o_disc, size_t n)
+{
+    if (wmbus_device_count() <= device || hipSetDevice(device) != hipSuccess) return WMBUS_ENODEVICE;
+    float *d[6] = {};
+    for (auto &p : d) if (hipMalloc((void **)&p, n * sizeof(float)) != hipSuccess) return WMBUS_ENOMEM;
+    hipMemcpy(d[0], a, n * sizeof(float), hipMemcpyHostToDevice);
+    hipMemcpy(d[1], b, n * sizeof(float), hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_selftest, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d[0], d[1], d[2], d[3], d[4], d[5], (uint32_t)n);
+    float *outs[4] = {o_sqrt, o_div, o_atan2, o_disc};
+    int rc = hipDeviceSynchronize() == hipSuccess ? WMBUS_OK : WMBUS_EDEVICE;
+    for (int k = 0; k < 4; k++) if (hipMemcpy(outs[k], d[2 + k], n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) rc = WMBUS_EDEVICE;
+    for (auto &p : d) hipFree(p);
+    return rc;
 }
 
 }  // extern "C"

@@ -38,6 +38,34 @@ def compare_chips(rx, ref, stream=0, chains=(0, 1), algos=(0, 1)):
             assert np.array_equal(pos, oc["sample"])
 
 
+def test_device_arithmetic_is_ieee_and_glibc_exact(wm):
+    """sqrt / divide correctly rounded, atan2f == this image's glibc, on the operand domains of the
+    RSSI (|s|^2 = k/64, k/256) and of the discriminator (products of k/8, k/16 boxcar outputs)."""
+    rng = np.random.default_rng(11)
+    k = np.arange(0, 2 * 1016 * 1016 + 1, dtype=np.int64)
+    a = np.concatenate([k / 64.0, rng.integers(0, 2 * 2880 * 2880, 1 << 21) / 256.0]).astype(np.float32)
+    i = rng.integers(-1016, 1017, a.size) / 8.0
+    q = rng.integers(-1016, 1017, a.size) / 8.0
+    small = rng.random(a.size) < 0.3
+    i[small] = rng.integers(-12, 13, small.sum()) / 8.0
+    q[small] = rng.integers(-12, 13, small.sum()) / 8.0
+    i = i.astype(np.float32); q = q.astype(np.float32)
+    r = wm.selftest_math(a, np.where(q == 0, np.float32(1), q))
+    assert np.array_equal(r["sqrt"].view(np.uint32), np.sqrt(a).view(np.uint32))
+    assert np.array_equal(r["div"].view(np.uint32), (a / np.where(q == 0, np.float32(1), q)).astype(np.float32).view(np.uint32))
+    r = wm.selftest_math(i, q)
+    # host reference = the reference's own expression with the host libm (atan2.h:7-10)
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6"); libm.atan2f.restype = ctypes.c_float; libm.atan2f.argtypes = [ctypes.c_float] * 2
+    idx = rng.integers(0, i.size, 200000)
+    want = np.array([libm.atan2f(float(i[j]), float(q[j])) for j in idx], np.float32)
+    assert np.array_equal(r["atan2"][idx].view(np.uint32), want.view(np.uint32))
+    ip, qp = np.roll(q, -1), np.roll(i, -1)                    # previous sample (i', q') per the ABI comment
+    re = (i * ip - q * (-qp)).astype(np.float32); im = (i * (-qp) + q * ip).astype(np.float32)
+    want = np.array([np.float32(libm.atan2f(float(im[j]), float(re[j]))) * np.float32(0.3183098861837907) for j in idx], np.float32)
+    assert np.array_equal(r["disc"][idx].view(np.uint32), want.view(np.uint32))
+
+
 @pytest.mark.parametrize("name,flags", BUNDLED_CASES, ids=[f"{n[14:22]}:{' '.join(f)}" for n, f in BUNDLED_CASES])
 def test_bundled_captures_match_reference_golden(wm, name, flags):
     cu8 = np.fromfile(os.path.join(SAMPLES, name), np.uint8)
