@@ -43,8 +43,9 @@ struct wmbus_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
     /* geometry */
-    uint32_t d = 2, S = 1, C[2] = {8192, 32768}, Mcap = 0, nseg_cap[2] = {0, 0}, ntiles_cap = 0, RF = 8;
+    uint32_t d = 2, S = 1, C[2] = {8192, 32768}, Mcap = 0, nseg_cap[2] = {0, 0}, ntiles_cap = 0, RF = 8, T = 1024;
     uint32_t cap[2] = {0, 0}, flags = 0;
+    bool k1_gen2 = false;
     uint64_t in_stride = 0, n0 = 0;
     size_t staged = 0;
     /* device buffers */
@@ -131,14 +132,27 @@ template <int RF> int launch_k1(wmbus_ctx *c, const K1Args &a, uint32_t ntiles)
     return 0;
 }
 
+template <int D, bool SHIFT> int launch_k1v2(wmbus_ctx *c, const K1Args &a, uint32_t ntiles)
+{
+    const size_t sm = K1Geo<D>::smem(SHIFT);
+    HIPCHK(c, hipFuncSetAttribute((const void *)k1_demod2<D, SHIFT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+    hipLaunchKernelGGL((k1_demod2<D, SHIFT>), dim3(ntiles, c->S), dim3(256), sm, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+/* The kernels' arithmetic (table-driven atan2 included) on arbitrary operand pairs. */
 __global__ void k_selftest(const float *a, const float *b, float *o_sqrt, float *o_div, float *o_atan2, float *o_disc, uint32_t n)
 {
+    __shared__ float tab[WM_ATAN_ROWS * WM_ATAN_ROW_WORDS];
+    for (int j = threadIdx.x; j < WM_ATAN_ROWS; j += blockDim.x) wm_atan_row(j, tab + WM_ATAN_ROW_WORDS * j);
+    __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     o_sqrt[i] = wm_sqrt(fabsf(a[i]));
     o_div[i] = wm_div(a[i], b[i]);
-    o_atan2[i] = wm_atan2f(a[i], b[i]);
-    o_disc[i] = wm_discriminator(a[i], b[i], b[(i + 1) % n], a[(i + 1) % n]);
+    o_atan2[i] = wm_atan2f_tab(a[i], b[i], tab);
+    o_disc[i] = wm_discriminator_tab(a[i], b[i], b[(i + 1) % n], a[(i + 1) % n], tab);
 }
 
 double now_ms()
@@ -213,12 +227,15 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
     /* tile: 2048 decimated samples up to d = 2, fewer for larger d so the staging fits in LDS */
     c->RF = c->d <= 5 ? 4 : 2;   /* RF = 8 needs 190 VGPRs (2 waves/SIMD) and measured 1.8x slower */
     if (const char *e = getenv("WMBUS_K1_RF")) { const int v = atoi(e); if (v == 8 || v == 4 || v == 2) c->RF = (uint32_t)v; }
-    const uint32_t T = 256 * c->RF;
+    /* decimations 2..5 run the second-generation tile kernel (tile 976); others the generic one */
+    c->k1_gen2 = c->d >= 2 && c->d <= 5 && c->RF == 4;
+    if (const char *e = getenv("WMBUS_K1_GEN")) c->k1_gen2 = c->k1_gen2 && atoi(e) != 1;
+    c->T = c->k1_gen2 ? (uint32_t)WM_K1_TILE2 : 256 * c->RF;
+    const uint32_t T = c->T;
     const uint64_t max_samples = cfg->max_push_bytes / 2;
-    c->Mcap = (uint32_t)(((max_samples / c->d + 1 + 8) + 127) / 128 * 128);
-    c->Mcap = (c->Mcap + T - 1) / T * T;                 /* whole tiles: partial tiles still store full runs */
+    c->ntiles_cap = (uint32_t)((max_samples / c->d + 1 + 8 + T - 1) / T);
+    c->Mcap = (c->ntiles_cap * T + 127) / 128 * 128;     /* whole tiles (partial tiles still store full runs), rows 512-byte aligned */
     for (int a = 0; a < 2; a++) c->nseg_cap[a] = (c->Mcap + c->C[a] - 1) / c->C[a];
-    c->ntiles_cap = c->Mcap / T;
     c->cap[1] = c->C[1] / 4 + 8;   /* time2: the lock logic needs >= 4 samples per chip */
     c->cap[0] = c->C[0] + 8;       /* run-length: bit length tracking may shrink the chip period towards one sample */
     c->in_stride = (WM_HIST_BYTES + cfg->max_push_bytes + WM_IN_SLACK + 255) / 256 * 256;
@@ -373,10 +390,16 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
     if (g.M > 0) {
         HIPCHK(c, hipMemsetAsync(c->d_scalars, 0, SC_COUNT * sizeof(uint32_t), c->stream));
         /* K1 */
-        const uint32_t T = 256 * c->RF, ntiles = (g.M + T - 1) / T;
+        const uint32_t T = c->T, ntiles = (g.M + T - 1) / T;
         K1Args k1{g, c->d_dphi, c->d_rssi, c->d_lut, c->d_lut + 32 * WM_MAX_DECIM, c->d_ema_head, c->d_ema_tail, ntiles, c->d_scalars + SC_ERR};
         HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-        int rc = c->RF == 8 ? launch_k1<8>(c, k1, ntiles) : c->RF == 4 ? launch_k1<4>(c, k1, ntiles) : launch_k1<2>(c, k1, ntiles);
+        int rc;
+        const bool sh = c->flags & WM_F_SHIFT;
+        if (c->k1_gen2 && c->d == 2) rc = sh ? launch_k1v2<2, true>(c, k1, ntiles) : launch_k1v2<2, false>(c, k1, ntiles);
+        else if (c->k1_gen2 && c->d == 3) rc = sh ? launch_k1v2<3, true>(c, k1, ntiles) : launch_k1v2<3, false>(c, k1, ntiles);
+        else if (c->k1_gen2 && c->d == 4) rc = sh ? launch_k1v2<4, true>(c, k1, ntiles) : launch_k1v2<4, false>(c, k1, ntiles);
+        else if (c->k1_gen2 && c->d == 5) rc = sh ? launch_k1v2<5, true>(c, k1, ntiles) : launch_k1v2<5, false>(c, k1, ntiles);
+        else rc = c->RF == 8 ? launch_k1<8>(c, k1, ntiles) : c->RF == 4 ? launch_k1<4>(c, k1, ntiles) : launch_k1<2>(c, k1, ntiles);
         if (rc) return rc;
         hipLaunchKernelGGL(k1_verify, dim3((2 * c->S + 63) / 64), dim3(64), 0, c->stream, c->d_ema_head, c->d_ema_tail,
                            c->d_ema_carry, ntiles, 2 * c->S, c->d_scalars + SC_ERR);

@@ -19,6 +19,7 @@
 #define WM_IN_SLACK     256u       /* readable slack behind the staged bytes                  */
 #define WM_K1_HALO      48         /* decimated-sample halo: 45 FIR + 1 discriminator, 48 EMA  */
 #define WM_EMA_WARMUP   48
+#define WM_K1_TILE2     976        /* tile of the second-generation K1: tile + halo = 1024      */
 #define WM_MAX_DECIM    32u
 
 #define WM_CHIP_VAL(w)   ((w) & 0xFFu)

@@ -113,6 +113,99 @@ WM_HD float wm_atan2f(float y, float x)
     return res;
 }
 
+/* ---------------------------------------------------------------------------------------------
+ * Table-driven form of the same function for the kernels' hot loop.
+ *
+ * The five argument-reduction ranges of s_atanf.c differ only in constants:
+ *     num = A*t + B,  den = C*t + D,  r = num/den,  atan = hi - ((r*(s1+s2) - lo) - r)
+ *   range            A   B     C    D    hi/lo
+ *   t <  7/16        1   0     0    1    0 / 0        (hi - ((p - 0) - r) == r - p bit for bit)
+ *   7/16 .. 11/16    2  -1     1    2    atan(0.5)
+ *   11/16 .. 19/16   1  -1     1    1    atan(1.0)
+ *   19/16 .. 39/16   1  -1.5   1.5  1    atan(1.5)
+ *   >= 39/16         0  -1     1    0    atan(inf)
+ * A*t is exact for A in {0,1,2} and C*t is the product the original forms (1.5*t) or exact, so
+ * num and den carry exactly the roundings of the branchy code.  All four range limits are
+ * multiples of 2^18 in the float's bit pattern, so `bits(t) >> 18` indexes a row table directly
+ * (81 rows of 8 floats: 79 distinct prefixes between 7/16 and 39/16 plus one row below and one
+ * above); one 32-byte row fetch replaces 4 compares, 14 selects and the four (num, den) pairs.
+ *
+ * Reachable-domain pruning (documented, checked by tests/exact_math_check.c on the discriminator's
+ * operand domain and on the device by wmbus_selftest_math): the discriminator's operands are
+ * integers (sums of <= 16 samples of magnitude <= 180, products of two such) times a common
+ * power of two, so for non-zero y and x:  2^-24 < |y/x| < 2^24.  The |t| < 2^-29, |t| >= 2^25 and
+ * exponent-gap (> 60) shortcuts of the original can therefore not trigger and are dropped; zero
+ * operands keep their exact special cases (signed zeros matter: atan2f(-0, x<0) = -pi).
+ * ------------------------------------------------------------------------------------------- */
+#define WM_ATAN_ROWS      81
+#define WM_ATAN_ROW_WORDS 8
+#define WM_ATAN_U0        0xFB8u      /* bits(7/16) >> 18 */
+
+/* Row j of the table (j = clamp((bits(t) >> 18) - (U0 - 1), 0, 80)). */
+WM_HD void wm_atan_row(int j, float *row)
+{
+    const uint32_t u = WM_ATAN_U0 - 1u + (uint32_t)j;
+    const int idx = j == 0 ? 0 : 1 + (u >= (0x3f300000u >> 18)) + (u >= (0x3f980000u >> 18)) + (u >= (0x401c0000u >> 18));
+    const float A[5] = {1.0f, 2.0f, 1.0f, 1.0f, 0.0f}, B[5] = {0.0f, -1.0f, -1.0f, -1.5f, -1.0f};
+    const float C[5] = {0.0f, 1.0f, 1.0f, 1.5f, 1.0f}, D[5] = {1.0f, 2.0f, 1.0f, 1.0f, 0.0f};
+    const uint32_t hi[5] = {0u, 0x3eed6338u, 0x3f490fdau, 0x3f7b985eu, 0x3fc90fdau};
+    const uint32_t lo[5] = {0u, 0x31ac3769u, 0x33222168u, 0x33140fb4u, 0x33a22168u};
+    row[0] = A[idx]; row[1] = B[idx]; row[2] = C[idx]; row[3] = D[idx];
+    row[4] = wm_u2f(hi[idx]); row[5] = wm_u2f(lo[idx]); row[6] = 0.0f; row[7] = 0.0f;
+}
+
+WM_HD float wm_copysign_bits(float mag, uint32_t sign_src) { return wm_u2f((wm_f2u(mag) & 0x7fffffffu) | (sign_src & 0x80000000u)); }
+
+WM_HD float wm_atan2f_tab(float y, float x, const float *tab)
+{
+    const uint32_t hx = wm_f2u(x), hy = wm_f2u(y);
+    const float pi = wm_u2f(0x40490fdbu), pi_o_2 = wm_u2f(0x3fc90fdbu), pi_lo = wm_u2f(0xb3bbbd2eu);
+    const float t = wm_u2f(wm_f2u(wm_div(y, x)) & 0x7fffffffu);       /* fabsf(y/x) */
+    int j = (int)(wm_f2u(t) >> 18) - (int)(WM_ATAN_U0 - 1u);
+    j = j < 0 ? 0 : (j > WM_ATAN_ROWS - 1 ? WM_ATAN_ROWS - 1 : j);
+    const float *e = tab + WM_ATAN_ROW_WORDS * j;
+    const float num = wm_add(wm_mul(e[0], t), e[1]);
+    const float den = wm_add(wm_mul(e[2], t), e[3]);
+    const float r = wm_div(num, den);
+
+    const float aT0 = wm_u2f(0x3eaaaaabu), aT1 = wm_u2f(0xbe4ccccdu), aT2 = wm_u2f(0x3e124925u),
+                aT3 = wm_u2f(0xbde38e38u), aT4 = wm_u2f(0x3dba2e6eu), aT5 = wm_u2f(0xbd9d8795u),
+                aT6 = wm_u2f(0x3d886b35u), aT7 = wm_u2f(0xbd6ef16bu), aT8 = wm_u2f(0x3d4bda59u),
+                aT9 = wm_u2f(0xbd15a221u), aT10 = wm_u2f(0x3c8569d7u);
+    const float z2 = wm_mul(r, r);
+    const float w = wm_mul(z2, z2);
+    float s1 = wm_add(aT8, wm_mul(w, aT10));
+    s1 = wm_add(aT6, wm_mul(w, s1));
+    s1 = wm_add(aT4, wm_mul(w, s1));
+    s1 = wm_add(aT2, wm_mul(w, s1));
+    s1 = wm_add(aT0, wm_mul(w, s1));
+    s1 = wm_mul(z2, s1);
+    float s2 = wm_add(aT7, wm_mul(w, aT9));
+    s2 = wm_add(aT5, wm_mul(w, s2));
+    s2 = wm_add(aT3, wm_mul(w, s2));
+    s2 = wm_add(aT1, wm_mul(w, s2));
+    s2 = wm_mul(w, s2);
+    const float p = wm_mul(r, wm_add(s1, s2));
+    const float z = wm_sub(e[4], wm_sub(wm_sub(p, e[5]), r));             /* atanf(|y/x|) >= 0 */
+    /* quadrant (e_atan2f.c): x >= 0: +-z ; x < 0: +-(pi - (z - pi_lo)) ; sign of y */
+    const float zq = (hx >> 31) ? wm_sub(pi, wm_sub(z, pi_lo)) : z;
+    float res = wm_copysign_bits(zq, hy);
+    res = (hx << 1) == 0u ? wm_copysign_bits(pi_o_2, hy) : res;           /* x == +-0            */
+    res = (hy << 1) == 0u ? ((hx >> 31) ? wm_copysign_bits(pi, hy) : y) : res;   /* y == +-0 first */
+    return res;
+}
+
+/* Polar discriminator on the table form.  The operands may carry any common power-of-two scale
+ * (the kernels pass the boxcar SUMS, not sums/8): products and sums stay exact integers, the
+ * signs of zero products are those of the reference's operands, and y/x is scale-free. */
+WM_HD float wm_discriminator_tab(float i, float q, float pi_, float pq_, const float *tab)
+{
+    const float c = pi_, d = -pq_;
+    const float re = wm_sub(wm_mul(i, c), wm_mul(q, d));
+    const float im = wm_add(wm_mul(i, d), wm_mul(q, c));
+    return wm_mul(wm_atan2f_tab(im, re, tab), wm_u2f(0x3ea2f983u));    /* (float)M_1_PI */
+}
+
 /* Polar discriminator (rtl_wmbus.c:517-534 / 553-570): y = s * conj(s_prev), cargf(y)/pi.
  * gcc expands the complex product as (a*c - b*d) + j(a*d + b*c) with (c,d) = (i', -q'). */
 WM_HD float wm_discriminator(float i, float q, float pi_, float pq_)

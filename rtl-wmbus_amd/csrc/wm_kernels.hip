@@ -269,6 +269,264 @@ __global__ __launch_bounds__(256) void k1_demod(K1Args a)
     }
 }
 
+/* =============================================================================================
+ * K1 (second generation): same arithmetic, far fewer instructions, balanced waves.
+ *
+ * Tile = 976 decimated samples, so that tile + 48-sample halo = 1024 = 256 threads x 4: every
+ * thread owns exactly one chunk of 4 consecutive samples in stage A (the first generation spent
+ * 20 wave-iterations on 1072 samples; this one 16 on 1024).
+ *   stage 0  cu8 -> packed int16 (i,q) in LDS, stored so that LDS word 0 is the oldest sample the
+ *            tile needs; quantisation with byte-permute + packed-int16 arithmetic.
+ *   stage A  a chunk needs the 4D+16 staged samples [4cD, 4cD+4D+16): aligned ds_read_b128, packed
+ *            int16 prefix sums, every boxcar (8 and 16 taps, 5 positions) one packed subtract.
+ *            Discriminator on the table-driven atan2 (wm_exact.h) fed with the unscaled sums.
+ *   stage B1 FIR from unskewed rows with aligned ds_read_b128 windows (13 + 4 loads instead of
+ *            49 + 14 dword loads).
+ *   stage B2 RSSI EMA: one wave per chain, 16 samples per lane behind a 48-sample warm-up
+ *            (first generation: all four waves, 8 samples per lane behind the same warm-up).
+ * LDS (words): U[max(staging, 2 magnitude rows)] | yDrT[YD] yDrS[YD] | sFin[128] sHead[128] |
+ *              atan rows[81*8] = 20.6 KB at d = 2 (7 workgroups per CU).  The magnitude rows
+ *              overlay the staging area: stage A keeps its 8 magnitudes in registers until the
+ *              barrier that retires the staging data.
+ * ===========================================================================================*/
+template <int D> struct K1Geo {
+    static constexpr int T = WM_K1_TILE2, NA = T + WM_K1_HALO;
+    static constexpr int NSTG = (NA * D + 16 + 8 + 7) / 8 * 8 + 8;   /* 8 slack words in front (stage 0 stores p >= -7) */
+    static constexpr int YD = NA + 8, YM = NA + NA / 16 + 4;
+    static constexpr int ustage(bool shift) { return NSTG * (shift ? 2 : 1); }
+    static constexpr int U(bool shift) { return ustage(shift) > 2 * YM ? ustage(shift) : 2 * YM; }
+    static constexpr size_t smem(bool shift)
+    {
+        return (size_t)(U(shift) + 2 * YD + 256 + WM_ATAN_ROWS * WM_ATAN_ROW_WORDS) * 4;
+    }
+};
+static_assert(K1Geo<2>::NA == 1024, "stage A maps one 4-sample chunk to each of the 256 threads");
+
+/* 8- and 16-tap boxcar sums at the five positions a0-1 .. a0+3 of one chunk from the staged
+ * samples w[0 .. 4D+16) (w[15] is the newest input of position a0-1). */
+template <int D>
+__device__ __forceinline__ void k1_boxcars(const uint32_t *w, wm_s2 s8[5], wm_s2 s16[5])
+{
+    constexpr int N = 4 * D + 16;
+    uint32_t x[N];
+#pragma unroll
+    for (int k = 0; k < N / 4; k++) {
+        const uint4 v = *(const uint4 *)(w + 4 * k);
+        x[4 * k] = v.x; x[4 * k + 1] = v.y; x[4 * k + 2] = v.z; x[4 * k + 3] = v.w;
+    }
+    wm_s2 P[N];
+    P[0] = __builtin_bit_cast(wm_s2, x[0]);
+#pragma unroll
+    for (int k = 1; k < N; k++) P[k] = P[k - 1] + __builtin_bit_cast(wm_s2, x[k]);
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const int n = j * D + 15;
+        s8[j] = P[n] - P[n - 8];
+        s16[j] = n >= 16 ? P[n] - P[n - 16] : P[n];
+    }
+}
+
+template <int D, bool SHIFT>
+__global__ __launch_bounds__(256) void k1_demod2(K1Args a)
+{
+    using G = K1Geo<D>;
+    constexpr int T = G::T, NA = G::NA, NSTG = G::NSTG, YD = G::YD, YM = G::YM;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t *stgT = (uint32_t *)smem + 8;                /* word 0 of a row = oldest sample of the tile */
+    uint32_t *stgS = SHIFT ? stgT + NSTG : stgT;
+    float *yMgT = (float *)smem, *yMgS = yMgT + YM;       /* overlay the staging rows (see stage A) */
+    float *yDrT = (float *)smem + G::U(SHIFT), *yDrS = yDrT + YD;
+    float *sFin = yDrS + YD, *sHead = sFin + 128, *tab = sHead + 128;
+
+    const WmPush &g = a.g;
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x, stream = blockIdx.y;
+    const int ts = tile * T;
+    const int tn = min(T, (int)g.M - ts);
+    const bool chT = g.flags & WM_F_T1C1, chS = g.flags & WM_F_S1;
+    const bool accurate = g.flags & WM_F_ACCURATE;
+
+    /* atan range rows (81 x 8 floats) */
+    for (int j = tid; j < WM_ATAN_ROWS; j += 256) wm_atan_row(j, tab + WM_ATAN_ROW_WORDS * j);
+
+    /* ---- stage 0 --------------------------------------------------------------------------- */
+    {
+        const long r_lo = ((long)(g.m0 + (uint64_t)ts) - WM_K1_HALO) * D - 16 - (long)g.n0;   /* LDS word 0 */
+        const long r_al = r_lo & ~7L;
+        const int off = (int)(r_lo - r_al);
+        const int nchunk = (NA * D + 16 + off + 7) >> 3;
+        const uint8_t *base = g.in + (uint64_t)stream * g.in_stride + WM_HIST_BYTES;
+        for (int c = tid; c < nchunk; c += 256) {
+            const long r = r_al + 8L * c;
+            const uint4 v = *(const uint4 *)(base + 2 * r);
+            const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+            const int p0 = 8 * c - off;
+            uint32_t li = 0;
+            if (SHIFT) {
+                const int L = (int)g.lut_n;
+                int rm = (int)(r % L); if (rm < 0) rm += L;
+                li = (g.lut_phase0 + 13u * (uint32_t)rm) % (uint32_t)L;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int p = p0 + k;
+                if (!SHIFT) {
+                    /* bytes (i,q) -> halfwords, then u - 127 - (u >> 7) per halfword
+                     * (= (int)((float)u - 127.5f), rtl_wmbus.c:1312-1313 + moving_average_filter.h:47) */
+                    const uint32_t h = __builtin_amdgcn_perm(0u, wv[k >> 1], (k & 1) ? 0x0c030c02u : 0x0c010c00u);
+                    const wm_s2 hv = __builtin_bit_cast(wm_s2, h);
+                    const wm_s2 c127 = {127, 127};
+                    const wm_s2 top = __builtin_bit_cast(wm_s2, (h >> 7) & 0x00010001u);
+                    const wm_s2 q = hv - c127 - top;
+                    stgT[p] = __builtin_bit_cast(uint32_t, q);
+                } else {
+                    const uint32_t iq = (wv[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
+                    const float fi = wm_sub((float)(iq & 0xFFu), 127.5f), fq = wm_sub((float)(iq >> 8), 127.5f);
+                    const float x = a.lut_cos[li], z = a.lut_msin[li];
+                    li += 13u; if (li >= g.lut_n) li -= g.lut_n;
+                    const float ix = wm_mul(fi, x), qx = wm_mul(fq, x), iz = wm_mul(fi, z), qz = wm_mul(fq, z);
+                    wm_s2 t, s;
+                    t.x = (short)(int)wm_sub(ix, qz); t.y = (short)(int)wm_add(qx, iz);
+                    s.x = (short)(int)wm_add(ix, qz); s.y = (short)(int)wm_sub(qx, iz);
+                    stgT[p] = __builtin_bit_cast(uint32_t, t); stgS[p] = __builtin_bit_cast(uint32_t, s);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    /* ---- stage A: thread = chunk ------------------------------------------------------------- */
+    float mgT[4], mgS[4];
+    {
+        const int c = tid;
+        wm_s2 s8[5], s16[5], u8[5], u16[5];
+        k1_boxcars<D>(stgT + 4 * c * D, s8, SHIFT ? u16 : s16);
+        if (SHIFT) k1_boxcars<D>(stgS + 4 * c * D, u8, s16);
+        float drT[4], drS[4];
+        if (chT) {
+            float pi_ = (float)s8[0].x, pq_ = (float)s8[0].y;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float i = (float)s8[j + 1].x, q = (float)s8[j + 1].y;       /* 8 x the reference's i, q */
+                drT[j] = accurate ? wm_discriminator_tab(i, q, pi_, pq_, tab)
+                                  : wm_mul(wm_discriminator_fast(i, q, pi_, pq_), 0.015625f);
+                mgT[j] = wm_mul(wm_sqrt(wm_add(wm_mul(i, i), wm_mul(q, q))), 0.125f);
+                pi_ = i; pq_ = q;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) drT[j] = mgT[j] = 0.0f;
+        }
+        if (chS) {
+            float pi_ = (float)s16[0].x, pq_ = (float)s16[0].y;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float i = (float)s16[j + 1].x, q = (float)s16[j + 1].y;     /* 16 x the reference's i, q */
+                drS[j] = accurate ? wm_discriminator_tab(i, q, pi_, pq_, tab)
+                                  : wm_mul(wm_discriminator_fast(i, q, pi_, pq_), 0.00390625f);
+                mgS[j] = wm_mul(wm_sqrt(wm_add(wm_mul(i, i), wm_mul(q, q))), 0.0625f);
+                pi_ = i; pq_ = q;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) drS[j] = mgS[j] = 0.0f;
+        }
+        /* element a of a discriminator row lives at word a + 4 */
+        *(float4 *)(yDrT + 4 * c + 4) = make_float4(drT[0], drT[1], drT[2], drT[3]);
+        *(float4 *)(yDrS + 4 * c + 4) = make_float4(drS[0], drS[1], drS[2], drS[3]);
+    }
+    __syncthreads();                                          /* staging data retired */
+    {   /* element a of a magnitude row lives at word a + a/16 (conflict-free 17-word lane stride in B2) */
+        const int qb = 4 * tid + (tid >> 2);
+#pragma unroll
+        for (int j = 0; j < 4; j++) { yMgT[qb + j] = mgT[j]; yMgS[qb + j] = mgS[j]; }
+    }
+
+    /* ---- stage B1: FIR low-pass, y[n] = sum_k b[k] x[n-k], k ascending (fir.h:48-72) ---------- */
+    {
+        const int m0l = 4 * tid;
+        const uint64_t row = (uint64_t)stream * g.Mcap + (uint64_t)ts + m0l;
+        if (chT && m0l < tn) {
+            float w[16];                                      /* w[i] = element 4 tid + 36 + i */
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float4 v = *(const float4 *)(yDrT + 4 * tid + 40 + 4 * k);
+                w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+            }
+            float acc[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float s = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 11; k++) s = wm_add(s, wm_mul(FIR_T[k], w[12 + j - k]));
+                acc[j] = s;
+            }
+            *(float4 *)(a.dphi + row) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        }
+        if (chS && m0l < tn) {
+            float w[52];                                      /* w[i] = element 4 tid + i */
+#pragma unroll
+            for (int k = 0; k < 13; k++) {
+                const float4 v = *(const float4 *)(yDrS + 4 * tid + 4 + 4 * k);
+                w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+            }
+            float acc[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float s = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 46; k++) s = wm_add(s, wm_mul(FIR_S[k], w[48 + j - k]));
+                acc[j] = s;
+            }
+            *(float4 *)(a.dphi + (uint64_t)g.S * g.Mcap + row) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        }
+    }
+
+    __syncthreads();                                          /* magnitude rows complete */
+
+    /* ---- stage B2: RSSI = EMA(|s|), alpha = 0.6789 (rtl_wmbus.c:475-495) --------------------- */
+    {
+        const int ch = tid >> 6, e = tid & 63;               /* wave 0: T1/C1, wave 1: S1 */
+        const bool on = ch < 2 && (ch ? chS : chT) && 16 * e < T;
+        const float *mg = (ch ? yMgS : yMgT) + 17 * e;        /* element 16 e + kk at 17 e + kk + kk/16 */
+        const float al = 0.6789f, be = wm_sub(1.0f, 0.6789f);
+        const int m0l = 16 * e;
+        float ema = 0.0f, tail = 0.0f, head = 0.0f;
+        if (on) {
+#pragma unroll
+            for (int k = 0; k < WM_EMA_WARMUP; k++)
+                ema = wm_add(wm_mul(al, mg[k + (k >> 4)]), wm_mul(be, ema));
+            head = ema;
+            uint32_t pk[4] = {0u, 0u, 0u, 0u};
+            if (tn == T) {                                    /* full tile: the tail is lane 63's last value */
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    ema = wm_add(wm_mul(al, mg[WM_K1_HALO + k + ((WM_K1_HALO + k) >> 4)]), wm_mul(be, ema));
+                    pk[k >> 2] |= ((uint32_t)ema & 0xFFu) << (8 * (k & 3));
+                }
+                tail = ema;
+            } else {                                          /* last tile of a push */
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    ema = wm_add(wm_mul(al, mg[WM_K1_HALO + k + ((WM_K1_HALO + k) >> 4)]), wm_mul(be, ema));
+                    pk[k >> 2] |= ((uint32_t)ema & 0xFFu) << (8 * (k & 3));
+                    if (m0l + k == tn - 1) tail = ema;
+                }
+            }
+            if (m0l < tn)
+                *(uint4 *)(a.rssi + ((uint64_t)ch * g.S + stream) * g.Mcap + ts + m0l) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            sFin[tid] = ema; sHead[tid] = head;
+        }
+        __syncthreads();
+        if (on) {
+            if (e > 0 && m0l < tn && wm_f2u(head) != wm_f2u(sFin[tid - 1])) atomicOr(a.err, WM_ERR_EMA);
+            const uint64_t ti = ((uint64_t)ch * g.S + stream) * a.ntiles + tile;
+            if (e == 0) a.ema_head[ti] = head;
+            if (m0l <= tn - 1 && tn - 1 < m0l + 16) a.ema_tail[ti] = tail;
+        }
+    }
+}
+
 /* head[tile] must equal tail[tile-1] (or the value carried from the previous push). */
 __global__ void k1_verify(const float *head, const float *tail, float *carry, uint32_t ntiles,
                           uint32_t rows, uint32_t *err)

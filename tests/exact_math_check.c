@@ -9,12 +9,14 @@
 static uint64_t s = 0x1234567887654321ull;
 static uint64_t rnd(void) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; }
 
+static float TAB[WM_ATAN_ROWS * WM_ATAN_ROW_WORDS];
+
 static long check(float im, float re)
 {
-    const float a = atan2f(im, re), b = wm_atan2f(im, re);
-    if (wm_f2u(a) != wm_f2u(b)) {
+    const float a = atan2f(im, re), b = wm_atan2f(im, re), b2 = wm_atan2f_tab(im, re, TAB);
+    if (wm_f2u(a) != wm_f2u(b) || wm_f2u(a) != wm_f2u(b2)) {
         static int shown;
-        if (shown++ < 10) printf("MISMATCH atan2f(%a,%a): libm %a ours %a\n", im, re, a, b);
+        if (shown++ < 10) printf("MISMATCH atan2f(%a,%a): libm %a ours %a table form %a\n", im, re, a, b, b2);
         return 1;
     }
     return 0;
@@ -24,6 +26,7 @@ int main(int argc, char **argv)
 {
     const long n = argc > 1 ? atol(argv[1]) : 10000000;
     long bad = 0, tot = 0;
+    for (int j = 0; j < WM_ATAN_ROWS; j++) wm_atan_row(j, TAB + WM_ATAN_ROW_WORDS * j);
     /* exhaustive small grid, both scalings (k/8 and k/16 operands) */
     for (int sc = 64; sc <= 256; sc *= 4)
         for (int y = -300; y <= 300; y++)
@@ -49,6 +52,8 @@ int main(int argc, char **argv)
         /* whole discriminator vs the reference's expression cargf(y)*(float)M_1_PI */
         const float ref = atan2f(im, re) * (float)M_1_PI;
         if (wm_f2u(ref) != wm_f2u(wm_discriminator(i, q, pi_, pq_))) bad++;
+        /* the kernels feed the table form with the unscaled boxcar sums */
+        if (wm_f2u(ref) != wm_f2u(wm_discriminator_tab((float)v[0], (float)v[1], (float)v[2], (float)v[3], TAB))) bad++;
     }
     printf("checked %ld cases, %ld mismatches\n", tot, bad);
     return bad != 0;
