@@ -144,8 +144,8 @@ template <int D, bool SHIFT> int launch_k1v2(wmbus_ctx *c, const K1Args &a, uint
 /* The kernels' arithmetic (table-driven atan2 included) on arbitrary operand pairs. */
 __global__ void k_selftest(const float *a, const float *b, float *o_sqrt, float *o_div, float *o_atan2, float *o_disc, uint32_t n)
 {
-    __shared__ float tab[WM_ATAN_ROWS * WM_ATAN_ROW_WORDS];
-    for (int j = threadIdx.x; j < WM_ATAN_ROWS; j += blockDim.x) wm_atan_row(j, tab + WM_ATAN_ROW_WORDS * j);
+    __shared__ float tab[WM_ATAN_TAB_WORDS];
+    for (int k = threadIdx.x; k < WM_ATAN_TAB_WORDS; k += blockDim.x) wm_atan_tab_word(k, tab);
     __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -379,6 +379,7 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
     g.Mcap = c->Mcap; g.d = c->d; g.S = c->S; g.lut_n = 32 * c->d;
     g.lut_phase0 = (uint32_t)((13ull * (c->n0 % g.lut_n)) % g.lut_n);
     g.flags = c->flags;
+    if (const char *e = getenv("WMBUS_K1_DEBUG")) g.flags |= (uint32_t)atoi(e) << 8;   /* timing experiments: skip K1 stages */
     for (int al = 0; al < 2; al++) {
         g.seg_len[al] = c->C[al]; g.nseg[al] = (g.M + c->C[al] - 1) / c->C[al]; g.nseg_cap[al] = c->nseg_cap[al]; g.cap[al] = c->cap[al];
     }

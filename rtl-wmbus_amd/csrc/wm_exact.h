@@ -127,8 +127,9 @@ WM_HD float wm_atan2f(float y, float x)
  * A*t is exact for A in {0,1,2} and C*t is the product the original forms (1.5*t) or exact, so
  * num and den carry exactly the roundings of the branchy code.  All four range limits are
  * multiples of 2^18 in the float's bit pattern, so `bits(t) >> 18` indexes a row table directly
- * (81 rows of 8 floats: 79 distinct prefixes between 7/16 and 39/16 plus one row below and one
- * above); one 32-byte row fetch replaces 4 compares, 14 selects and the four (num, den) pairs.
+ * (79 distinct prefixes between 7/16 and 39/16 plus everything below and everything above): a
+ * byte LUT gives the range, one 32-byte row fetch gives its constants; together they replace 4
+ * compares, 14 selects and the four (num, den) pairs.
  *
  * Reachable-domain pruning (documented, checked by tests/exact_math_check.c on the discriminator's
  * operand domain and on the device by wmbus_selftest_math): the discriminator's operands are
@@ -137,21 +138,36 @@ WM_HD float wm_atan2f(float y, float x)
  * exponent-gap (> 60) shortcuts of the original can therefore not trigger and are dropped; zero
  * operands keep their exact special cases (signed zeros matter: atan2f(-0, x<0) = -pi).
  * ------------------------------------------------------------------------------------------- */
-#define WM_ATAN_ROWS      81
+#define WM_ATAN_RANGES    5
 #define WM_ATAN_ROW_WORDS 8
+#define WM_ATAN_LUT_BYTES 81
 #define WM_ATAN_U0        0xFB8u      /* bits(7/16) >> 18 */
+#define WM_ATAN_TAB_WORDS (WM_ATAN_RANGES * WM_ATAN_ROW_WORDS + 24)   /* 5 rows + 81-byte range LUT, padded */
 
-/* Row j of the table (j = clamp((bits(t) >> 18) - (U0 - 1), 0, 80)). */
-WM_HD void wm_atan_row(int j, float *row)
+/* Table = 5 rows {A, B, C, D, hi, lo, 0, 0} followed by an 81-byte LUT: range of prefix
+ * j = clamp((bits(t) >> 18) - (U0 - 1), 0, 80).  On the device it lives in LDS: the LUT's bytes
+ * share 21 dwords in distinct banks and the 5 rows sit 32 bytes apart, so neither fetch can
+ * conflict whatever the lanes' arguments are (lanes reading the same row are a broadcast). */
+WM_HD void wm_atan_tab_word(int k, float *tab)        /* fills word k of the table, k < WM_ATAN_TAB_WORDS */
 {
-    const uint32_t u = WM_ATAN_U0 - 1u + (uint32_t)j;
-    const int idx = j == 0 ? 0 : 1 + (u >= (0x3f300000u >> 18)) + (u >= (0x3f980000u >> 18)) + (u >= (0x401c0000u >> 18));
     const float A[5] = {1.0f, 2.0f, 1.0f, 1.0f, 0.0f}, B[5] = {0.0f, -1.0f, -1.0f, -1.5f, -1.0f};
     const float C[5] = {0.0f, 1.0f, 1.0f, 1.5f, 1.0f}, D[5] = {1.0f, 2.0f, 1.0f, 1.0f, 0.0f};
     const uint32_t hi[5] = {0u, 0x3eed6338u, 0x3f490fdau, 0x3f7b985eu, 0x3fc90fdau};
     const uint32_t lo[5] = {0u, 0x31ac3769u, 0x33222168u, 0x33140fb4u, 0x33a22168u};
-    row[0] = A[idx]; row[1] = B[idx]; row[2] = C[idx]; row[3] = D[idx];
-    row[4] = wm_u2f(hi[idx]); row[5] = wm_u2f(lo[idx]); row[6] = 0.0f; row[7] = 0.0f;
+    if (k < WM_ATAN_RANGES * WM_ATAN_ROW_WORDS) {
+        const int r = k >> 3, c = k & 7;
+        tab[k] = c == 0 ? A[r] : c == 1 ? B[r] : c == 2 ? C[r] : c == 3 ? D[r] : c == 4 ? wm_u2f(hi[r]) : c == 5 ? wm_u2f(lo[r]) : 0.0f;
+    } else {
+        uint32_t w = 0;
+        for (int b = 0; b < 4; b++) {
+            const int j = 4 * (k - WM_ATAN_RANGES * WM_ATAN_ROW_WORDS) + b;
+            const uint32_t u = WM_ATAN_U0 - 1u + (uint32_t)j;
+            const uint32_t idx = j == 0 ? 0u : j > 80 ? 4u
+                : 1u + (u >= (0x3f300000u >> 18)) + (u >= (0x3f980000u >> 18)) + (u >= (0x401c0000u >> 18));
+            w |= idx << (8 * b);
+        }
+        tab[k] = wm_u2f(w);
+    }
 }
 
 WM_HD float wm_copysign_bits(float mag, uint32_t sign_src) { return wm_u2f((wm_f2u(mag) & 0x7fffffffu) | (sign_src & 0x80000000u)); }
@@ -162,8 +178,9 @@ WM_HD float wm_atan2f_tab(float y, float x, const float *tab)
     const float pi = wm_u2f(0x40490fdbu), pi_o_2 = wm_u2f(0x3fc90fdbu), pi_lo = wm_u2f(0xb3bbbd2eu);
     const float t = wm_u2f(wm_f2u(wm_div(y, x)) & 0x7fffffffu);       /* fabsf(y/x) */
     int j = (int)(wm_f2u(t) >> 18) - (int)(WM_ATAN_U0 - 1u);
-    j = j < 0 ? 0 : (j > WM_ATAN_ROWS - 1 ? WM_ATAN_ROWS - 1 : j);
-    const float *e = tab + WM_ATAN_ROW_WORDS * j;
+    j = j < 0 ? 0 : (j > WM_ATAN_LUT_BYTES - 1 ? WM_ATAN_LUT_BYTES - 1 : j);
+    const uint32_t idx = ((const uint8_t *)(tab + WM_ATAN_RANGES * WM_ATAN_ROW_WORDS))[j];
+    const float *e = tab + WM_ATAN_ROW_WORDS * idx;
     const float num = wm_add(wm_mul(e[0], t), e[1]);
     const float den = wm_add(wm_mul(e[2], t), e[3]);
     const float r = wm_div(num, den);

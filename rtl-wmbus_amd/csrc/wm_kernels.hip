@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void k1_demod(K1Args a)
  *   stage B2 RSSI EMA: one wave per chain, 16 samples per lane behind a 48-sample warm-up
  *            (first generation: all four waves, 8 samples per lane behind the same warm-up).
  * LDS (words): U[max(staging, 2 magnitude rows)] | yDrT[YD] yDrS[YD] | sFin[128] sHead[128] |
- *              atan rows[81*8] = 20.6 KB at d = 2 (7 workgroups per CU).  The magnitude rows
+ *              atan table[64] = 18.3 KB at d = 2 (8 workgroups per CU).  The magnitude rows
  *              overlay the staging area: stage A keeps its 8 magnitudes in registers until the
  *              barrier that retires the staging data.
  * ===========================================================================================*/
@@ -297,7 +297,7 @@ template <int D> struct K1Geo {
     static constexpr int U(bool shift) { return ustage(shift) > 2 * YM ? ustage(shift) : 2 * YM; }
     static constexpr size_t smem(bool shift)
     {
-        return (size_t)(U(shift) + 2 * YD + 256 + WM_ATAN_ROWS * WM_ATAN_ROW_WORDS) * 4;
+        return (size_t)(U(shift) + 2 * YD + 256 + WM_ATAN_TAB_WORDS) * 4;
     }
 };
 static_assert(K1Geo<2>::NA == 1024, "stage A maps one 4-sample chunk to each of the 256 threads");
@@ -345,50 +345,59 @@ __global__ __launch_bounds__(256) void k1_demod2(K1Args a)
     const int tn = min(T, (int)g.M - ts);
     const bool chT = g.flags & WM_F_T1C1, chS = g.flags & WM_F_S1;
     const bool accurate = g.flags & WM_F_ACCURATE;
+    const bool dbgA = g.flags & 256u, dbgF = g.flags & 512u, dbgE = g.flags & 1024u, dbg0 = g.flags & 2048u;   /* timing experiments */
 
-    /* atan range rows (81 x 8 floats) */
-    for (int j = tid; j < WM_ATAN_ROWS; j += 256) wm_atan_row(j, tab + WM_ATAN_ROW_WORDS * j);
+    if (tid < WM_ATAN_TAB_WORDS) wm_atan_tab_word(tid, tab);   /* 5 range rows + range LUT */
 
-    /* ---- stage 0 --------------------------------------------------------------------------- */
+    /* ---- stage 0: one dword (two IQ samples) per lane and pass: coalesced loads, LDS stores at a
+     * two-word lane stride (the 16-byte-per-lane variant stored at an 8-word stride: 8-way bank
+     * conflicts) ------------------------------------------------------------------------------- */
     {
         const long r_lo = ((long)(g.m0 + (uint64_t)ts) - WM_K1_HALO) * D - 16 - (long)g.n0;   /* LDS word 0 */
-        const long r_al = r_lo & ~7L;
-        const int off = (int)(r_lo - r_al);
-        const int nchunk = (NA * D + 16 + off + 7) >> 3;
+        const long r_al = r_lo & ~1L;
+        const int off = (int)(r_lo - r_al);                   /* 0 or 1 */
+        constexpr int NDW = (NA * D + 16 + 1 + 1) / 2;        /* dwords covering the staged samples */
         const uint8_t *base = g.in + (uint64_t)stream * g.in_stride + WM_HIST_BYTES;
-        for (int c = tid; c < nchunk; c += 256) {
-            const long r = r_al + 8L * c;
-            const uint4 v = *(const uint4 *)(base + 2 * r);
-            const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
-            const int p0 = 8 * c - off;
-            uint32_t li = 0;
-            if (SHIFT) {
-                const int L = (int)g.lut_n;
-                int rm = (int)(r % L); if (rm < 0) rm += L;
-                li = (g.lut_phase0 + 13u * (uint32_t)rm) % (uint32_t)L;
-            }
+        const uint32_t *src = (const uint32_t *)(base + 2 * r_al);
+        constexpr int NP = (NDW + 255) / 256;
+        uint32_t wv[NP];
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int p = p0 + k;
+        for (int it = 0; it < NP; it++) {
+            const int u = tid + 256 * it;
+            wv[it] = u < NDW ? src[u] : 0u;
+        }
+#pragma unroll
+        for (int it = 0; it < NP; it++) {
+            const int u = tid + 256 * it;
+            if (u < NDW && !dbg0) {
+                const int p = 2 * u - off;
                 if (!SHIFT) {
                     /* bytes (i,q) -> halfwords, then u - 127 - (u >> 7) per halfword
                      * (= (int)((float)u - 127.5f), rtl_wmbus.c:1312-1313 + moving_average_filter.h:47) */
-                    const uint32_t h = __builtin_amdgcn_perm(0u, wv[k >> 1], (k & 1) ? 0x0c030c02u : 0x0c010c00u);
-                    const wm_s2 hv = __builtin_bit_cast(wm_s2, h);
                     const wm_s2 c127 = {127, 127};
-                    const wm_s2 top = __builtin_bit_cast(wm_s2, (h >> 7) & 0x00010001u);
-                    const wm_s2 q = hv - c127 - top;
-                    stgT[p] = __builtin_bit_cast(uint32_t, q);
+#pragma unroll
+                    for (int k = 0; k < 2; k++) {
+                        const uint32_t h = __builtin_amdgcn_perm(0u, wv[it], k ? 0x0c030c02u : 0x0c010c00u);
+                        const wm_s2 q = __builtin_bit_cast(wm_s2, h) - c127 - __builtin_bit_cast(wm_s2, (h >> 7) & 0x00010001u);
+                        stgT[p + k] = __builtin_bit_cast(uint32_t, q);
+                    }
                 } else {
-                    const uint32_t iq = (wv[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
-                    const float fi = wm_sub((float)(iq & 0xFFu), 127.5f), fq = wm_sub((float)(iq >> 8), 127.5f);
-                    const float x = a.lut_cos[li], z = a.lut_msin[li];
-                    li += 13u; if (li >= g.lut_n) li -= g.lut_n;
-                    const float ix = wm_mul(fi, x), qx = wm_mul(fq, x), iz = wm_mul(fi, z), qz = wm_mul(fq, z);
-                    wm_s2 t, s;
-                    t.x = (short)(int)wm_sub(ix, qz); t.y = (short)(int)wm_add(qx, iz);
-                    s.x = (short)(int)wm_add(ix, qz); s.y = (short)(int)wm_sub(qx, iz);
-                    stgT[p] = __builtin_bit_cast(uint32_t, t); stgS[p] = __builtin_bit_cast(uint32_t, s);
+                    /* LUT index of global sample n: (13 n) mod lut_n, rtl_wmbus.c:1006-1010 */
+                    const int L = (int)g.lut_n;
+                    int rm = (int)((r_al + 2L * u) % L); if (rm < 0) rm += L;
+                    uint32_t li = (g.lut_phase0 + 13u * (uint32_t)rm) % (uint32_t)L;
+#pragma unroll
+                    for (int k = 0; k < 2; k++) {
+                        const uint32_t iq = (wv[it] >> (16 * k)) & 0xFFFFu;
+                        const float fi = wm_sub((float)(iq & 0xFFu), 127.5f), fq = wm_sub((float)(iq >> 8), 127.5f);
+                        const float x = a.lut_cos[li], z = a.lut_msin[li];
+                        li += 13u; if (li >= g.lut_n) li -= g.lut_n;
+                        const float ix = wm_mul(fi, x), qx = wm_mul(fq, x), iz = wm_mul(fi, z), qz = wm_mul(fq, z);
+                        wm_s2 t, sv;
+                        t.x = (short)(int)wm_sub(ix, qz); t.y = (short)(int)wm_add(qx, iz);
+                        sv.x = (short)(int)wm_add(ix, qz); sv.y = (short)(int)wm_sub(qx, iz);
+                        stgT[p + k] = __builtin_bit_cast(uint32_t, t); stgS[p + k] = __builtin_bit_cast(uint32_t, sv);
+                    }
                 }
             }
         }
@@ -403,6 +412,10 @@ __global__ __launch_bounds__(256) void k1_demod2(K1Args a)
         k1_boxcars<D>(stgT + 4 * c * D, s8, SHIFT ? u16 : s16);
         if (SHIFT) k1_boxcars<D>(stgS + 4 * c * D, u8, s16);
         float drT[4], drS[4];
+        if (dbgA) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) { drT[j] = (float)s8[j + 1].x; drS[j] = (float)s16[j + 1].y; mgT[j] = (float)s8[j].y; mgS[j] = (float)s16[j].x; }
+        } else {
         if (chT) {
             float pi_ = (float)s8[0].x, pq_ = (float)s8[0].y;
 #pragma unroll
@@ -431,6 +444,7 @@ __global__ __launch_bounds__(256) void k1_demod2(K1Args a)
 #pragma unroll
             for (int j = 0; j < 4; j++) drS[j] = mgS[j] = 0.0f;
         }
+        }
         /* element a of a discriminator row lives at word a + 4 */
         *(float4 *)(yDrT + 4 * c + 4) = make_float4(drT[0], drT[1], drT[2], drT[3]);
         *(float4 *)(yDrS + 4 * c + 4) = make_float4(drS[0], drS[1], drS[2], drS[3]);
@@ -446,7 +460,7 @@ __global__ __launch_bounds__(256) void k1_demod2(K1Args a)
     {
         const int m0l = 4 * tid;
         const uint64_t row = (uint64_t)stream * g.Mcap + (uint64_t)ts + m0l;
-        if (chT && m0l < tn) {
+        if (chT && m0l < tn && !dbgF) {
             float w[16];                                      /* w[i] = element 4 tid + 36 + i */
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -463,7 +477,7 @@ __global__ __launch_bounds__(256) void k1_demod2(K1Args a)
             }
             *(float4 *)(a.dphi + row) = make_float4(acc[0], acc[1], acc[2], acc[3]);
         }
-        if (chS && m0l < tn) {
+        if (chS && m0l < tn && !dbgF) {
             float w[52];                                      /* w[i] = element 4 tid + i */
 #pragma unroll
             for (int k = 0; k < 13; k++) {
@@ -487,7 +501,7 @@ __global__ __launch_bounds__(256) void k1_demod2(K1Args a)
     /* ---- stage B2: RSSI = EMA(|s|), alpha = 0.6789 (rtl_wmbus.c:475-495) --------------------- */
     {
         const int ch = tid >> 6, e = tid & 63;               /* wave 0: T1/C1, wave 1: S1 */
-        const bool on = ch < 2 && (ch ? chS : chT) && 16 * e < T;
+        const bool on = ch < 2 && (ch ? chS : chT) && 16 * e < T && !dbgE;
         const float *mg = (ch ? yMgS : yMgT) + 17 * e;        /* element 16 e + kk at 17 e + kk + kk/16 */
         const float al = 0.6789f, be = wm_sub(1.0f, 0.6789f);
         const int m0l = 16 * e;

@@ -9,7 +9,7 @@
 static uint64_t s = 0x1234567887654321ull;
 static uint64_t rnd(void) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; }
 
-static float TAB[WM_ATAN_ROWS * WM_ATAN_ROW_WORDS];
+static float TAB[WM_ATAN_TAB_WORDS];
 
 static long check(float im, float re)
 {
@@ -26,7 +26,7 @@ int main(int argc, char **argv)
 {
     const long n = argc > 1 ? atol(argv[1]) : 10000000;
     long bad = 0, tot = 0;
-    for (int j = 0; j < WM_ATAN_ROWS; j++) wm_atan_row(j, TAB + WM_ATAN_ROW_WORDS * j);
+    for (int k = 0; k < WM_ATAN_TAB_WORDS; k++) wm_atan_tab_word(k, TAB);
     /* exhaustive small grid, both scalings (k/8 and k/16 operands) */
     for (int sc = 64; sc <= 256; sc *= 4)
         for (int y = -300; y <= 300; y++)

@@ -3,6 +3,6 @@
 mkdir -p gpurun_out; export TMPDIR=/tmp
 for v in "$@"; do
   echo "=== $v"
-  ( env $v timeout 600 python bench.py --steps 2 --warmup 1 --contexts 1 --no-cpu-baseline --no-check ) > gpurun_out/ab.log 2>&1
-  grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*\|"stage_ms_last_step": \[{[^}]*}' gpurun_out/ab.log; tail -2 gpurun_out/ab.log | cut -c1-200 | grep -v value
+  ( env $v timeout 600 python bench.py --steps 2 --warmup 1 --contexts 1 --streams ${STREAMS:-256} --no-cpu-baseline --no-check ) > gpurun_out/ab.log 2>&1
+  grep -o '"stage_ms_last_step": \[{[^}]*}' gpurun_out/ab.log || tail -5 gpurun_out/ab.log
 done

@@ -97,6 +97,34 @@ DEF_BENCH(cvtub, F8, F8I, OPCVTU(a0) OPCVTU(a1) OPCVTU(a2) OPCVTU(a3) OPCVTU(a4)
 #define OPDS(x) asm volatile("v_div_scale_f32 %0, vcc, %0, %1, %1" : "+v"(x) : "v"(b) : "vcc");
 DEF_BENCH(dscale, F8, F8I, OPDS(a0) OPDS(a1) OPDS(a2) OPDS(a3) OPDS(a4) OPDS(a5) OPDS(a6) OPDS(a7), OPDS(a0), F8S)
 
+
+// ---- third batch: operand kinds ------------------------------------------------------------------
+#define OPLIT(x) asm volatile("v_mul_f32 %0, 0x3f7c0e52, %0" : "+v"(x));
+DEF_BENCH(mullit, F8, F8I, OPLIT(a0) OPLIT(a1) OPLIT(a2) OPLIT(a3) OPLIT(a4) OPLIT(a5) OPLIT(a6) OPLIT(a7), OPLIT(a0), F8S)
+#define OPSG(x) asm volatile("v_mul_f32 %0, s20, %0" : "+v"(x) : : "s20");
+DEF_BENCH(mulsgpr, F8, F8I, OPSG(a0) OPSG(a1) OPSG(a2) OPSG(a3) OPSG(a4) OPSG(a5) OPSG(a6) OPSG(a7), OPSG(a0), F8S)
+#define OPINL(x) asm volatile("v_mul_f32 %0, 0.5, %0" : "+v"(x));
+DEF_BENCH(mulinl, F8, F8I, OPINL(a0) OPINL(a1) OPINL(a2) OPINL(a3) OPINL(a4) OPINL(a5) OPINL(a6) OPINL(a7), OPINL(a0), F8S)
+// FIR-like: t = lit * w ; acc = acc + t   (two instructions per OP; 4 accumulators in flight)
+#define OPFIRL(acc, w) asm volatile("v_mul_f32 %1, 0x3f7c0e52, %2\n\tv_add_f32 %0, %0, %1" : "+v"(acc), "=&v"(tmpf) : "v"(w));
+#define OPFIRS(acc, w) asm volatile("v_mul_f32 %1, s20, %2\n\tv_add_f32 %0, %0, %1" : "+v"(acc), "=&v"(tmpf) : "v"(w) : "s20");
+#define F8T float a0, a1, a2, a3, a4, a5, a6, a7, b, tmpf
+DEF_BENCH(firlit, F8T, F8I, OPFIRL(a0, a4) OPFIRL(a1, a5) OPFIRL(a2, a6) OPFIRL(a3, a7) OPFIRL(a0, a5) OPFIRL(a1, a6) OPFIRL(a2, a7) OPFIRL(a3, a4), OPFIRL(a0, a4), F8S)
+DEF_BENCH(firsgpr, F8T, F8I, OPFIRS(a0, a4) OPFIRS(a1, a5) OPFIRS(a2, a6) OPFIRS(a3, a7) OPFIRS(a0, a5) OPFIRS(a1, a6) OPFIRS(a2, a7) OPFIRS(a3, a4), OPFIRS(a0, a4), F8S)
+// three distinct VGPR operands
+#define OP3R(x, y, z) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(x) : "v"(y), "v"(z));
+DEF_BENCH(mul3r, F8, F8I, OP3R(a0, a1, a2) OP3R(a1, a2, a3) OP3R(a2, a3, a4) OP3R(a3, a4, a5) OP3R(a4, a5, a6) OP3R(a5, a6, a7) OP3R(a6, a7, a0) OP3R(a7, a0, a1), OP3R(a0, a0, a1), F8S)
+#define OPSUB(x) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(x) : "v"(b));
+DEF_BENCH(sub, F8, F8I, OPSUB(a0) OPSUB(a1) OPSUB(a2) OPSUB(a3) OPSUB(a4) OPSUB(a5) OPSUB(a6) OPSUB(a7), OPSUB(a0), F8S)
+#define OPCVTI(x) asm volatile("v_cvt_u32_f32 %0, %0" : "+v"(x));
+DEF_BENCH(cvtu32, F8, F8I, OPCVTI(a0) OPCVTI(a1) OPCVTI(a2) OPCVTI(a3) OPCVTI(a4) OPCVTI(a5) OPCVTI(a6) OPCVTI(a7), OPCVTI(a0), F8S)
+#define OPMOV(x) asm volatile("v_mov_b32 %0, %1" : "=v"(x) : "v"(b));
+DEF_BENCH(mov, F8, F8I, OPMOV(a0) OPMOV(a1) OPMOV(a2) OPMOV(a3) OPMOV(a4) OPMOV(a5) OPMOV(a6) OPMOV(a7), OPMOV(a0), F8S)
+#define OPXOR(x) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(x) : "v"(b));
+DEF_BENCH(xor_, F8, F8I, OPXOR(a0) OPXOR(a1) OPXOR(a2) OPXOR(a3) OPXOR(a4) OPXOR(a5) OPXOR(a6) OPXOR(a7), OPXOR(a0), F8S)
+#define OPMULLO(x) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(x) : "v"(b));
+DEF_BENCH(mulu24, F8, F8I, OPMULLO(a0) OPMULLO(a1) OPMULLO(a2) OPMULLO(a3) OPMULLO(a4) OPMULLO(a5) OPMULLO(a6) OPMULLO(a7), OPMULLO(a0), F8S)
+
 // LDS read throughput / latency
 __global__ void lds_b32(uint64_t *out, float seed) {
     __shared__ float s[4096];
@@ -132,7 +160,7 @@ int main()
     uint64_t *d_out; hipMalloc(&d_out, 8 * 1000001 + 64);
     Entry e[] = {
 #define E(n) {#n, n##_thr, n##_lat}
-        E(mul), E(add), E(fma), E(rcp), E(sqrt), E(cvt), E(cnd), E(fixup), E(fmas), E(pki16), E(pkmul), E(pkadd), E(pkfma), E(and_), E(lshl), E(addu), E(maxf), E(bfi), E(med3), E(perm), E(mad24), E(and_or), E(cnd64), E(cmp), E(cmp64), E(cmpcnd), E(mix31), E(cvtub), E(dscale)};
+        E(mul), E(add), E(fma), E(rcp), E(sqrt), E(cvt), E(cnd), E(fixup), E(fmas), E(pki16), E(pkmul), E(pkadd), E(pkfma), E(and_), E(lshl), E(addu), E(maxf), E(bfi), E(med3), E(perm), E(mad24), E(and_or), E(cnd64), E(cmp), E(cmp64), E(cmpcnd), E(mix31), E(cvtub), E(dscale), E(mullit), E(mulsgpr), E(mulinl), E(firlit), E(firsgpr), E(mul3r), E(sub), E(cvtu32), E(mov), E(xor_), E(mulu24)};
     // s_memtime / readcyclecounter ticks: report raw ticks per wave-instruction
     printf("%-8s %12s %12s %12s %12s   (ticks per wave-instruction; thr = 8 indep chains, lat = 1 chain)\n", "op", "thr 1w/SIMD", "thr 4w/SIMD",
            "thr 8w/SIMD", "lat 1w/SIMD");
