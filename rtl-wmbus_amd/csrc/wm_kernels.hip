@@ -645,21 +645,136 @@ __device__ __forceinline__ int wm_sdiv(int a, int b)
     return a < 0 ? -(int)q : (int)q;
 }
 
-#define WM_RSSI_ROW 9            /* u32 words per lane in the LDS rssi staging (32 bytes + pad)  */
+#define WM_RSSI_ROW 9            /* u32 words per lane in the LDS rssi staging (32 bytes + pad), run-length kernel */
+#define WM_CLK_XROW 36           /* words per lane in the clock kernel's soft-symbol buffer: 32 + 4 (rows stay 16-byte
+                                    aligned; a lane's 8 ds_read_b128 are bank-conflict free: 9 L mod 16 is a permutation) */
+#define WM_CLK_RROW 12           /* words per lane in its RSSI buffer: 32 bytes + 16 */
+
+/* Level of the recovered clock = (y * gain >= 0) with gain = 1.874981046e-06f (iir.h:74, rtl_wmbus.c:338,353,
+ * 1089).  The product is only ever compared with zero, and it is >= 0 exactly when y is not below
+ * -266669 * 2^-149 (the largest negative y whose product rounds to -0; found by running the multiply
+ * over every subnormal y on the host, tests/test_exact_math.py).  On the bit pattern this is one
+ * carry: bits(y) + WM_LEVEL_CARRY overflows 32 bits <=> level low. */
+#define WM_LEVEL_CARRY 0x7FFBEE52u      /* 0xFFFFFFFF - (0x80000000 + 266669) */
+
+/* 32 samples through [DC remover] -> x^2 -> 3 biquads -> clock level, SOFTWARE-PIPELINED across the
+ * filter sections: at tick t section k works on sample t - k, so the three (four with -o) recurrences
+ * of a tick are independent instruction streams; a lone wave issues a dependent VALU operation only
+ * every ~8.5 cycles on gfx950, and the straight per-sample order is one 36-deep dependent chain.
+ * The compiler's scheduler would undo the interleaving (it sinks each section's recurrence into one
+ * serial run over the block), so the levels of a tick are fenced with sched_barrier.  The pipeline
+ * drains at the end of the block: the lane state at block boundaries is the plain sequential
+ * state.  Every value is produced by exactly the operations of iir.h:57-74 / rtl_wmbus.c:497-515.
+ *
+ * Bits: the slicer output (soft >= 0, rtl_wmbus.c:1059) is the inverted sign bit -- a soft symbol
+ * is never -0 (the FIR accumulates from +0, and +0 + -0 = +0; the DC remover's x - x_old is never
+ * -0 either) -- shifted into a word with one v_alignbit; clock levels via WM_LEVEL_CARRY. */
+template <bool DC>
+__device__ __forceinline__ void clk_block32(WmClkState &s, const IirCoef &c, const float *xrow, uint32_t &bitw, uint32_t &smask)
+{
+    /* xrow: this lane's 32 soft symbols in LDS; four are fetched every fourth tick, so the block in
+     * flight and the one after it can stay in registers (two blocks of loads outstanding per lane) */
+    float4 xq = {0.0f, 0.0f, 0.0f, 0.0f};
+    constexpr int P = DC ? 1 : 0;                          /* pipeline depth before the first biquad */
+    float h1[3] = {s.h[0], s.h[2], s.h[4]}, h2[3] = {s.h[1], s.h[3], s.h[5]};
+    float dcx = s.dc_x, dcy = s.dc_y;
+    float in[3] = {0.0f, 0.0f, 0.0f};                      /* input of section k at the coming tick */
+    float soft = 0.0f;                                     /* DC stage output waiting for section 0 */
+    uint32_t sgn = 0, low = 0;                             /* MSB-first: sample n ends up in bit 31 - n */
+    const float al = 0.999f, kk = wm_div(wm_add(1.0f, al), 2.0f);
+#pragma unroll
+    for (int t = 0; t < 32 + P + 2; t++) {
+        float m1[3], m2[3], p1[3], p2[3], tt[3], h0[3], u[3], o[3];
+        float d1 = 0.0f, d2 = 0.0f, d3 = 0.0f;
+        if (t < 32 && (t & 3) == 0) xq = *(const float4 *)(xrow + t);
+        const float xt = (t & 3) == 0 ? xq.x : (t & 3) == 1 ? xq.y : (t & 3) == 2 ? xq.z : xq.w;   /* sample t (t < 32) */
+        /* level 1: every product that only needs last tick's state */
+        if (DC && t < 32) { d1 = wm_sub(xt, dcx); d2 = wm_mul(al, dcy); }
+        {   /* section 0's input: the (DC-filtered) soft symbol, squared */
+            const int n0 = t - P;
+            if (n0 >= 0 && n0 < 32) {
+                const float sf = DC ? soft : xt;
+                sgn = __builtin_amdgcn_alignbit(sgn, wm_f2u(sf), 31);      /* (sgn << 1) | signbit */
+                in[0] = wm_mul(sf, sf);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int n = t - P - k;
+            if (n >= 0 && n < 32) {
+                m1[k] = wm_mul(c.a1[k], h1[k]); m2[k] = wm_mul(c.a2[k], h2[k]);
+                p1[k] = wm_mul(c.b1[k], h1[k]); p2[k] = wm_mul(c.b2[k], h2[k]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        /* level 2 */
+        if (DC && t < 32) d3 = wm_mul(kk, d1);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { const int n = t - P - k; if (n >= 0 && n < 32) tt[k] = wm_add(m1[k], m2[k]); }
+        __builtin_amdgcn_sched_barrier(0);
+        /* level 3 */
+        if (DC && t < 32) { const float y = wm_add(d3, d2); dcx = xt; dcy = y; soft = y; }
+#pragma unroll
+        for (int k = 0; k < 3; k++) { const int n = t - P - k; if (n >= 0 && n < 32) h0[k] = wm_sub(in[k], tt[k]); }
+        __builtin_amdgcn_sched_barrier(0);
+        /* level 4, 5 */
+#pragma unroll
+        for (int k = 0; k < 3; k++) { const int n = t - P - k; if (n >= 0 && n < 32) u[k] = wm_add(h0[k], p1[k]); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { const int n = t - P - k; if (n >= 0 && n < 32) o[k] = wm_add(u[k], p2[k]); }
+        /* hand over: section k's output is section k+1's input at the next tick */
+#pragma unroll
+        for (int k = 2; k >= 0; k--) {
+            const int n = t - P - k;
+            if (n >= 0 && n < 32) {
+                h2[k] = h1[k]; h1[k] = h0[k];
+                if (k < 2) in[k + 1] = o[k];
+                else {
+                    uint32_t tmp;
+                    asm("v_add_co_u32 %1, vcc, %3, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                        : "+v"(low), "=&v"(tmp) : "v"(wm_f2u(o[2])), "s"(WM_LEVEL_CARRY) : "vcc");
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    s.h[0] = h1[0]; s.h[1] = h2[0]; s.h[2] = h1[1]; s.h[3] = h2[1]; s.h[4] = h1[2]; s.h[5] = h2[2];
+    s.dc_x = dcx; s.dc_y = dcy;
+    bitw = ~__builtin_bitreverse32(sgn);
+    /* clock lock (rtl_wmbus.c:1092-1111): take the bit at n iff the levels at n-3..n are L,H,H,H */
+    /* WmClkState.clk keeps the last three levels with the NEWEST in bit 0; here time runs upwards */
+    const uint32_t prev3 = ((s.clk & 1u) << 2) | (s.clk & 2u) | ((s.clk >> 2) & 1u);
+    const uint64_t H = ((uint64_t)(~__builtin_bitreverse32(low)) << 3) | prev3;           /* bit n+3 = level at n */
+    smask = (uint32_t)((~H) & (H >> 1) & (H >> 2) & (H >> 3));
+    const uint32_t last3 = (uint32_t)(H >> 32) & 7u;                                        /* levels at 29, 30, 31 */
+    s.clk = ((last3 & 1u) << 2) | (last3 & 2u) | ((last3 >> 2) & 1u);
+}
 
 /* Clock-recovery lane.  The reference's lock counter (rtl_wmbus.c:1092-1111: rising edge -> 1,
  * still high -> 2, third high sample -> take the bit) is equivalent to "sample at n iff the clock
  * levels at n-3..n are L,H,H,H" (checked exhaustively over all level sequences);
- * the lane state keeps the last three levels. */
+ * the lane state keeps the last three levels.
+ *
+ * Memory: a lane walks its own row (stream, chain) of soft symbols, 128 bytes per 32-sample block.
+ * When the 64 lanes of the wave are 64 consecutive streams of one (chain, segment) -- n_streams a
+ * multiple of 64, first pass -- the wave fetches the 64 rows' blocks COOPERATIVELY: 8 lanes per
+ * row read one whole 128-byte line, and the block is transposed through LDS (conflict-free, see
+ * WM_CLK_XROW).  Lane-private 16-byte loads of the same data touch 64 lines per instruction and
+ * re-fetch each line from L2 several times.  Re-run launches and odd stream counts take the
+ * lane-private path. */
 template <bool DC>
 __global__ __launch_bounds__(64) void k2_clock(K2Args a)
 {
-    __shared__ uint32_t s_rssi[64 * WM_RSSI_ROW];
-    uint32_t lane = blockIdx.x * 64 + threadIdx.x;
-    if (lane >= a.n_lanes) return;
+    __shared__ __attribute__((aligned(16))) float s_x[64 * WM_CLK_XROW];
+    __shared__ __attribute__((aligned(16))) uint32_t s_rssi[64 * WM_CLK_RROW];
+    const uint32_t ln = threadIdx.x;
+    uint32_t lane = blockIdx.x * 64 + ln;
     const bool rerun = a.list != nullptr;
-    if (rerun) lane = a.list[lane];
     const WmPush &g = a.g;
+    const bool coop = !rerun && (g.S % 64u) == 0u;         /* wave = 64 consecutive streams, lock step */
+    if (lane >= a.n_lanes) return;
+    if (rerun) lane = a.list[lane];
     uint32_t ch, stream, seg;
     lane_decode(g, 1, lane, ch, stream, seg);
     if (!(g.flags & (ch ? WM_F_S1 : WM_F_T1C1))) return;
@@ -682,13 +797,20 @@ __global__ __launch_bounds__(64) void k2_clock(K2Args a)
     const bool t2a = g.flags & WM_F_T2A;
     const float *x = a.dphi + row * g.Mcap;
     const uint8_t *rs = a.rssi + row * g.Mcap;
+    /* cooperative view: lane ln fetches piece ln%8 of row (8 i + ln/8), i = 0..7 (soft symbols) and
+     * half ln%2 of row (32 i + ln/2), i = 0..1 (RSSI bytes); rows of the wave are consecutive */
+    const uint64_t row0 = row - ln;
+    const float *xc = a.dphi + (row0 + (ln >> 3)) * g.Mcap + 4u * (ln & 7u);
+    const uint8_t *rc = a.rssi + (row0 + (ln >> 1)) * g.Mcap + 16u * (ln & 1u);
+    const uint64_t xc_step = 8ull * g.Mcap, rc_step = 32ull * g.Mcap;
     const uint32_t syncw = ch ? WM_SYNC_S1 : WM_SYNC_T1C1, syncm = ch ? WM_SYNC_S1_MASK : WM_SYNC_T1C1_MASK;
     uint32_t *out = a.chips + sidx * cap_t2;
     uint32_t *bw = a.bits + row * (g.Mcap / 32);
-    uint32_t *my_rssi = s_rssi + threadIdx.x * WM_RSSI_ROW;
+    uint32_t *my_rssi = s_rssi + ln * WM_CLK_RROW;
     uint32_t n_out = 0;
 
-    /* chips of one 32-sample block: walk the set bits of the sample mask */
+    /* chips of one 32-sample block: walk the set bits of the sample mask (ragged tail, shift
+     * register upkeep during warm-up) */
     auto emit_block = [&](uint32_t m0, uint32_t smask, uint32_t bitw, bool emit) {
         while (smask) {
             const uint32_t k = (uint32_t)__ffs((int)smask) - 1u;
@@ -705,44 +827,101 @@ __global__ __launch_bounds__(64) void k2_clock(K2Args a)
         }
     };
 
-    /* Full 32-sample blocks; the next block's soft symbols and RSSI bytes are fetched while the
-     * current one is processed (each lane walks its own row: nothing else hides HBM latency). */
     const uint32_t me_full = mb + ((me - mb) & ~31u);
-    float4 cur[8], nxt[8];
-    uint4 r0, r1, nr0 = {}, nr1 = {};
+    /* Two blocks of loads are kept in flight per lane (register sets A and B, used alternately):
+     * with one, the kernel ran at the latency of a single 10 KB request per wave (2.8 TB/s). */
+    float4 gxA[8], gxB[8];
+    uint4 grA[2] = {}, grB[2] = {};
+    auto fetch_x = [&](float4 (&gx)[8], uint32_t mm) {
+        if (coop) {
 #pragma unroll
-    for (int k = 0; k < 8; k++) cur[k] = *(const float4 *)(x + m + 4 * k);
-    r0 = *(const uint4 *)(rs + m); r1 = *(const uint4 *)(rs + m + 16);
-    for (; m < me_full; m += 32) {
-        if (m + 32 < me_full) {
+            for (int i = 0; i < 8; i++) gx[i] = *(const float4 *)(xc + i * xc_step + mm);
+        } else {
 #pragma unroll
-            for (int k = 0; k < 8; k++) nxt[k] = *(const float4 *)(x + m + 32 + 4 * k);
-            nr0 = *(const uint4 *)(rs + m + 32); nr1 = *(const uint4 *)(rs + m + 48);
+            for (int i = 0; i < 8; i++) gx[i] = *(const float4 *)(x + mm + 4 * i);
         }
-        const bool emit = m >= mb;
-        if (m == mb) stS[sidx] = s;                      /* state the main loop starts from */
-        if (emit) {
-            my_rssi[0] = r0.x; my_rssi[1] = r0.y; my_rssi[2] = r0.z; my_rssi[3] = r0.w;
-            my_rssi[4] = r1.x; my_rssi[5] = r1.y; my_rssi[6] = r1.z; my_rssi[7] = r1.w;
-        }
-        uint32_t bitw = 0, smask = 0, hist = s.clk;
+    };
+    auto fetch_r = [&](uint4 (&gr)[2], uint32_t mm) {
+        if (coop) { gr[0] = *(const uint4 *)(rc + mm); gr[1] = *(const uint4 *)(rc + rc_step + mm); }
+        else { gr[0] = *(const uint4 *)(rs + mm); gr[1] = *(const uint4 *)(rs + mm + 16); }
+    };
+    /* registers -> LDS rows (coop: the pieces I fetched for other lanes' rows; else my own row) */
+    const uint32_t xw = coop ? (ln >> 3) * WM_CLK_XROW + 4u * (ln & 7u) : ln * WM_CLK_XROW;
+    const uint32_t xw_step = coop ? 8u * WM_CLK_XROW : 4u;
+    const uint32_t rw = coop ? (ln >> 1) * WM_CLK_RROW + 4u * (ln & 1u) : ln * WM_CLK_RROW;
+    const uint32_t rw_step = coop ? 32u * WM_CLK_RROW : 4u;
+    const float *xrow = s_x + ln * WM_CLK_XROW;
+    auto put_x = [&](const float4 (&gx)[8]) {
+        __builtin_amdgcn_wave_barrier();                     /* the previous block's reads are done */
 #pragma unroll
-        for (int k = 0; k < 32; k++) {
-            const float xin = k & 2 ? (k & 1 ? cur[k >> 2].w : cur[k >> 2].z) : (k & 1 ? cur[k >> 2].y : cur[k >> 2].x);
-            float soft;
-            const uint32_t high = clk_step(s, c, DC, xin, soft);
-            hist = ((hist << 1) | high) & 0xFu;
-            bitw |= (uint32_t)(soft >= 0.0f) << k;                   /* slicer, rtl_wmbus.c:1059 */
-            smask |= (uint32_t)(hist == 7u) << k;
-        }
-        s.clk = hist & 7u;
-        if (emit) bw[m >> 5] = bitw;
-        emit_block(m, smask, bitw, emit);
+        for (int i = 0; i < 8; i++) *(float4 *)(s_x + xw + i * xw_step) = gx[i];
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto put_r = [&](const uint4 (&gr)[2]) {
+        *(uint4 *)(s_rssi + rw) = gr[0];
+        *(uint4 *)(s_rssi + rw + rw_step) = gr[1];
+        __builtin_amdgcn_wave_barrier();
+    };
+    const uint32_t m_last = me_full >= 32u ? me_full - 32u : 0u;      /* clamp for prefetches past the end */
+
+    /* ---- phase 1: warm-up blocks [m, mb): soft symbols only; no store is issued in this loop, so
+     * waiting for a block in flight never waits for anything else (gfx950's vmcnt counts loads
+     * and stores in one in-order queue) --------------------------------------------------------- */
+    auto warm_block = [&](float4 (&gx)[8]) {
+        put_x(gx);
+        fetch_x(gx, min(m + 64u, m_last));
+        uint32_t bitw, smask;
+        clk_block32<DC>(s, c, xrow, bitw, smask);
+        emit_block(m, smask, bitw, false);
+        m += 32;
+    };
+    if (m < me_full) { fetch_x(gxA, m); fetch_x(gxB, min(m + 32u, m_last)); }
+    while (m < mb) {
+        warm_block(gxA);
+        if (m < mb) warm_block(gxB);
+        else {                                               /* keep "A = next block" for phase 2 */
 #pragma unroll
-        for (int k = 0; k < 8; k++) cur[k] = nxt[k];
-        r0 = nr0; r1 = nr1;
+            for (int i = 0; i < 8; i++) { const float4 t = gxA[i]; gxA[i] = gxB[i]; gxB[i] = t; }
+        }
     }
-    if (m == mb) stS[sidx] = s;                          /* segment shorter than one block */
+    stS[sidx] = s;                                       /* state the main loop starts from */
+    /* ---- phase 2: blocks of the segment proper.  Exactly three stores per block (slicer word and
+     * two 16-byte chip stores; a block holds at most 8 chips because the lock pattern L,H,H,H needs 4
+     * samples, and slots beyond the block's chips are overwritten by the next block), so the
+     * compiler can wait for a prefetched block with a counted vmcnt instead of draining the stores. */
+    auto main_block = [&](float4 (&gx)[8], uint4 (&gr)[2]) {
+        put_x(gx);
+        put_r(gr);
+        fetch_x(gx, min(m + 64u, m_last));
+        fetch_r(gr, min(m + 64u, m_last));
+        uint32_t bitw, smask;
+        clk_block32<DC>(s, c, xrow, bitw, smask);
+        uint32_t cw[8], cnt = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const bool has = smask != 0u;
+            const uint32_t k = has ? (uint32_t)__ffs((int)smask) - 1u : 0u;
+            smask &= smask - 1u;
+            const uint32_t bit = (bitw >> k) & 1u;
+            const uint32_t sr_new = ((s.sr << 1) | bit) & syncm;          /* rtl_wmbus.c:818-828 */
+            s.sr = has ? sr_new : s.sr;
+            const uint32_t val = bit | (sr_new == syncw ? 2u : 0u);
+            const uint32_t rssi = ((const uint8_t *)my_rssi)[k];
+            cw[i] = ((m + k - mb) << 16) | (rssi << 8) | val;
+            if (has && (val & 2u) && t2a) record_hit(a, lane, n_out + (uint32_t)i);
+            cnt += has;
+        }
+        bw[m >> 5] = bitw;
+        *(uint4 *)(out + n_out) = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+        *(uint4 *)(out + n_out + 4) = make_uint4(cw[4], cw[5], cw[6], cw[7]);
+        n_out += t2a ? cnt : 0u;
+        m += 32;
+    };
+    if (m < me_full) { fetch_r(grA, m); fetch_r(grB, min(m + 32u, m_last)); }
+    while (m < me_full) {
+        main_block(gxA, grA);
+        if (m < me_full) main_block(gxB, grB);
+    }
     if (m < me) {                                        /* ragged tail of the last segment */
         uint32_t bitw = 0, smask = 0, hist = s.clk;
         for (uint32_t k = 0; m + k < me; k++) {
