@@ -646,8 +646,10 @@ __device__ __forceinline__ int wm_sdiv(int a, int b)
 }
 
 #define WM_RSSI_ROW 9            /* u32 words per lane in the LDS rssi staging (32 bytes + pad), run-length kernel */
+#define WM_RLA_CROW 17           /* words per lane in the run-length kernel's chip staging (16 + 1: conflict-free) */
 #define WM_CLK_XROW 36           /* words per lane in the clock kernel's soft-symbol buffer: 32 + 4 (rows stay 16-byte
                                     aligned; a lane's 8 ds_read_b128 are bank-conflict free: 9 L mod 16 is a permutation) */
+#define WM_CLK_CROW 17           /* words per lane in its chip staging (16 + 1) */
 #define WM_CLK_RROW 12           /* words per lane in its RSSI buffer: 32 bytes + 16 */
 
 /* Level of the recovered clock = (y * gain >= 0) with gain = 1.874981046e-06f (iir.h:74, rtl_wmbus.c:338,353,
@@ -768,6 +770,7 @@ __global__ __launch_bounds__(64) void k2_clock(K2Args a)
 {
     __shared__ __attribute__((aligned(16))) float s_x[64 * WM_CLK_XROW];
     __shared__ __attribute__((aligned(16))) uint32_t s_rssi[64 * WM_CLK_RROW];
+    __shared__ uint32_t s_chip[64 * WM_CLK_CROW];
     const uint32_t ln = threadIdx.x;
     uint32_t lane = blockIdx.x * 64 + ln;
     const bool rerun = a.list != nullptr;
@@ -889,6 +892,20 @@ __global__ __launch_bounds__(64) void k2_clock(K2Args a)
      * two 16-byte chip stores; a block holds at most 8 chips because the lock pattern L,H,H,H needs 4
      * samples, and slots beyond the block's chips are overwritten by the next block), so the
      * compiler can wait for a prefetched block with a counted vmcnt instead of draining the stores. */
+    /* chips leave in whole, 32-byte aligned groups of 8 (see k2_rla: partial-sector stores from
+     * 131 072 lanes with private output regions become read-modify-write traffic) */
+    uint32_t *my_chip = s_chip + ln * WM_CLK_CROW;
+    uint32_t pend = 0, n_fl = 0;
+    auto flush8 = [&]() {
+        uint32_t w[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) w[i] = my_chip[i];
+        *(uint4 *)(out + n_fl) = make_uint4(w[0], w[1], w[2], w[3]);
+        *(uint4 *)(out + n_fl + 4) = make_uint4(w[4], w[5], w[6], w[7]);
+#pragma unroll
+        for (int i = 0; i < 8; i++) { const uint32_t v = my_chip[8 + i]; if (8u + i < pend) my_chip[i] = v; }
+        n_fl += 8u; pend = pend > 8u ? pend - 8u : 0u;
+    };
     auto main_block = [&](float4 (&gx)[8], uint4 (&gr)[2]) {
         put_x(gx);
         put_r(gr);
@@ -896,7 +913,7 @@ __global__ __launch_bounds__(64) void k2_clock(K2Args a)
         fetch_r(gr, min(m + 64u, m_last));
         uint32_t bitw, smask;
         clk_block32<DC>(s, c, xrow, bitw, smask);
-        uint32_t cw[8], cnt = 0;
+        uint32_t cnt = 0;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const bool has = smask != 0u;
@@ -907,14 +924,13 @@ __global__ __launch_bounds__(64) void k2_clock(K2Args a)
             s.sr = has ? sr_new : s.sr;
             const uint32_t val = bit | (sr_new == syncw ? 2u : 0u);
             const uint32_t rssi = ((const uint8_t *)my_rssi)[k];
-            cw[i] = ((m + k - mb) << 16) | (rssi << 8) | val;
-            if (has && (val & 2u) && t2a) record_hit(a, lane, n_out + (uint32_t)i);
+            my_chip[pend + i] = ((m + k - mb) << 16) | (rssi << 8) | val;    /* slots beyond the block's chips are rewritten */
+            if (has && (val & 2u) && t2a) record_hit(a, lane, n_fl + pend + (uint32_t)i);
             cnt += has;
         }
+        pend += t2a ? cnt : 0u;
         bw[m >> 5] = bitw;
-        *(uint4 *)(out + n_out) = make_uint4(cw[0], cw[1], cw[2], cw[3]);
-        *(uint4 *)(out + n_out + 4) = make_uint4(cw[4], cw[5], cw[6], cw[7]);
-        n_out += t2a ? cnt : 0u;
+        if (pend >= 8u) flush8();
         m += 32;
     };
     if (m < me_full) { fetch_r(grA, m); fetch_r(grB, min(m + 32u, m_last)); }
@@ -922,6 +938,8 @@ __global__ __launch_bounds__(64) void k2_clock(K2Args a)
         main_block(gxA, grA);
         if (m < me_full) main_block(gxB, grB);
     }
+    n_out = n_fl + pend;
+    if (pend) flush8();                                  /* last group; slots beyond n_out are never read */
     if (m < me) {                                        /* ragged tail of the last segment */
         uint32_t bitw = 0, smask = 0, hist = s.clk;
         for (uint32_t k = 0; m + k < me; k++) {
@@ -968,6 +986,7 @@ __device__ __forceinline__ uint32_t deglitch_block(uint64_t W, bool s1)
 __global__ __launch_bounds__(64) void k2_rla(K2Args a)
 {
     __shared__ uint32_t s_rssi[64 * WM_RSSI_ROW];
+    __shared__ uint32_t s_chip[64 * WM_RLA_CROW];
     uint32_t lane = blockIdx.x * 64 + threadIdx.x;
     if (lane >= a.n_lanes) return;
     const bool rerun = a.list != nullptr;
@@ -994,17 +1013,32 @@ __global__ __launch_bounds__(64) void k2_rla(K2Args a)
     const uint8_t *rs = a.rssi + row * g.Mcap;
     uint32_t *out = a.chips + sidx * cap_rl;
     uint32_t *my_rssi = s_rssi + threadIdx.x * WM_RSSI_ROW;
-    uint32_t n_out = 0;
     const bool s1 = ch != 0;
     const uint32_t syncw = s1 ? WM_SYNC_S1 : WM_SYNC_T1C1, syncm = s1 ? WM_SYNC_S1_MASK : WM_SYNC_T1C1_MASK;
     const uint32_t hist_mask = s1 ? 0x1Cu : 0x1Fu;       /* S1 looks back 3 samples, T1/C1 5      */
 
+    /* Chips are staged in LDS (16 words per lane) and leave in whole, 32-byte aligned groups of 8:
+     * every lane appends to its own region of HBM, so with half a million lanes in flight the
+     * partially written lines do not stay in L2; 4-byte stores (or unaligned 16-byte ones) turn
+     * into read-modify-write traffic at the memory side and cost 3 of the kernel's 8.4 ms. */
+    uint32_t *my_chip = s_chip + threadIdx.x * WM_RLA_CROW;
+    uint32_t pend = 0, n_fl = 0;                             /* staged chips; chips already in HBM (multiple of 8) */
+    auto flush8 = [&]() {                                    /* the oldest 8 staged words -> HBM */
+        uint32_t w[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) w[i] = my_chip[i];
+        if (n_fl + 8u <= cap_rl) {
+            *(uint4 *)(out + n_fl) = make_uint4(w[0], w[1], w[2], w[3]);
+            *(uint4 *)(out + n_fl + 4) = make_uint4(w[4], w[5], w[6], w[7]);
+        }
+        for (uint32_t i = 8; i < pend; i++) my_chip[i - 8] = my_chip[i];
+        n_fl += 8u; pend = pend > 8u ? pend - 8u : 0u;
+    };
+
     uint32_t word = bw[m >> 5], nword = 0;
     uint4 r0 = *(const uint4 *)(rs + m), r1 = *(const uint4 *)(rs + m + 16), nr0 = {}, nr1 = {};
-    for (; m < me; m += 32) {
+    auto block = [&](const bool emit) {
         if (m + 32 < me) { nword = bw[(m >> 5) + 1]; nr0 = *(const uint4 *)(rs + m + 32); nr1 = *(const uint4 *)(rs + m + 48); }
-        const bool emit = m >= mb;
-        if (m == mb) stS[sidx] = s;
         my_rssi[0] = r0.x; my_rssi[1] = r0.y; my_rssi[2] = r0.z; my_rssi[3] = r0.w;
         my_rssi[4] = r1.x; my_rssi[5] = r1.y; my_rssi[6] = r1.z; my_rssi[7] = r1.w;
         const uint32_t kend = min(32u, me - m);
@@ -1041,9 +1075,9 @@ __global__ __launch_bounds__(64) void k2_rla(K2Args a)
                     s.sr = ((s.sr << 1) | level) & syncm;
                     if (emit) {
                         const uint32_t val = level | (s.sr == syncw ? 2u : 0u) | ((s.state & 2u) ? 4u : 0u);
-                        if (n_out < cap_rl) out[n_out] = ((m + k - mb) << 16) | (rssi << 8) | val;
-                        if (val & 2u) record_hit(a, lane, n_out);
-                        n_out++;
+                        my_chip[pend] = ((m + k - mb) << 16) | (rssi << 8) | val;
+                        if (val & 2u) record_hit(a, lane, n_fl + pend);
+                        if (++pend == 16u) flush8();         /* a long run can emit many chips at one edge */
                     }
                     s.state &= ~2u;                        /* reset marker travels with the first chip */
                     n++;
@@ -1062,8 +1096,14 @@ __global__ __launch_bounds__(64) void k2_rla(K2Args a)
         }
         s.raw = (uint32_t)(W >> kend) & hist_mask;        /* the five newest raw bits, time order */
         word = nword; r0 = nr0; r1 = nr1;
-    }
-    if (mb >= me) stS[sidx] = s;
+        if (emit && pend >= 8u) flush8();
+        m += 32;
+    };
+    while (m < mb) block(false);                         /* speculative look-back: no stores at all */
+    stS[sidx] = s;
+    while (m < me) block(true);
+    const uint32_t n_out = n_fl + pend;
+    while (pend) flush8();                               /* last group: the slots beyond n_out are never read */
     stF[sidx] = s;
     a.counts[sidx] = n_out;
     if (n_out > cap_rl) atomicOr(a.err, WM_ERR_CHIP_OVERFLOW);
