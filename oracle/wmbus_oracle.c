@@ -695,3 +695,8 @@ size_t wmo_run(const wmo_opts *opts, const uint8_t *cu8, size_t nbytes, char **t
 }
 
 void wmo_free_text(char *t) { free(t); }
+
+/* ---- array helpers for the device arithmetic self-test (tests/test_gpu_parity.py) ------------- */
+void wmo_libm_atan2f(const float *y, const float *x, float *out, size_t n) { for (size_t i = 0; i < n; i++) out[i] = atan2f(y[i], x[i]); }
+void wmo_ieee_div(const float *a, const float *b, float *out, size_t n) { for (size_t i = 0; i < n; i++) out[i] = a[i] / b[i]; }
+void wmo_ieee_sqrt(const float *a, float *out, size_t n) { for (size_t i = 0; i < n; i++) out[i] = sqrtf(a[i]); }

@@ -89,6 +89,11 @@ const char *wmo_output(const wmo_ctx *c, size_t *len);
 void        wmo_clear_output(wmo_ctx *c);
 
 /* Convenience for timing: process nbytes and return the number of output lines. */
+/* Array helpers for the device arithmetic self-test: this host's libm atan2f, IEEE divide and sqrt. */
+void wmo_libm_atan2f(const float *y, const float *x, float *out, size_t n);
+void wmo_ieee_div(const float *a, const float *b, float *out, size_t n);
+void wmo_ieee_sqrt(const float *a, float *out, size_t n);
+
 size_t wmo_run(const wmo_opts *opts, const uint8_t *cu8, size_t nbytes, char **text_out);
 void   wmo_free_text(char *text);
 

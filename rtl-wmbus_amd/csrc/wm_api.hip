@@ -149,8 +149,8 @@ __global__ void k_selftest(const float *a, const float *b, float *o_sqrt, float 
     __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    o_sqrt[i] = wm_sqrt(fabsf(a[i]));
-    o_div[i] = wm_div(a[i], b[i]);
+    o_sqrt[i] = wm_sqrt_dom(fabsf(a[i]));
+    o_div[i] = wm_div_dom(a[i], b[i]);
     o_atan2[i] = wm_atan2f_tab(a[i], b[i], tab);
     o_disc[i] = wm_discriminator_tab(a[i], b[i], b[(i + 1) % n], a[(i + 1) % n], tab);
 }

@@ -47,6 +47,42 @@ WM_HD float wm_div(float a, float b) { return a / b; }
 WM_HD float wm_sqrt(float a) { return sqrtf(a); }
 #endif
 
+/* Correctly rounded divide and square root for TAME operands (no subnormal, infinite or NaN
+ * operand or result, exponents far from the limits): the same Newton/FMA refinement the compiler
+ * emits for `/` and sqrtf under -fhip-fp32-correctly-rounded-divide-sqrt, without its range
+ * scaling (v_div_scale / v_div_fmas scaling, the 2^32 pre-scale of tiny sqrt arguments) and
+ * special-case fix-up (v_div_fixup, the class test), which can only act outside that domain.
+ * 11 -> 8 and ~18 -> 9 instructions.  The discriminator divides integers below 2^24 (and range
+ * reduced values in [2^-24, 2^24]); the RSSI takes the root of an integer below 2^24.  A zero
+ * DIVISOR gives NaN here instead of +-Inf: wm_atan2f_tab overrides x == 0 anyway.
+ * tests/test_gpu_parity.py checks both on the device against the host's IEEE results:
+ * the square root exhaustively on [0, 2^24), the quotient on 10^8 operand pairs of the domain. */
+#if defined(__HIP_DEVICE_COMPILE__)
+WM_HD float wm_div_dom(float a, float b)
+{
+    float y = __builtin_amdgcn_rcpf(b);                      /* 1 ulp */
+    const float e = __builtin_fmaf(-b, y, 1.0f);
+    y = __builtin_fmaf(e, y, y);
+    float q = __fmul_rn(a, y);
+    float r = __builtin_fmaf(-b, q, a);
+    q = __builtin_fmaf(r, y, q);
+    r = __builtin_fmaf(-b, q, a);
+    return __builtin_fmaf(r, y, q);
+}
+WM_HD float wm_sqrt_dom(float x)
+{
+    float s = __builtin_amdgcn_sqrtf(x);                     /* 1 ulp */
+    const float sm = wm_u2f(wm_f2u(s) - 1u), sp = wm_u2f(wm_f2u(s) + 1u);
+    const float em = __builtin_fmaf(-sm, s, x), ep = __builtin_fmaf(-sp, s, x);
+    s = em <= 0.0f ? sm : s;
+    s = ep > 0.0f ? sp : s;
+    return s;
+}
+#else
+WM_HD float wm_div_dom(float a, float b) { return a / b; }
+WM_HD float wm_sqrt_dom(float x) { return sqrtf(x); }
+#endif
+
 /* fdlibm atan2f (glibc 2.35 e_atan2f.c + s_atanf.c) for finite arguments, restated WITHOUT
  * branches: on a 64-lane wavefront the five argument-reduction ranges and the special cases
  * would otherwise all execute serially.  Every range's (numerator, denominator) pair is formed
@@ -176,14 +212,14 @@ WM_HD float wm_atan2f_tab(float y, float x, const float *tab)
 {
     const uint32_t hx = wm_f2u(x), hy = wm_f2u(y);
     const float pi = wm_u2f(0x40490fdbu), pi_o_2 = wm_u2f(0x3fc90fdbu), pi_lo = wm_u2f(0xb3bbbd2eu);
-    const float t = wm_u2f(wm_f2u(wm_div(y, x)) & 0x7fffffffu);       /* fabsf(y/x) */
+    const float t = wm_u2f(wm_f2u(wm_div_dom(y, x)) & 0x7fffffffu);       /* fabsf(y/x) */
     int j = (int)(wm_f2u(t) >> 18) - (int)(WM_ATAN_U0 - 1u);
     j = j < 0 ? 0 : (j > WM_ATAN_LUT_BYTES - 1 ? WM_ATAN_LUT_BYTES - 1 : j);
     const uint32_t idx = ((const uint8_t *)(tab + WM_ATAN_RANGES * WM_ATAN_ROW_WORDS))[j];
     const float *e = tab + WM_ATAN_ROW_WORDS * idx;
     const float num = wm_add(wm_mul(e[0], t), e[1]);
     const float den = wm_add(wm_mul(e[2], t), e[3]);
-    const float r = wm_div(num, den);
+    const float r = wm_div_dom(num, den);
 
     const float aT0 = wm_u2f(0x3eaaaaabu), aT1 = wm_u2f(0xbe4ccccdu), aT2 = wm_u2f(0x3e124925u),
                 aT3 = wm_u2f(0xbde38e38u), aT4 = wm_u2f(0x3dba2e6eu), aT5 = wm_u2f(0xbd9d8795u),

@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256) void k1_demod2(K1Args a)
                 const float i = (float)s8[j + 1].x, q = (float)s8[j + 1].y;       /* 8 x the reference's i, q */
                 drT[j] = accurate ? wm_discriminator_tab(i, q, pi_, pq_, tab)
                                   : wm_mul(wm_discriminator_fast(i, q, pi_, pq_), 0.015625f);
-                mgT[j] = wm_mul(wm_sqrt(wm_add(wm_mul(i, i), wm_mul(q, q))), 0.125f);
+                mgT[j] = wm_mul(wm_sqrt_dom(wm_add(wm_mul(i, i), wm_mul(q, q))), 0.125f);
                 pi_ = i; pq_ = q;
             }
         } else {
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256) void k1_demod2(K1Args a)
                 const float i = (float)s16[j + 1].x, q = (float)s16[j + 1].y;     /* 16 x the reference's i, q */
                 drS[j] = accurate ? wm_discriminator_tab(i, q, pi_, pq_, tab)
                                   : wm_mul(wm_discriminator_fast(i, q, pi_, pq_), 0.00390625f);
-                mgS[j] = wm_mul(wm_sqrt(wm_add(wm_mul(i, i), wm_mul(q, q))), 0.0625f);
+                mgS[j] = wm_mul(wm_sqrt_dom(wm_add(wm_mul(i, i), wm_mul(q, q))), 0.0625f);
                 pi_ = i; pq_ = q;
             }
         } else {

@@ -38,32 +38,70 @@ def compare_chips(rx, ref, stream=0, chains=(0, 1), algos=(0, 1)):
             assert np.array_equal(pos, oc["sample"])
 
 
-def test_device_arithmetic_is_ieee_and_glibc_exact(wm):
-    """sqrt / divide correctly rounded, atan2f == this image's glibc, on the operand domains of the
-    RSSI (|s|^2 = k/64, k/256) and of the discriminator (products of k/8, k/16 boxcar outputs)."""
-    rng = np.random.default_rng(11)
-    k = np.arange(0, 2 * 1016 * 1016 + 1, dtype=np.int64)
-    a = np.concatenate([k / 64.0, rng.integers(0, 2 * 2880 * 2880, 1 << 21) / 256.0]).astype(np.float32)
-    i = rng.integers(-1016, 1017, a.size) / 8.0
-    q = rng.integers(-1016, 1017, a.size) / 8.0
-    small = rng.random(a.size) < 0.3
-    i[small] = rng.integers(-12, 13, small.sum()) / 8.0
-    q[small] = rng.integers(-12, 13, small.sum()) / 8.0
-    i = i.astype(np.float32); q = q.astype(np.float32)
-    r = wm.selftest_math(a, np.where(q == 0, np.float32(1), q))
-    assert np.array_equal(r["sqrt"].view(np.uint32), np.sqrt(a).view(np.uint32))
-    assert np.array_equal(r["div"].view(np.uint32), (a / np.where(q == 0, np.float32(1), q)).astype(np.float32).view(np.uint32))
-    r = wm.selftest_math(i, q)
-    # host reference = the reference's own expression with the host libm (atan2.h:7-10)
+def test_device_arithmetic_is_ieee_and_glibc_exact(wm, oracle):
+    """The kernels' scalar arithmetic (wm_exact.h) on the device against this host's IEEE / glibc:
+      * square root: EXHAUSTIVE over the RSSI operand domain, every integer in [0, 2^24) (the
+        kernels take the root of the unscaled integer sums i^2 + q^2) plus the k/64, k/256 forms;
+      * divide: 5*10^7 operand pairs of the discriminator's domain (integers below 2^24 and the
+        range-reduced quotients of the arctangent);
+      * atan2f and the whole discriminator: 3*10^7 pairs, every one compared with libm's atan2f
+        (the reference's atan2.h:7-10 expression)."""
+    L = oracle.lib()
     import ctypes
-    libm = ctypes.CDLL("libm.so.6"); libm.atan2f.restype = ctypes.c_float; libm.atan2f.argtypes = [ctypes.c_float] * 2
-    idx = rng.integers(0, i.size, 200000)
-    want = np.array([libm.atan2f(float(i[j]), float(q[j])) for j in idx], np.float32)
-    assert np.array_equal(r["atan2"][idx].view(np.uint32), want.view(np.uint32))
-    ip, qp = np.roll(q, -1), np.roll(i, -1)                    # previous sample (i', q') per the ABI comment
-    re = (i * ip - q * (-qp)).astype(np.float32); im = (i * (-qp) + q * ip).astype(np.float32)
-    want = np.array([np.float32(libm.atan2f(float(im[j]), float(re[j]))) * np.float32(0.3183098861837907) for j in idx], np.float32)
-    assert np.array_equal(r["disc"][idx].view(np.uint32), want.view(np.uint32))
+    fp = ctypes.POINTER(ctypes.c_float)
+    for f in (L.wmo_libm_atan2f, L.wmo_ieee_div):
+        f.argtypes = [fp, fp, fp, ctypes.c_size_t]; f.restype = None
+    L.wmo_ieee_sqrt.argtypes = [fp, fp, ctypes.c_size_t]; L.wmo_ieee_sqrt.restype = None
+
+    def host2(fn, x, y):
+        out = np.empty_like(x); fn(x.ctypes.data_as(fp), y.ctypes.data_as(fp), out.ctypes.data_as(fp), x.size); return out
+
+    rng = np.random.default_rng(11)
+    # ---- sqrt, exhaustive on the integer domain, in 4 slabs of 2^22
+    for slab in range(4):
+        a = np.arange(slab << 22, (slab + 1) << 22, dtype=np.float32)
+        r = wm.selftest_math(a, np.ones_like(a))
+        want = np.empty_like(a); L.wmo_ieee_sqrt(a.ctypes.data_as(fp), want.ctypes.data_as(fp), a.size)
+        assert np.array_equal(r["sqrt"].view(np.uint32), want.view(np.uint32)), f"sqrt slab {slab}"
+    a = np.concatenate([np.arange(0, 2 * 1016 * 1016 + 1) / 64.0, rng.integers(0, 2 * 2880 * 2880, 1 << 21) / 256.0]).astype(np.float32)
+    r = wm.selftest_math(a, np.ones_like(a))
+    assert np.array_equal(r["sqrt"].view(np.uint32), np.sqrt(a).view(np.uint32))
+
+    # ---- divide / atan2 / discriminator on discriminator-shaped operands
+    n = 1 << 22
+    for rnd in range(12):
+        lim, sc = ((1016, 8.0), (2880, 16.0))[rnd & 1]
+        v = rng.integers(-lim, lim + 1, (4, n))
+        weak = rng.random((4, n)) < 0.3
+        v = np.where(weak, rng.integers(-12, 13, (4, n)), v)
+        if rnd >= 8:                                              # unscaled boxcar sums, as the kernels feed them
+            sc = 1.0
+        i, q, ip, qp = [(v[k] / sc).astype(np.float32) for k in range(4)]
+        re = (i * ip - q * (-qp)).astype(np.float32); im = (i * (-qp) + q * ip).astype(np.float32)
+        r = wm.selftest_math(im, re)
+        nz = re != 0
+        want = host2(L.wmo_ieee_div, im, np.where(nz, re, np.float32(1)))
+        assert np.array_equal(r["div"][nz].view(np.uint32), want[nz].view(np.uint32)), f"divide round {rnd}"
+        want = host2(L.wmo_libm_atan2f, im, re)
+        assert np.array_equal(r["atan2"].view(np.uint32), want.view(np.uint32)), f"atan2f round {rnd}"
+        # range-reduced operands of the second division: t in [7/16, 39/16) -> (2t-1)/(2+t), (t-1)/(t+1), (t-1.5)/(1+1.5t); -1/t
+        t = np.abs(want) .astype(np.float32) + np.float32(0.4375)
+        num = np.where(t < 0.6875, 2 * t - 1, np.where(t < 1.1875, t - 1, t - np.float32(1.5))).astype(np.float32)
+        den = np.where(t < 0.6875, 2 + t, np.where(t < 1.1875, t + 1, 1 + np.float32(1.5) * t)).astype(np.float32)
+        r2 = wm.selftest_math(num, den)
+        assert np.array_equal(r2["div"].view(np.uint32), host2(L.wmo_ieee_div, num, den).view(np.uint32)), f"reduced divide round {rnd}"
+        # whole discriminator: o_disc[j] = discriminator(i=a[j], q=b[j], i'=b[j+1], q'=a[j+1])
+        r3 = wm.selftest_math(i, q)
+        ipp, qpp = np.roll(q, -1), np.roll(i, -1)
+        re3 = (i * ipp - q * (-qpp)).astype(np.float32); im3 = (i * (-qpp) + q * ipp).astype(np.float32)
+        want3 = (host2(L.wmo_libm_atan2f, im3, re3) * np.float32(0.3183098861837907)).astype(np.float32)
+        assert np.array_equal(r3["disc"].view(np.uint32), want3.view(np.uint32)), f"discriminator round {rnd}"
+    # signed zeros and axes
+    z = np.array([0.0, -0.0, 3.5, -3.5, 0.0, -0.0, 2.25, -2.25], np.float32)
+    yy, xx = np.meshgrid(z, z)
+    yy = np.ascontiguousarray(yy.ravel()); xx = np.ascontiguousarray(xx.ravel())
+    r = wm.selftest_math(yy, xx)
+    assert np.array_equal(r["atan2"].view(np.uint32), host2(L.wmo_libm_atan2f, yy, xx).view(np.uint32))
 
 
 @pytest.mark.parametrize("name,flags", BUNDLED_CASES, ids=[f"{n[14:22]}:{' '.join(f)}" for n, f in BUNDLED_CASES])
