@@ -234,7 +234,7 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
     const uint32_t T = c->T;
     const uint64_t max_samples = cfg->max_push_bytes / 2;
     c->ntiles_cap = (uint32_t)((max_samples / c->d + 1 + 8 + T - 1) / T);
-    c->Mcap = (c->ntiles_cap * T + 127) / 128 * 128;     /* whole tiles (partial tiles still store full runs), rows 512-byte aligned */
+    c->Mcap = (c->ntiles_cap * T + 255) / 256 * 256;     /* whole tiles (partial tiles still store full runs); slicer-word rows 32-byte aligned */
     for (int a = 0; a < 2; a++) c->nseg_cap[a] = (c->Mcap + c->C[a] - 1) / c->C[a];
     c->cap[1] = c->C[1] / 4 + 8;   /* time2: the lock logic needs >= 4 samples per chip */
     c->cap[0] = c->C[0] + 8;       /* run-length: bit length tracking may shrink the chip period towards one sample */
@@ -438,7 +438,7 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
                     c->h_pending[(al * 2 + ch) * c->S + s] = c->decs[((size_t)s * 2 + ch) * 2 + al].owed;
         HIPCHK(c, hipMemcpyAsync(c->d_pending, c->h_pending, 4 * c->S * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         K3Args k3{};
-        k3.g = g;
+        k3.g = g; k3.rssi = c->d_rssi;
         k3.chips[0] = c->d_chips[0]; k3.chips[1] = c->d_chips[1]; k3.counts[0] = c->d_counts[0]; k3.counts[1] = c->d_counts[1];
         k3.hits = c->d_hits; k3.n_hits = c->d_scalars + SC_NHITS; k3.hits_cap = c->hits_cap; k3.pending = c->d_pending;
         k3.hdr = c->d_hdr; k3.hdr_cap = c->hdr_cap; k3.words = c->d_words; k3.words_cap = c->words_cap;
@@ -634,7 +634,7 @@ long wmbus_read_chips(wmbus_ctx *c, int chain, int algo, unsigned stream, uint32
     if (hipMalloc((void **)&d_dst, max_elems * 4) != hipSuccess || hipMalloc((void **)&d_pos, max_elems * 8) != hipSuccess ||
         hipMalloc((void **)&d_n, 4) != hipSuccess) return WMBUS_ENOMEM;
     hipLaunchKernelGGL(k4_flatten, dim3(1), dim3(1), 0, c->stream, c->last, (uint32_t)algo, c->d_chips[algo], c->d_counts[algo],
-                       c->cap[algo], (uint32_t)chain, stream, d_dst, d_pos, (uint32_t)max_elems, d_n);
+                       c->d_rssi, c->cap[algo], (uint32_t)chain, stream, d_dst, d_pos, (uint32_t)max_elems, d_n);
     uint32_t n = 0;
     hipStreamSynchronize(c->stream);
     hipMemcpy(&n, d_n, 4, hipMemcpyDeviceToHost);

@@ -645,12 +645,11 @@ __device__ __forceinline__ int wm_sdiv(int a, int b)
     return a < 0 ? -(int)q : (int)q;
 }
 
-#define WM_RSSI_ROW 9            /* u32 words per lane in the LDS rssi staging (32 bytes + pad), run-length kernel */
 #define WM_RLA_CROW 17           /* words per lane in the run-length kernel's chip staging (16 + 1: conflict-free) */
 #define WM_CLK_XROW 36           /* words per lane in the clock kernel's soft-symbol buffer: 32 + 4 (rows stay 16-byte
                                     aligned; a lane's 8 ds_read_b128 are bank-conflict free: 9 L mod 16 is a permutation) */
 #define WM_CLK_CROW 17           /* words per lane in its chip staging (16 + 1) */
-#define WM_CLK_RROW 12           /* words per lane in its RSSI buffer: 32 bytes + 16 */
+#define WM_CLK_BROW 9            /* words per lane in its slicer-word staging (8 + 1) */
 
 /* Level of the recovered clock = (y * gain >= 0) with gain = 1.874981046e-06f (iir.h:74, rtl_wmbus.c:338,353,
  * 1089).  The product is only ever compared with zero, and it is >= 0 exactly when y is not below
@@ -769,8 +768,8 @@ template <bool DC>
 __global__ __launch_bounds__(64) void k2_clock(K2Args a)
 {
     __shared__ __attribute__((aligned(16))) float s_x[64 * WM_CLK_XROW];
-    __shared__ __attribute__((aligned(16))) uint32_t s_rssi[64 * WM_CLK_RROW];
     __shared__ uint32_t s_chip[64 * WM_CLK_CROW];
+    __shared__ uint32_t s_bits[64 * WM_CLK_BROW];
     const uint32_t ln = threadIdx.x;
     uint32_t lane = blockIdx.x * 64 + ln;
     const bool rerun = a.list != nullptr;
@@ -799,17 +798,14 @@ __global__ __launch_bounds__(64) void k2_clock(K2Args a)
     const IirCoef c = iir_coef(ch);
     const bool t2a = g.flags & WM_F_T2A;
     const float *x = a.dphi + row * g.Mcap;
-    const uint8_t *rs = a.rssi + row * g.Mcap;
-    /* cooperative view: lane ln fetches piece ln%8 of row (8 i + ln/8), i = 0..7 (soft symbols) and
-     * half ln%2 of row (32 i + ln/2), i = 0..1 (RSSI bytes); rows of the wave are consecutive */
+    /* cooperative view: lane ln fetches piece ln%8 of row (8 i + ln/8), i = 0..7; rows of the wave
+     * are consecutive */
     const uint64_t row0 = row - ln;
     const float *xc = a.dphi + (row0 + (ln >> 3)) * g.Mcap + 4u * (ln & 7u);
-    const uint8_t *rc = a.rssi + (row0 + (ln >> 1)) * g.Mcap + 16u * (ln & 1u);
-    const uint64_t xc_step = 8ull * g.Mcap, rc_step = 32ull * g.Mcap;
+    const uint64_t xc_step = 8ull * g.Mcap;
     const uint32_t syncw = ch ? WM_SYNC_S1 : WM_SYNC_T1C1, syncm = ch ? WM_SYNC_S1_MASK : WM_SYNC_T1C1_MASK;
     uint32_t *out = a.chips + sidx * cap_t2;
     uint32_t *bw = a.bits + row * (g.Mcap / 32);
-    uint32_t *my_rssi = s_rssi + ln * WM_CLK_RROW;
     uint32_t n_out = 0;
 
     /* chips of one 32-sample block: walk the set bits of the sample mask (ragged tail, shift
@@ -822,8 +818,7 @@ __global__ __launch_bounds__(64) void k2_clock(K2Args a)
             s.sr = ((s.sr << 1) | bit) & syncm;                       /* rtl_wmbus.c:818-828 */
             if (emit && t2a) {
                 const uint32_t val = bit | (s.sr == syncw ? 2u : 0u);
-                const uint32_t rssi = ((const uint8_t *)my_rssi)[k];
-                if (n_out < cap_t2) out[n_out] = ((m0 + k - mb) << 16) | (rssi << 8) | val;
+                if (n_out < cap_t2) out[n_out] = ((m0 + k - mb) << 16) | val;
                 if (val & 2u) record_hit(a, lane, n_out);
                 n_out++;
             }
@@ -834,7 +829,6 @@ __global__ __launch_bounds__(64) void k2_clock(K2Args a)
     /* Two blocks of loads are kept in flight per lane (register sets A and B, used alternately):
      * with one, the kernel ran at the latency of a single 10 KB request per wave (2.8 TB/s). */
     float4 gxA[8], gxB[8];
-    uint4 grA[2] = {}, grB[2] = {};
     auto fetch_x = [&](float4 (&gx)[8], uint32_t mm) {
         if (coop) {
 #pragma unroll
@@ -844,25 +838,14 @@ __global__ __launch_bounds__(64) void k2_clock(K2Args a)
             for (int i = 0; i < 8; i++) gx[i] = *(const float4 *)(x + mm + 4 * i);
         }
     };
-    auto fetch_r = [&](uint4 (&gr)[2], uint32_t mm) {
-        if (coop) { gr[0] = *(const uint4 *)(rc + mm); gr[1] = *(const uint4 *)(rc + rc_step + mm); }
-        else { gr[0] = *(const uint4 *)(rs + mm); gr[1] = *(const uint4 *)(rs + mm + 16); }
-    };
     /* registers -> LDS rows (coop: the pieces I fetched for other lanes' rows; else my own row) */
     const uint32_t xw = coop ? (ln >> 3) * WM_CLK_XROW + 4u * (ln & 7u) : ln * WM_CLK_XROW;
     const uint32_t xw_step = coop ? 8u * WM_CLK_XROW : 4u;
-    const uint32_t rw = coop ? (ln >> 1) * WM_CLK_RROW + 4u * (ln & 1u) : ln * WM_CLK_RROW;
-    const uint32_t rw_step = coop ? 32u * WM_CLK_RROW : 4u;
     const float *xrow = s_x + ln * WM_CLK_XROW;
     auto put_x = [&](const float4 (&gx)[8]) {
         __builtin_amdgcn_wave_barrier();                     /* the previous block's reads are done */
 #pragma unroll
         for (int i = 0; i < 8; i++) *(float4 *)(s_x + xw + i * xw_step) = gx[i];
-        __builtin_amdgcn_wave_barrier();
-    };
-    auto put_r = [&](const uint4 (&gr)[2]) {
-        *(uint4 *)(s_rssi + rw) = gr[0];
-        *(uint4 *)(s_rssi + rw + rw_step) = gr[1];
         __builtin_amdgcn_wave_barrier();
     };
     const uint32_t m_last = me_full >= 32u ? me_full - 32u : 0u;      /* clamp for prefetches past the end */
@@ -906,11 +889,11 @@ __global__ __launch_bounds__(64) void k2_clock(K2Args a)
         for (int i = 0; i < 8; i++) { const uint32_t v = my_chip[8 + i]; if (8u + i < pend) my_chip[i] = v; }
         n_fl += 8u; pend = pend > 8u ? pend - 8u : 0u;
     };
-    auto main_block = [&](float4 (&gx)[8], uint4 (&gr)[2]) {
+    /* slicer words leave in aligned groups of 8 as well (one word per 32 samples and lane) */
+    uint32_t *my_bits = s_bits + ln * WM_CLK_BROW;
+    auto main_block = [&](float4 (&gx)[8]) {
         put_x(gx);
-        put_r(gr);
         fetch_x(gx, min(m + 64u, m_last));
-        fetch_r(gr, min(m + 64u, m_last));
         uint32_t bitw, smask;
         clk_block32<DC>(s, c, xrow, bitw, smask);
         uint32_t cnt = 0;
@@ -923,21 +906,28 @@ __global__ __launch_bounds__(64) void k2_clock(K2Args a)
             const uint32_t sr_new = ((s.sr << 1) | bit) & syncm;          /* rtl_wmbus.c:818-828 */
             s.sr = has ? sr_new : s.sr;
             const uint32_t val = bit | (sr_new == syncw ? 2u : 0u);
-            const uint32_t rssi = ((const uint8_t *)my_rssi)[k];
-            my_chip[pend + i] = ((m + k - mb) << 16) | (rssi << 8) | val;    /* slots beyond the block's chips are rewritten */
+            my_chip[pend + i] = ((m + k - mb) << 16) | val;                 /* slots beyond the block's chips are rewritten */
             if (has && (val & 2u) && t2a) record_hit(a, lane, n_fl + pend + (uint32_t)i);
             cnt += has;
         }
         pend += t2a ? cnt : 0u;
-        bw[m >> 5] = bitw;
+        const uint32_t bi = m >> 5;
+        my_bits[bi & 7u] = bitw;
+        if ((bi & 7u) == 7u) {
+            uint32_t w[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) w[i] = my_bits[i];
+            *(uint4 *)(bw + (bi - 7u)) = make_uint4(w[0], w[1], w[2], w[3]);
+            *(uint4 *)(bw + (bi - 3u)) = make_uint4(w[4], w[5], w[6], w[7]);
+        }
         if (pend >= 8u) flush8();
         m += 32;
     };
-    if (m < me_full) { fetch_r(grA, m); fetch_r(grB, min(m + 32u, m_last)); }
     while (m < me_full) {
-        main_block(gxA, grA);
-        if (m < me_full) main_block(gxB, grB);
+        main_block(gxA);
+        if (m < me_full) main_block(gxB);
     }
+    for (uint32_t bi = (m >> 5) & ~7u; bi < (m >> 5); bi++) bw[bi] = my_bits[bi & 7u];   /* incomplete last group */
     n_out = n_fl + pend;
     if (pend) flush8();                                  /* last group; slots beyond n_out are never read */
     if (m < me) {                                        /* ragged tail of the last segment */
@@ -948,7 +938,6 @@ __global__ __launch_bounds__(64) void k2_clock(K2Args a)
             hist = ((hist << 1) | high) & 0xFu;
             bitw |= (uint32_t)(soft >= 0.0f) << k;
             smask |= (uint32_t)(hist == 7u) << k;
-            ((uint8_t *)my_rssi)[k] = rs[m + k];
         }
         s.clk = hist & 7u;
         bw[m >> 5] = bitw;
@@ -985,7 +974,6 @@ __device__ __forceinline__ uint32_t deglitch_block(uint64_t W, bool s1)
  * from the masked history.  WmRlaState.raw keeps the last five raw bits in time order. */
 __global__ __launch_bounds__(64) void k2_rla(K2Args a)
 {
-    __shared__ uint32_t s_rssi[64 * WM_RSSI_ROW];
     __shared__ uint32_t s_chip[64 * WM_RLA_CROW];
     uint32_t lane = blockIdx.x * 64 + threadIdx.x;
     if (lane >= a.n_lanes) return;
@@ -1010,9 +998,7 @@ __global__ __launch_bounds__(64) void k2_rla(K2Args a)
     else { s = reset; m = mb - g.lookback; }
 
     const uint32_t *bw = a.bits + row * (g.Mcap / 32);
-    const uint8_t *rs = a.rssi + row * g.Mcap;
     uint32_t *out = a.chips + sidx * cap_rl;
-    uint32_t *my_rssi = s_rssi + threadIdx.x * WM_RSSI_ROW;
     const bool s1 = ch != 0;
     const uint32_t syncw = s1 ? WM_SYNC_S1 : WM_SYNC_T1C1, syncm = s1 ? WM_SYNC_S1_MASK : WM_SYNC_T1C1_MASK;
     const uint32_t hist_mask = s1 ? 0x1Cu : 0x1Fu;       /* S1 looks back 3 samples, T1/C1 5      */
@@ -1035,12 +1021,20 @@ __global__ __launch_bounds__(64) void k2_rla(K2Args a)
         n_fl += 8u; pend = pend > 8u ? pend - 8u : 0u;
     };
 
-    uint32_t word = bw[m >> 5], nword = 0;
-    uint4 r0 = *(const uint4 *)(rs + m), r1 = *(const uint4 *)(rs + m + 16), nr0 = {}, nr1 = {};
+    /* slicer words arrive 8 at a time (one aligned 32-byte sector per lane and 256 samples; single
+     * words cost a sector of HBM traffic each); the next group is in flight while this one is used */
+    uint32_t grp = m >> 8;                                   /* group (256 samples) the lane is in */
+    uint4 wq0 = *(const uint4 *)(bw + 8u * grp), wq1 = *(const uint4 *)(bw + 8u * grp + 4), nq0 = {}, nq1 = {};
+    auto fetch_group = [&](uint32_t gq) {                    /* rows hold whole groups (Mcap is a multiple of 256) */
+        if (gq * 256u < g.Mcap) { nq0 = *(const uint4 *)(bw + 8u * gq); nq1 = *(const uint4 *)(bw + 8u * gq + 4); }
+    };
+    fetch_group(grp + 1u);
     auto block = [&](const bool emit) {
-        if (m + 32 < me) { nword = bw[(m >> 5) + 1]; nr0 = *(const uint4 *)(rs + m + 32); nr1 = *(const uint4 *)(rs + m + 48); }
-        my_rssi[0] = r0.x; my_rssi[1] = r0.y; my_rssi[2] = r0.z; my_rssi[3] = r0.w;
-        my_rssi[4] = r1.x; my_rssi[5] = r1.y; my_rssi[6] = r1.z; my_rssi[7] = r1.w;
+        const uint32_t sub = (m >> 5) & 7u;
+        const uint32_t wsel[8] = {wq0.x, wq0.y, wq0.z, wq0.w, wq1.x, wq1.y, wq1.z, wq1.w};
+        uint32_t word = wsel[0];
+#pragma unroll
+        for (int i = 1; i < 8; i++) word = sub == (uint32_t)i ? wsel[i] : word;
         const uint32_t kend = min(32u, me - m);
         const uint32_t valid = kend == 32u ? 0xFFFFFFFFu : ((1u << kend) - 1u);
         uint64_t W = ((uint64_t)(word & valid) << 5) | (s.raw & hist_mask);
@@ -1068,14 +1062,13 @@ __global__ __launch_bounds__(64) void k2_rla(K2Args a)
                 W &= ~((2ull << (5u + k)) - 1ull);       /* raw history cleared, incl. sample k */
                 D = deglitch_block(W, s1);
             } else {
-                const uint32_t rssi = ((const uint8_t *)my_rssi)[k];
                 int n = 0;
                 while (s.run > half) {                                                       /* :765-779 / :680-694 */
                     s.run -= unit;
                     s.sr = ((s.sr << 1) | level) & syncm;
                     if (emit) {
                         const uint32_t val = level | (s.sr == syncw ? 2u : 0u) | ((s.state & 2u) ? 4u : 0u);
-                        my_chip[pend] = ((m + k - mb) << 16) | (rssi << 8) | val;
+                        my_chip[pend] = ((m + k - mb) << 16) | val;
                         if (val & 2u) record_hit(a, lane, n_fl + pend);
                         if (++pend == 16u) flush8();         /* a long run can emit many chips at one edge */
                     }
@@ -1095,7 +1088,7 @@ __global__ __launch_bounds__(64) void k2_rla(K2Args a)
             k0 = k + 1u;
         }
         s.raw = (uint32_t)(W >> kend) & hist_mask;        /* the five newest raw bits, time order */
-        word = nword; r0 = nr0; r1 = nr1;
+        if (sub == 7u) { wq0 = nq0; wq1 = nq1; grp++; fetch_group(grp + 1u); }
         if (emit && pend >= 8u) flush8();
         m += 32;
     };
@@ -1130,6 +1123,7 @@ __global__ void k2_verify(WmPush g, uint32_t algo, const uint32_t *st_start, con
  * ===========================================================================================*/
 struct K3Args {
     WmPush g;
+    const uint8_t *rssi;         /* [2][S][Mcap]: the framers no longer copy the RSSI byte into every chip */
     const uint32_t *chips[2];    /* per algo: [2][S][nseg_cap][cap]                          */
     const uint32_t *counts[2];   /* per algo: [2][S][nseg_cap]                               */
     const uint2 *hits; const uint32_t *n_hits; uint32_t hits_cap;
@@ -1230,8 +1224,10 @@ __global__ __launch_bounds__(64) void k3_bursts(K3Args a)
     for (uint32_t j = ln; j < n; j += 64u) {
         uint32_t sg, kk; locate(j, sg, kk);
         const uint32_t w = base[(uint64_t)sg * cap + kk];
-        const uint64_t pos = g.m0 + (uint64_t)sg * seg_len + WM_CHIP_POS(w);
-        a.words[woff + j] = ((uint32_t)(pos - pos0) << 11) | (WM_CHIP_RSSI(w) << 3) | (WM_CHIP_VAL(w) & 7u);
+        const uint32_t pm = sg * seg_len + WM_CHIP_POS(w);               /* push-relative decimated sample */
+        const uint64_t pos = g.m0 + pm;
+        const uint32_t rssi = a.rssi[row * g.Mcap + pm];                 /* (unsigned)EMA at the chip's sample */
+        a.words[woff + j] = ((uint32_t)(pos - pos0) << 11) | (rssi << 3) | (WM_CHIP_VAL(w) & 7u);
     }
     if (ln == 0) {
         WmBurstHdr h;
@@ -1242,7 +1238,7 @@ __global__ __launch_bounds__(64) void k3_bursts(K3Args a)
 }
 
 /* Debug/parity helper: flatten one (chain, algo, stream) chip stream. */
-__global__ void k4_flatten(WmPush g, uint32_t algo, const uint32_t *chips, const uint32_t *counts, uint32_t cap,
+__global__ void k4_flatten(WmPush g, uint32_t algo, const uint32_t *chips, const uint32_t *counts, const uint8_t *rssi, uint32_t cap,
                            uint32_t ch, uint32_t stream, uint32_t *dst, uint64_t *pos, uint32_t max_out, uint32_t *n_out)
 {
     if (blockIdx.x || threadIdx.x) return;
@@ -1253,7 +1249,7 @@ __global__ void k4_flatten(WmPush g, uint32_t algo, const uint32_t *chips, const
         for (uint32_t k = 0; k < c; k++, n++)
             if (n < max_out) {
                 const uint32_t w = chips[(row * g.nseg_cap[algo] + s) * (uint64_t)cap + k];
-                dst[n] = w;
+                dst[n] = w | ((uint32_t)rssi[row * g.Mcap + s * g.seg_len[algo] + WM_CHIP_POS(w)] << 8);
                 if (pos) pos[n] = g.m0 + (uint64_t)s * g.seg_len[algo] + WM_CHIP_POS(w);
             }
     }
