@@ -379,7 +379,6 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
     g.Mcap = c->Mcap; g.d = c->d; g.S = c->S; g.lut_n = 32 * c->d;
     g.lut_phase0 = (uint32_t)((13ull * (c->n0 % g.lut_n)) % g.lut_n);
     g.flags = c->flags;
-    if (const char *e = getenv("WMBUS_K1_DEBUG")) g.flags |= (uint32_t)atoi(e) << 8;   /* timing experiments: skip K1 stages */
     for (int al = 0; al < 2; al++) {
         g.seg_len[al] = c->C[al]; g.nseg[al] = (g.M + c->C[al] - 1) / c->C[al]; g.nseg_cap[al] = c->nseg_cap[al]; g.cap[al] = c->cap[al];
     }

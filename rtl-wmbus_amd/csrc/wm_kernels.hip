@@ -345,7 +345,6 @@ __global__ __launch_bounds__(256) void k1_demod2(K1Args a)
     const int tn = min(T, (int)g.M - ts);
     const bool chT = g.flags & WM_F_T1C1, chS = g.flags & WM_F_S1;
     const bool accurate = g.flags & WM_F_ACCURATE;
-    const bool dbgA = g.flags & 256u, dbgF = g.flags & 512u, dbgE = g.flags & 1024u, dbg0 = g.flags & 2048u;   /* timing experiments */
 
     if (tid < WM_ATAN_TAB_WORDS) wm_atan_tab_word(tid, tab);   /* 5 range rows + range LUT */
 
@@ -369,7 +368,7 @@ __global__ __launch_bounds__(256) void k1_demod2(K1Args a)
 #pragma unroll
         for (int it = 0; it < NP; it++) {
             const int u = tid + 256 * it;
-            if (u < NDW && !dbg0) {
+            if (u < NDW) {
                 const int p = 2 * u - off;
                 if (!SHIFT) {
                     /* bytes (i,q) -> halfwords, then u - 127 - (u >> 7) per halfword
@@ -412,10 +411,6 @@ __global__ __launch_bounds__(256) void k1_demod2(K1Args a)
         k1_boxcars<D>(stgT + 4 * c * D, s8, SHIFT ? u16 : s16);
         if (SHIFT) k1_boxcars<D>(stgS + 4 * c * D, u8, s16);
         float drT[4], drS[4];
-        if (dbgA) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) { drT[j] = (float)s8[j + 1].x; drS[j] = (float)s16[j + 1].y; mgT[j] = (float)s8[j].y; mgS[j] = (float)s16[j].x; }
-        } else {
         if (chT) {
             float pi_ = (float)s8[0].x, pq_ = (float)s8[0].y;
 #pragma unroll
@@ -444,7 +439,6 @@ __global__ __launch_bounds__(256) void k1_demod2(K1Args a)
 #pragma unroll
             for (int j = 0; j < 4; j++) drS[j] = mgS[j] = 0.0f;
         }
-        }
         /* element a of a discriminator row lives at word a + 4 */
         *(float4 *)(yDrT + 4 * c + 4) = make_float4(drT[0], drT[1], drT[2], drT[3]);
         *(float4 *)(yDrS + 4 * c + 4) = make_float4(drS[0], drS[1], drS[2], drS[3]);
@@ -460,7 +454,7 @@ __global__ __launch_bounds__(256) void k1_demod2(K1Args a)
     {
         const int m0l = 4 * tid;
         const uint64_t row = (uint64_t)stream * g.Mcap + (uint64_t)ts + m0l;
-        if (chT && m0l < tn && !dbgF) {
+        if (chT && m0l < tn) {
             float w[16];                                      /* w[i] = element 4 tid + 36 + i */
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -477,7 +471,7 @@ __global__ __launch_bounds__(256) void k1_demod2(K1Args a)
             }
             *(float4 *)(a.dphi + row) = make_float4(acc[0], acc[1], acc[2], acc[3]);
         }
-        if (chS && m0l < tn && !dbgF) {
+        if (chS && m0l < tn) {
             float w[52];                                      /* w[i] = element 4 tid + i */
 #pragma unroll
             for (int k = 0; k < 13; k++) {
@@ -501,7 +495,7 @@ __global__ __launch_bounds__(256) void k1_demod2(K1Args a)
     /* ---- stage B2: RSSI = EMA(|s|), alpha = 0.6789 (rtl_wmbus.c:475-495) --------------------- */
     {
         const int ch = tid >> 6, e = tid & 63;               /* wave 0: T1/C1, wave 1: S1 */
-        const bool on = ch < 2 && (ch ? chS : chT) && 16 * e < T && !dbgE;
+        const bool on = ch < 2 && (ch ? chS : chT) && 16 * e < T;
         const float *mg = (ch ? yMgS : yMgT) + 17 * e;        /* element 16 e + kk at 17 e + kk + kk/16 */
         const float al = 0.6789f, be = wm_sub(1.0f, 0.6789f);
         const int m0l = 16 * e;
