@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -392,6 +393,14 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
         /* K1 */
         const uint32_t T = c->T, ntiles = (g.M + T - 1) / T;
         K1Args k1{g, c->d_dphi, c->d_rssi, c->d_lut, c->d_lut + 32 * WM_MAX_DECIM, c->d_ema_head, c->d_ema_tail, ntiles, c->d_scalars + SC_ERR};
+        /* Contexts of one process take turns in the demodulation kernel: it fills the GPU on its own
+         * (VALU bound), so two of them side by side only time-slice, while one of them beside the
+         * other contexts' latency- and memory-bound framer kernels is complementary.  The turn also
+         * makes the event pair below measure the kernel rather than its share of the GPU. */
+        static std::mutex k1_turn[16];
+        std::unique_lock<std::mutex> turn(k1_turn[c->cfg.device & 15], std::defer_lock);
+        static const bool take_turns = !(getenv("WMBUS_K1_TURNS") && atoi(getenv("WMBUS_K1_TURNS")) == 0);
+        if (take_turns) turn.lock();
         HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
         int rc;
         const bool sh = c->flags & WM_F_SHIFT;
@@ -404,6 +413,7 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
         hipLaunchKernelGGL(k1_verify, dim3((2 * c->S + 63) / 64), dim3(64), 0, c->stream, c->d_ema_head, c->d_ema_tail,
                            c->d_ema_carry, ntiles, 2 * c->S, c->d_scalars + SC_ERR);
         HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+        if (take_turns) { HIPCHK(c, hipEventSynchronize(c->ev[4])); turn.unlock(); }
 
         /* K2: clock recovery + time2 framer (also produces the slicer bits the RLA needs) */
         K2Args k2{};
