@@ -275,6 +275,14 @@ WM_HD float wm_discriminator_fast(float i, float q, float pi_, float pq_)
     return wm_sub(wm_mul(pi_, q), wm_mul(i, pq_));
 }
 
+/* Level of the recovered clock = (y * gain >= 0) with gain = 1.874981046e-06f (iir.h:74, rtl_wmbus.c:338,353,
+ * 1089).  The product is only ever compared with zero, and it is >= 0 exactly when y is not below
+ * -266669 * 2^-149 (the largest negative y whose product rounds to -0; found by running the multiply
+ * over every subnormal y on the host, tests/test_exact_math.py).  On the bit pattern this is one
+ * carry: bits(y) + WM_LEVEL_CARRY overflows 32 bits <=> level low. */
+#define WM_LEVEL_CARRY 0x7FFBEE52u      /* 0xFFFFFFFF - (0x80000000 + 266669) */
+WM_HD int wm_level_high(float y) { return (uint64_t)wm_f2u(y) + WM_LEVEL_CARRY <= 0xFFFFFFFFull; }
+
 /* cu8 sample -> boxcar input (rtl_wmbus.c:1312-1313 then the int parameter of mavgi,
  * moving_average_filter.h:47): (int)((float)u8 - 127.5f), truncation toward zero. */
 WM_HD int wm_quantise(unsigned u8) { return u8 >= 128u ? (int)u8 - 128 : (int)u8 - 127; }

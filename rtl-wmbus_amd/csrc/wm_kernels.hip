@@ -645,13 +645,6 @@ __device__ __forceinline__ int wm_sdiv(int a, int b)
 #define WM_CLK_CROW 17           /* words per lane in its chip staging (16 + 1) */
 #define WM_CLK_BROW 9            /* words per lane in its slicer-word staging (8 + 1) */
 
-/* Level of the recovered clock = (y * gain >= 0) with gain = 1.874981046e-06f (iir.h:74, rtl_wmbus.c:338,353,
- * 1089).  The product is only ever compared with zero, and it is >= 0 exactly when y is not below
- * -266669 * 2^-149 (the largest negative y whose product rounds to -0; found by running the multiply
- * over every subnormal y on the host, tests/test_exact_math.py).  On the bit pattern this is one
- * carry: bits(y) + WM_LEVEL_CARRY overflows 32 bits <=> level low. */
-#define WM_LEVEL_CARRY 0x7FFBEE52u      /* 0xFFFFFFFF - (0x80000000 + 266669) */
-
 /* 32 samples through [DC remover] -> x^2 -> 3 biquads -> clock level, SOFTWARE-PIPELINED across the
  * filter sections: at tick t section k works on sample t - k, so the three (four with -o) recurrences
  * of a tick are independent instruction streams; a lone wave issues a dependent VALU operation only

@@ -55,6 +55,25 @@ int main(int argc, char **argv)
         /* the kernels feed the table form with the unscaled boxcar sums */
         if (wm_f2u(ref) != wm_f2u(wm_discriminator_tab((float)v[0], (float)v[1], (float)v[2], (float)v[3], TAB))) bad++;
     }
+    /* clock level: (y * gain >= 0) decided on the bit pattern of y (wm_level_high), every subnormal y,
+     * both signs, plus a sweep of normal values */
+    {
+        volatile float gain = 1.874981046e-06f;
+        for (uint32_t m = 0; m < 0x00800000u + 4096u; m++)
+            for (uint32_t sgn = 0; sgn < 2; sgn++) {
+                const float y = wm_u2f((sgn << 31) | m);
+                volatile float p = y * gain;
+                if ((p >= 0.0f) != wm_level_high(y)) bad++;
+                tot++;
+            }
+        for (long k = 0; k < 4000000; k++) {
+            const float y = wm_u2f((uint32_t)rnd());
+            if (y != y) continue;
+            volatile float p = y * gain;
+            if ((p >= 0.0f) != wm_level_high(y)) bad++;
+            tot++;
+        }
+    }
     printf("checked %ld cases, %ld mismatches\n", tot, bad);
     return bad != 0;
 }
