@@ -62,7 +62,14 @@ typedef struct wmbus_cfg {
     unsigned rla_lookback;      /* speculative run-length lookback                   */
     unsigned host_threads;      /* host decoder threads, 0 = auto                    */
     int keep_taps;              /* 1: keep soft symbols readable via wmbus_read_tap  */
+    /* Low-pass in front of the decimator.  BOXCAR = the moving averages the reference's main()
+     * runs (rtl_wmbus.c:1333-1344): what every reference binary computes, bit for bit.
+     * POLYPHASE = lp_ppf_butter_1600kHz_160kHz_200kHz (rtl_wmbus.c:258-294 over ppf.h:46-59), which
+     * the reference defines but never calls: an extension, 1.6 MS/s (decimation 2, no -s) only. */
+    int prefilter;
 } wmbus_cfg;
+
+enum { WMBUS_PREFILTER_BOXCAR = 0, WMBUS_PREFILTER_POLYPHASE = 1 };
 
 typedef struct wmbus_ctx wmbus_ctx;
 

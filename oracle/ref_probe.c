@@ -10,7 +10,11 @@
  *   stages <prefix> [a] stdin = cu8 (d = 2, no -s/-o).  Runs the reference's own stage functions
  *                       in the order main()/the signal chains call them (rtl_wmbus.c:1310-1356,
  *                       1047-1111, 1139-1203) and writes <prefix>.{iq,draw,dphi,rssi,clk}{0,1}.f32
- *                       taps (chain 0 = T1/C1, 1 = S1).  Optional 'a' = inaccurate atan (-a).
+ *                       taps (chain 0 = T1/C1, 1 = S1).  Optional flag letters: 'a' = inaccurate atan
+ *                       (-a); 'p' = the polyphase low-pass lp_ppf_butter_1600kHz_160kHz_200kHz
+ *                       (rtl_wmbus.c:258-294, ppf.h:46-59; defined by the reference but never called
+ *                       from its main()) in place of the two moving averages: one (i,q) pair feeds
+ *                       both chains.
  *   chips <chain> <algo-tag>   stdin = (chip value, rssi) byte pairs -> reference packet decoder;
  *                       datagram lines appear on stdout exactly as the reference prints them.
  */
@@ -45,7 +49,7 @@ static int mode_tables(void)
     return 0;
 }
 
-static int mode_stages(const char *prefix, int inaccurate)
+static int mode_stages(const char *prefix, int inaccurate, int use_ppf)
 {
     size_t cap = 1 << 20, n = 0;
     uint8_t *in = malloc(cap);
@@ -66,8 +70,14 @@ static int mode_stages(const char *prefix, int inaccurate)
     unsigned idx = 0;
     for (size_t k = 0; k < n; k += 2) {
         const float i_unfilt = ((float)(in[k]) - 127.5f), q_unfilt = ((float)(in[k + 1]) - 127.5f);
-        const float it = moving_average_t1_c1(i_unfilt, 0), qt = moving_average_t1_c1(q_unfilt, 1);
-        const float is = moving_average_s1(i_unfilt, 0), qs = moving_average_s1(q_unfilt, 1);
+        float it, qt, is, qs;
+        if (use_ppf) {
+            it = is = lp_ppf_butter_1600kHz_160kHz_200kHz(i_unfilt, 0);
+            qt = qs = lp_ppf_butter_1600kHz_160kHz_200kHz(q_unfilt, 1);
+        } else {
+            it = moving_average_t1_c1(i_unfilt, 0); qt = moving_average_t1_c1(q_unfilt, 1);
+            is = moving_average_s1(i_unfilt, 0); qs = moving_average_s1(q_unfilt, 1);
+        }
         if (++idx < 2) continue;
         idx = 0;
         iq[0][2 * m] = it; iq[0][2 * m + 1] = qt; iq[1][2 * m] = is; iq[1][2 * m + 1] = qs;
@@ -106,8 +116,9 @@ static int mode_chips(int chain, const char *tag)
 int main(int argc, char **argv)
 {
     if (argc >= 2 && !strcmp(argv[1], "tables")) return mode_tables();
-    if (argc >= 3 && !strcmp(argv[1], "stages")) return mode_stages(argv[2], argc >= 4);
+    if (argc >= 3 && !strcmp(argv[1], "stages"))
+        return mode_stages(argv[2], argc >= 4 && strchr(argv[3], 'a') != NULL, argc >= 4 && strchr(argv[3], 'p') != NULL);
     if (argc >= 4 && !strcmp(argv[1], "chips")) { opts_show_used_algorithm = 1; return mode_chips(atoi(argv[2]), argv[3]); }
-    fprintf(stderr, "usage: ref_probe tables | stages <prefix> [a] | chips <chain> <tag>\n");
+    fprintf(stderr, "usage: ref_probe tables | stages <prefix> [a][p] | chips <chain> <tag>\n");
     return 2;
 }

@@ -398,8 +398,12 @@ typedef struct chain_state {
     pkt_decoder rl_dec;
 } chain_state;
 
+/* ppf.h:36-59 + rtl_wmbus.c:258-294: two phases of 12 taps, one ring per phase and component. */
+typedef struct ppf_state { float sum; unsigned phase; float hist[2][12]; int pos[2]; } ppf_state;
+
 struct wmo_ctx {
     wmo_opts o;
+    ppf_state ppf[2];        /* i, q */
     unsigned dec_idx;        /* rtl_wmbus.c:1255 */
     size_t lut_n, lut_pos;   /* rtl_wmbus.c:974-1010 */
     float *lut_cos, *lut_msin;
@@ -645,6 +649,32 @@ static void chain_step(wmo_ctx *c, chain_state *ch)
     }
 }
 
+/* rtl_wmbus.c:262-266: b[PHASES][COEFFS]; filter[..].fir = {b[1] for phase 0, b[0] for phase 1} (:275-276). */
+static const float PPF_B[2][12] = {
+    {0.000140535927, 0.0001309279731, 0.00551787474, 0.03160167988, 0.08315031015, 0.1295143636, 0.1295143636,
+     0.08315031015, 0.03160167988, 0.00551787474, 0.0001309279731, 0.000140535927},
+    {1.102280392e-05, 0.001356012537, 0.01499414005, 0.05525973093, 0.1099887688, 0.1366692652, 0.1099887688,
+     0.05525973093, 0.01499414005, 0.001356012537, 1.102280392e-05, 0},
+};
+
+/* ppf.h:46-59: at phase == max_phase the running sum restarts; every call adds the current phase's
+ * FIR (fir.h:48-72: ring history, taps ascending from the newest sample, accumulated from 0). */
+static float ppf_step(ppf_state *f, float sample)
+{
+    if (f->phase == 2) { f->phase = 0; f->sum = 0; }
+    const float *b = PPF_B[f->phase == 0 ? 1 : 0];
+    float *hist = f->hist[f->phase];
+    int *pos = &f->pos[f->phase];
+    hist[*pos] = sample;
+    float acc = 0;
+    int p = *pos;
+    for (int k = 0; k < 12; k++) { acc += b[k] * hist[p]; p = p ? p - 1 : 11; }
+    *pos = *pos + 1 == 12 ? 0 : *pos + 1;
+    f->sum += acc;
+    f->phase++;
+    return f->sum;
+}
+
 /* rtl_wmbus.c:1298-1357: the per-input-sample loop. */
 size_t wmo_feed(wmo_ctx *c, const uint8_t *cu8, size_t nbytes)
 {
@@ -663,12 +693,17 @@ size_t wmo_feed(wmo_ctx *c, const uint8_t *cu8, size_t nbytes)
         }
         /* float -> int truncation happens at the boxcar's int parameter (A.1). */
         chain_state *a = &c->ch[0], *b = &c->ch[1];
+        if (c->o.prefilter == 1) {                     /* one filtered (i,q) pair feeds both chains */
+            a->i = b->i = ppf_step(&c->ppf[0], fi);
+            a->q = b->q = ppf_step(&c->ppf[1], fq);
+        } else {
         a->i = boxcar(a, 0, (int)it);
         a->q = boxcar(a, 1, (int)qt);
         a->box_pos = a->box_pos + 1 == a->box_len ? 0 : a->box_pos + 1;
         b->i = boxcar(b, 0, (int)is);
         b->q = boxcar(b, 1, (int)qs);
         b->box_pos = b->box_pos + 1 == b->box_len ? 0 : b->box_pos + 1;
+        }
 
         if (++c->dec_idx < c->o.decimation) continue; /* :1350-1352 */
         c->dec_idx = 0;

@@ -37,6 +37,9 @@ typedef struct wmo_opts {
     int time2_enabled;       /* 0 after -t 0                            */
     int show_algorithm;      /* -v                                      */
     int fixed_timestamp;     /* 1: print the literal "TS" instead of wall-clock time */
+    int prefilter;           /* 0: the moving averages main() calls (rtl_wmbus.c:1333-1344);
+                                1: the polyphase low-pass the reference defines but never calls
+                                   (rtl_wmbus.c:258-294, ppf.h:46-59), d = 2 only, no -s */
 } wmo_opts;
 
 void wmo_default_opts(wmo_opts *o);

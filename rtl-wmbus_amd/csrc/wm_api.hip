@@ -142,6 +142,15 @@ template <int D, bool SHIFT> int launch_k1v2(wmbus_ctx *c, const K1Args &a, uint
     return 0;
 }
 
+int launch_k1_ppf(wmbus_ctx *c, const K1Args &a, uint32_t ntiles)
+{
+    const size_t sm = K1PpfGeo::smem();
+    HIPCHK(c, hipFuncSetAttribute((const void *)k1_demod_ppf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+    hipLaunchKernelGGL(k1_demod_ppf, dim3(ntiles, c->S), dim3(256), sm, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
 /* The kernels' arithmetic (table-driven atan2 included) on arbitrary operand pairs. */
 __global__ void k_selftest(const float *a, const float *b, float *o_sqrt, float *o_div, float *o_atan2, float *o_disc, uint32_t n)
 {
@@ -210,6 +219,10 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
     if (cfg->n_streams < 1) return bail(fail(c, WMBUS_EINVAL, "n_streams must be >= 1"));
     if (cfg->max_push_bytes < WMBUS_BLOCK_BYTES || cfg->max_push_bytes % WMBUS_BLOCK_BYTES)
         return bail(fail(c, WMBUS_EINVAL, "max_push_bytes must be a positive multiple of 4096"));
+    if (cfg->prefilter != WMBUS_PREFILTER_BOXCAR && cfg->prefilter != WMBUS_PREFILTER_POLYPHASE)
+        return bail(fail(c, WMBUS_EINVAL, "prefilter must be WMBUS_PREFILTER_BOXCAR or WMBUS_PREFILTER_POLYPHASE"));
+    if (cfg->prefilter == WMBUS_PREFILTER_POLYPHASE && (cfg->decimation != 2 || cfg->simultaneous))
+        return bail(fail(c, WMBUS_EINVAL, "the polyphase pre-filter is the 1.6 MS/s design of rtl_wmbus.c:258-294: decimation 2, no -s"));
     if (wmbus_device_count() <= cfg->device) return bail(fail(c, WMBUS_ENODEVICE, "no HIP device %d (this library has no CPU fallback)", cfg->device));
     if (hipSetDevice(cfg->device) != hipSuccess) return bail(fail(c, WMBUS_EDEVICE, "hipSetDevice(%d) failed", cfg->device));
 
@@ -404,7 +417,8 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
         HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
         int rc;
         const bool sh = c->flags & WM_F_SHIFT;
-        if (c->k1_gen2 && c->d == 2) rc = sh ? launch_k1v2<2, true>(c, k1, ntiles) : launch_k1v2<2, false>(c, k1, ntiles);
+        if (c->cfg.prefilter == WMBUS_PREFILTER_POLYPHASE) rc = launch_k1_ppf(c, k1, ntiles);
+        else if (c->k1_gen2 && c->d == 2) rc = sh ? launch_k1v2<2, true>(c, k1, ntiles) : launch_k1v2<2, false>(c, k1, ntiles);
         else if (c->k1_gen2 && c->d == 3) rc = sh ? launch_k1v2<3, true>(c, k1, ntiles) : launch_k1v2<3, false>(c, k1, ntiles);
         else if (c->k1_gen2 && c->d == 4) rc = sh ? launch_k1v2<4, true>(c, k1, ntiles) : launch_k1v2<4, false>(c, k1, ntiles);
         else if (c->k1_gen2 && c->d == 5) rc = sh ? launch_k1v2<5, true>(c, k1, ntiles) : launch_k1v2<5, false>(c, k1, ntiles);

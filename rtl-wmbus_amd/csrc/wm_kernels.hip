@@ -326,6 +326,101 @@ __device__ __forceinline__ void k1_boxcars(const uint32_t *w, wm_s2 s8[5], wm_s2
     }
 }
 
+/* Stages B1 (FIR) and B2 (RSSI EMA + hand-off certification) of a 976-sample tile; shared by the
+ * moving-average and the polyphase front ends.  Rows: element a of a discriminator row at word
+ * a + 4, of a magnitude row at a + a/16 (the two chains' rows may alias when they carry the same
+ * data).  Ends with the magnitude rows' barrier already passed by every thread. */
+__device__ __forceinline__ void k1_stage_b(const K1Args &a, const int tid, const int tile, const int stream, const int ts, const int tn,
+                                           const bool chT, const bool chS, const float *yDrT, const float *yDrS,
+                                           const float *yMgT, const float *yMgS, float *sFin, float *sHead)
+{
+    constexpr int T = WM_K1_TILE2;
+    const WmPush &g = a.g;
+    /* ---- stage B1: FIR low-pass, y[n] = sum_k b[k] x[n-k], k ascending (fir.h:48-72) ---------- */
+    {
+        const int m0l = 4 * tid;
+        const uint64_t row = (uint64_t)stream * g.Mcap + (uint64_t)ts + m0l;
+        if (chT && m0l < tn) {
+            float w[16];                                      /* w[i] = element 4 tid + 36 + i */
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float4 v = *(const float4 *)(yDrT + 4 * tid + 40 + 4 * k);
+                w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+            }
+            float acc[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float s = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 11; k++) s = wm_add(s, wm_mul(FIR_T[k], w[12 + j - k]));
+                acc[j] = s;
+            }
+            *(float4 *)(a.dphi + row) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        }
+        if (chS && m0l < tn) {
+            float w[52];                                      /* w[i] = element 4 tid + i */
+#pragma unroll
+            for (int k = 0; k < 13; k++) {
+                const float4 v = *(const float4 *)(yDrS + 4 * tid + 4 + 4 * k);
+                w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+            }
+            float acc[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float s = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 46; k++) s = wm_add(s, wm_mul(FIR_S[k], w[48 + j - k]));
+                acc[j] = s;
+            }
+            *(float4 *)(a.dphi + (uint64_t)g.S * g.Mcap + row) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        }
+    }
+
+    __syncthreads();                                          /* magnitude rows complete */
+
+    /* ---- stage B2: RSSI = EMA(|s|), alpha = 0.6789 (rtl_wmbus.c:475-495) --------------------- */
+    {
+        const int ch = tid >> 6, e = tid & 63;               /* wave 0: T1/C1, wave 1: S1 */
+        const bool on = ch < 2 && (ch ? chS : chT) && 16 * e < T;
+        const float *mg = (ch ? yMgS : yMgT) + 17 * e;        /* element 16 e + kk at 17 e + kk + kk/16 */
+        const float al = 0.6789f, be = wm_sub(1.0f, 0.6789f);
+        const int m0l = 16 * e;
+        float ema = 0.0f, tail = 0.0f, head = 0.0f;
+        if (on) {
+#pragma unroll
+            for (int k = 0; k < WM_EMA_WARMUP; k++)
+                ema = wm_add(wm_mul(al, mg[k + (k >> 4)]), wm_mul(be, ema));
+            head = ema;
+            uint32_t pk[4] = {0u, 0u, 0u, 0u};
+            if (tn == T) {                                    /* full tile: the tail is lane 63's last value */
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    ema = wm_add(wm_mul(al, mg[WM_K1_HALO + k + ((WM_K1_HALO + k) >> 4)]), wm_mul(be, ema));
+                    pk[k >> 2] |= ((uint32_t)ema & 0xFFu) << (8 * (k & 3));
+                }
+                tail = ema;
+            } else {                                          /* last tile of a push */
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    ema = wm_add(wm_mul(al, mg[WM_K1_HALO + k + ((WM_K1_HALO + k) >> 4)]), wm_mul(be, ema));
+                    pk[k >> 2] |= ((uint32_t)ema & 0xFFu) << (8 * (k & 3));
+                    if (m0l + k == tn - 1) tail = ema;
+                }
+            }
+            if (m0l < tn)
+                *(uint4 *)(a.rssi + ((uint64_t)ch * g.S + stream) * g.Mcap + ts + m0l) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            sFin[tid] = ema; sHead[tid] = head;
+        }
+        __syncthreads();
+        if (on) {
+            if (e > 0 && m0l < tn && wm_f2u(head) != wm_f2u(sFin[tid - 1])) atomicOr(a.err, WM_ERR_EMA);
+            const uint64_t ti = ((uint64_t)ch * g.S + stream) * a.ntiles + tile;
+            if (e == 0) a.ema_head[ti] = head;
+            if (m0l <= tn - 1 && tn - 1 < m0l + 16) a.ema_tail[ti] = tail;
+        }
+    }
+}
+
 template <int D, bool SHIFT>
 __global__ __launch_bounds__(256) void k1_demod2(K1Args a)
 {
@@ -450,89 +545,113 @@ __global__ __launch_bounds__(256) void k1_demod2(K1Args a)
         for (int j = 0; j < 4; j++) { yMgT[qb + j] = mgT[j]; yMgS[qb + j] = mgS[j]; }
     }
 
-    /* ---- stage B1: FIR low-pass, y[n] = sum_k b[k] x[n-k], k ascending (fir.h:48-72) ---------- */
+    k1_stage_b(a, tid, tile, stream, ts, tn, chT, chS, yDrT, yDrS, yMgT, yMgS, sFin, sHead);
+}
+
+/* =============================================================================================
+ * K1 with the POLYPHASE pre-filter: ppf.h:46-59 driven as the reference's
+ * lp_ppf_butter_1600kHz_160kHz_200kHz does (rtl_wmbus.c:258-294): even input samples through the
+ * 12 taps b[1], odd ones through b[0], y[m] = (0 + F_even[m]) + F_odd[m] taken after the odd
+ * sample -- in place of the two moving averages.  The reference defines this filter but never calls
+ * it, so it is an OPTION here (cfg.prefilter = 1, d = 2, no -s) and is pinned at stage level: the
+ * reference's own function, driven by oracle/ref_probe.c, against the oracle, and the oracle against
+ * this kernel.  One filtered (i,q) pair feeds both chains, so discriminator and magnitude are
+ * computed once; the operands are arbitrary floats, hence the general wm_atan2f / wm_sqrt.
+ * LDS (words): float2 staging[2 NA + 24] (the magnitude row overlays it) | yDr[YD] | sFin, sHead.
+ * ===========================================================================================*/
+__device__ static constexpr float PPF_EVEN[12] = {1.102280392e-05f, 0.001356012537f, 0.01499414005f, 0.05525973093f,
+    0.1099887688f, 0.1366692652f, 0.1099887688f, 0.05525973093f, 0.01499414005f, 0.001356012537f, 1.102280392e-05f, 0.0f};
+__device__ static constexpr float PPF_ODD[12] = {0.000140535927f, 0.0001309279731f, 0.00551787474f, 0.03160167988f,
+    0.08315031015f, 0.1295143636f, 0.1295143636f, 0.08315031015f, 0.03160167988f, 0.00551787474f, 0.0001309279731f,
+    0.000140535927f};
+
+struct K1PpfGeo {
+    static constexpr int T = WM_K1_TILE2, NA = T + WM_K1_HALO;
+    static constexpr int NSTG = 2 * (2 * NA + 24);                    /* words: float2 per input sample */
+    static constexpr int YD = NA + 8, YM = NA + NA / 16 + 4;
+    static constexpr size_t smem() { return (size_t)(NSTG + YD + 256) * 4; }
+};
+
+__global__ __launch_bounds__(256) void k1_demod_ppf(K1Args a)
+{
+    using G = K1PpfGeo;
+    constexpr int T = G::T, NA = G::NA;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *stg = (float2 *)smem;                            /* element 0 = input sample 2 (m_first - 12) */
+    float *yMg = (float *)smem;                              /* overlays the staging after stage A */
+    float *yDr = (float *)smem + G::NSTG;
+    float *sFin = yDr + G::YD, *sHead = sFin + 128;
+
+    const WmPush &g = a.g;
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x, stream = blockIdx.y;
+    const int ts = tile * T;
+    const int tn = min(T, (int)g.M - ts);
+    const bool chT = g.flags & WM_F_T1C1, chS = g.flags & WM_F_S1;
+    const bool accurate = g.flags & WM_F_ACCURATE;
+
+    /* ---- stage 0: bytes -> floats (rtl_wmbus.c:1312-1313), no truncation on this path; samples
+     * before the start of the stream are the filters' zero history, not the byte the input window
+     * was pre-filled with ---------------------------------------------------------------------- */
     {
-        const int m0l = 4 * tid;
-        const uint64_t row = (uint64_t)stream * g.Mcap + (uint64_t)ts + m0l;
-        if (chT && m0l < tn) {
-            float w[16];                                      /* w[i] = element 4 tid + 36 + i */
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const float4 v = *(const float4 *)(yDrT + 4 * tid + 40 + 4 * k);
-                w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
-            }
-            float acc[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                float s = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 11; k++) s = wm_add(s, wm_mul(FIR_T[k], w[12 + j - k]));
-                acc[j] = s;
-            }
-            *(float4 *)(a.dphi + row) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        }
-        if (chS && m0l < tn) {
-            float w[52];                                      /* w[i] = element 4 tid + i */
-#pragma unroll
-            for (int k = 0; k < 13; k++) {
-                const float4 v = *(const float4 *)(yDrS + 4 * tid + 4 + 4 * k);
-                w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
-            }
-            float acc[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                float s = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 46; k++) s = wm_add(s, wm_mul(FIR_S[k], w[48 + j - k]));
-                acc[j] = s;
-            }
-            *(float4 *)(a.dphi + (uint64_t)g.S * g.Mcap + row) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        const long n_first = 2L * ((long)(g.m0 + (uint64_t)ts) - WM_K1_HALO - 1 - 11);     /* global input index of element 0 */
+        const long r_lo = n_first - (long)g.n0;                                            /* even: n0 is a multiple of 2048 */
+        const uint8_t *base = g.in + (uint64_t)stream * g.in_stride + WM_HIST_BYTES;
+        const uint32_t *src = (const uint32_t *)(base + 2 * r_lo);
+        constexpr int NDW = (2 * NA + 24) / 2;
+        for (int u = tid; u < NDW; u += 256) {
+            const uint32_t w = src[u];
+            const bool live = n_first + 2L * u >= 0;
+            float4 v;
+            v.x = live ? wm_sub((float)(w & 0xFFu), 127.5f) : 0.0f;
+            v.y = live ? wm_sub((float)((w >> 8) & 0xFFu), 127.5f) : 0.0f;
+            v.z = live ? wm_sub((float)((w >> 16) & 0xFFu), 127.5f) : 0.0f;
+            v.w = live ? wm_sub((float)(w >> 24), 127.5f) : 0.0f;
+            *(float4 *)(stg + 2 * u) = v;
         }
     }
+    __syncthreads();
 
-    __syncthreads();                                          /* magnitude rows complete */
-
-    /* ---- stage B2: RSSI = EMA(|s|), alpha = 0.6789 (rtl_wmbus.c:475-495) --------------------- */
+    /* ---- stage A: thread = 4 consecutive decimated samples (+ the one before, for the
+     * discriminator); output j (a = 4 tid - 1 + j) uses staged samples 2 (j + 11 - k) [+ 1] of the
+     * thread's 32-sample window ---------------------------------------------------------------- */
+    float mg[4];
     {
-        const int ch = tid >> 6, e = tid & 63;               /* wave 0: T1/C1, wave 1: S1 */
-        const bool on = ch < 2 && (ch ? chS : chT) && 16 * e < T;
-        const float *mg = (ch ? yMgS : yMgT) + 17 * e;        /* element 16 e + kk at 17 e + kk + kk/16 */
-        const float al = 0.6789f, be = wm_sub(1.0f, 0.6789f);
-        const int m0l = 16 * e;
-        float ema = 0.0f, tail = 0.0f, head = 0.0f;
-        if (on) {
+        float2 x[32];
 #pragma unroll
-            for (int k = 0; k < WM_EMA_WARMUP; k++)
-                ema = wm_add(wm_mul(al, mg[k + (k >> 4)]), wm_mul(be, ema));
-            head = ema;
-            uint32_t pk[4] = {0u, 0u, 0u, 0u};
-            if (tn == T) {                                    /* full tile: the tail is lane 63's last value */
+        for (int k = 0; k < 16; k++) {
+            const float4 v = *(const float4 *)(stg + 8 * tid + 2 * k);
+            x[2 * k] = make_float2(v.x, v.y); x[2 * k + 1] = make_float2(v.z, v.w);
+        }
+        float fi[5], fq[5];
 #pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    ema = wm_add(wm_mul(al, mg[WM_K1_HALO + k + ((WM_K1_HALO + k) >> 4)]), wm_mul(be, ema));
-                    pk[k >> 2] |= ((uint32_t)ema & 0xFFu) << (8 * (k & 3));
-                }
-                tail = ema;
-            } else {                                          /* last tile of a push */
+        for (int j = 0; j < 5; j++) {
+            float ei = 0.0f, eq = 0.0f, oi = 0.0f, oq = 0.0f;        /* fir.h:58-67: accumulate from 0, taps ascending */
 #pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    ema = wm_add(wm_mul(al, mg[WM_K1_HALO + k + ((WM_K1_HALO + k) >> 4)]), wm_mul(be, ema));
-                    pk[k >> 2] |= ((uint32_t)ema & 0xFFu) << (8 * (k & 3));
-                    if (m0l + k == tn - 1) tail = ema;
-                }
+            for (int k = 0; k < 12; k++) {
+                const float2 e = x[2 * (j + 11 - k)], o = x[2 * (j + 11 - k) + 1];
+                ei = wm_add(ei, wm_mul(PPF_EVEN[k], e.x)); eq = wm_add(eq, wm_mul(PPF_EVEN[k], e.y));
+                oi = wm_add(oi, wm_mul(PPF_ODD[k], o.x)); oq = wm_add(oq, wm_mul(PPF_ODD[k], o.y));
             }
-            if (m0l < tn)
-                *(uint4 *)(a.rssi + ((uint64_t)ch * g.S + stream) * g.Mcap + ts + m0l) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-            sFin[tid] = ema; sHead[tid] = head;
+            fi[j] = wm_add(wm_add(0.0f, ei), oi);                     /* ppf.h:49-54: sum = 0; sum += even; sum += odd */
+            fq[j] = wm_add(wm_add(0.0f, eq), oq);
         }
-        __syncthreads();
-        if (on) {
-            if (e > 0 && m0l < tn && wm_f2u(head) != wm_f2u(sFin[tid - 1])) atomicOr(a.err, WM_ERR_EMA);
-            const uint64_t ti = ((uint64_t)ch * g.S + stream) * a.ntiles + tile;
-            if (e == 0) a.ema_head[ti] = head;
-            if (m0l <= tn - 1 && tn - 1 < m0l + 16) a.ema_tail[ti] = tail;
+        float dr[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float i = fi[j + 1], q = fq[j + 1], pi_ = fi[j], pq_ = fq[j];
+            dr[j] = accurate ? wm_discriminator(i, q, pi_, pq_) : wm_discriminator_fast(i, q, pi_, pq_);
+            mg[j] = wm_sqrt(wm_add(wm_mul(i, i), wm_mul(q, q)));
         }
+        *(float4 *)(yDr + 4 * tid + 4) = make_float4(dr[0], dr[1], dr[2], dr[3]);
     }
+    __syncthreads();                                          /* staging data retired */
+    {
+        const int qb = 4 * tid + (tid >> 2);
+#pragma unroll
+        for (int j = 0; j < 4; j++) yMg[qb + j] = mg[j];
+    }
+    k1_stage_b(a, tid, tile, stream, ts, tn, chT, chS, yDr, yDr, yMg, yMg, sFin, sHead);
 }
 
 /* head[tile] must equal tail[tile-1] (or the value carried from the previous push). */

@@ -36,6 +36,7 @@ static void print_usage(const char *prog)
     fprintf(stdout, "\t-f exit if flow of incoming data stops\n");
     fprintf(stdout, "\t-B bytes per GPU push (multiple of 4096, default 1048576)\n");
     fprintf(stdout, "\t-G HIP device ordinal (default 0)\n");
+    fprintf(stdout, "\t-P polyphase low-pass (ppf.h) instead of the moving average before decimation (1.6 MS/s, -d 2, no -s)\n");
     fprintf(stdout, "\t-h print this help\n");
 }
 
@@ -67,7 +68,7 @@ int main(int argc, char **argv)
     wmbus_default_cfg(&cfg);
     cfg.max_push_bytes = 1u << 20;
     int check_flow = 0, opt;
-    while ((opt = getopt(argc, argv, "ofad:p:r:vVst:B:G:")) != -1) {
+    while ((opt = getopt(argc, argv, "ofad:p:r:vVst:B:G:P")) != -1) {
         switch (opt) {
         case 'o': cfg.remove_dc = 1; break;
         case 'f': check_flow = 1; break;
@@ -85,6 +86,7 @@ int main(int argc, char **argv)
         case 'V': fprintf(stdout, "rtl_wmbus: " VERSION "\n"); return EXIT_SUCCESS;
         case 'B': cfg.max_push_bytes = (size_t)strtoull(optarg, NULL, 10) / WMBUS_BLOCK_BYTES * WMBUS_BLOCK_BYTES; break;
         case 'G': cfg.device = atoi(optarg); break;
+        case 'P': cfg.prefilter = WMBUS_PREFILTER_POLYPHASE; break;
         default: print_usage(argv[0]); return EXIT_FAILURE;
         }
     }

@@ -126,6 +126,37 @@ def test_synthetic_captures_match_reference_golden_and_oracle(wm, oracle, case):
     assert text == ref["text"]
 
 
+@pytest.mark.parametrize("flags", [[], ["-a"], ["-o"], ["-p", "S"]], ids=lambda f: " ".join(f) or "default")
+def test_polyphase_prefilter_matches_oracle(wm, oracle, samples, flags):
+    """cfg.prefilter = POLYPHASE (ppf.h:46-59 as rtl_wmbus.c:258-294 drives it).  The
+    oracle's polyphase stage is pinned on the reference's own function (test_oracle_units.py); here
+    the HIP kernel must reproduce the oracle: soft symbols, RSSI, slicer bits, every chip, the text."""
+    kw = flags_to_kwargs(flags + ["-v"])
+    oo = flags_to_oracle_opts(oracle, flags + ["-v"]); oo.prefilter = 1
+    chains = [c for c, on in ((0, kw.get("t1c1", True)), (1, kw.get("s1", True))) if on]
+    for cu8 in (samples["samples2"],
+                wm.synth_capture(seed=41, n_samples=1 << 19, kinds=15, frames_per_s=90.0, amplitude=35.0)[0]):
+        ref = oracle.run(cu8, oo, taps=True, chips=True)
+        with wm.Receiver(n_streams=1, max_push_bytes=cu8.size, prefilter=1, **kw) as rx:
+            text = rx.run(cu8)[0]
+            compare_taps(rx, ref, chains=chains)
+            compare_chips(rx, ref, chains=chains)
+        assert text == ref["text"]
+    assert len(text.splitlines()) >= 4
+
+
+def test_polyphase_prefilter_streams_and_rejects_other_rates(wm, oracle):
+    cu8, _ = wm.synth_capture(seed=43, n_samples=1 << 18, kinds=15, frames_per_s=90.0, amplitude=35.0)
+    oo = oracle.make_opts(prefilter=1)
+    ref = oracle.run(cu8, oo)["text"]
+    with wm.Receiver(n_streams=1, max_push_bytes=1 << 18, prefilter=1) as rx:
+        assert rx.run(cu8, push_bytes=4096 * 9)[0] == ref      # filter history carried across pushes
+    with pytest.raises(wm.WmbusError):
+        wm.Receiver(n_streams=1, decimation=3, prefilter=1)
+    with pytest.raises(wm.WmbusError):
+        wm.Receiver(n_streams=1, simultaneous=True, prefilter=1)
+
+
 @pytest.mark.parametrize("seg_len,w0,w1,lb", [(4096, 1024, 1024, 64), (8192, 4096, 8192, 256), (65536, 24576, 49152, 1024)])
 def test_result_independent_of_segmentation(wm, oracle, samples, seg_len, w0, w1, lb):
     """Short warm-ups force hand-off verification failures: the re-run path must restore exactness."""

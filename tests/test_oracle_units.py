@@ -45,6 +45,23 @@ def test_soft_symbol_taps_bit_identical(wm, tmp_path, inaccurate):
             assert np.array_equal(ref.view(np.uint32), r[key][ch].view(np.uint32)), (name, ch)
 
 
+@pytest.mark.parametrize("inaccurate", [False, True])
+def test_polyphase_prefilter_taps_bit_identical(wm, tmp_path, inaccurate):
+    """the polyphase low-pass the reference defines (ppf.h:46-59, rtl_wmbus.c:258-294)
+    but never calls.  The oracle's optional prefilter is pinned on the reference's own function:
+    filtered (i,q), discriminator, FIR, RSSI and clock-filter taps of the reference stage functions
+    fed by lp_ppf_butter_1600kHz_160kHz_200kHz equal the oracle's with prefilter=1, bit for bit."""
+    cu8, _ = wm.synth_capture(seed=17, n_samples=1 << 18, kinds=15, frames_per_s=80.0, amplitude=30.0)
+    prefix = str(tmp_path / "ppf")
+    subprocess.run([O.REF_PROBE, "stages", prefix, "pa" if inaccurate else "p"], input=cu8.tobytes(), check=True)
+    r = O.run(cu8, O.make_opts(accurate_atan=0 if inaccurate else 1, prefilter=1), taps=True)
+    for ch in (0, 1):
+        for name, key in (("iq", "iq"), ("draw", "dphi_raw"), ("dphi", "dphi"), ("rssi", "rssi"), ("clk", "clk")):
+            ref = np.fromfile(f"{prefix}.{name}{ch}.f32", np.float32)
+            assert np.array_equal(ref.view(np.uint32), r[key][ch].view(np.uint32)), (name, ch)
+    assert len(r["text"].splitlines()) >= 4      # the synthetic telegrams still decode behind this filter
+
+
 def test_reference_decoder_accepts_oracle_chip_log(wm):
     """Feed the oracle's chip log to the reference's packet decoders: same lines as the oracle."""
     cu8, _ = wm.synth_capture(seed=9, n_samples=1 << 19, kinds=15, frames_per_s=80.0, amplitude=30.0)
