@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--warmup-t1c1", type=int, default=0)
     ap.add_argument("--contexts", type=int, default=4, help="receiver contexts per GPU (GPU / host-decode overlap)")
     ap.add_argument("--stagger", type=float, default=-1.0, help="seconds between context starts (-1: a step / contexts)")
+    ap.add_argument("--from-host", action="store_true",
+                    help="informational: stage every capture from pinned host memory inside each step (PCIe-inclusive rate; "
+                         "the BASELINE metric keeps the input resident in HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     return ap.parse_args()
@@ -128,6 +131,15 @@ def main():
         base += per_ctx[i]
     t_h2d = time.perf_counter() - t_h2d      # includes buffer allocation; pageable host memory
 
+    host_caps = None
+    if a.from_host:                                    # pinned copies of the captures, one slab per context
+        host_caps, base = [], 0
+        for i in range(nctx):
+            slab = wm.pinned_array(per_ctx[i] * push_bytes).reshape(per_ctx[i], push_bytes)
+            for s_ in range(per_ctx[i]):
+                slab[s_] = caps[base + s_]
+            host_caps.append(slab)
+            base += per_ctx[i]
     pool = cf.ThreadPoolExecutor(nctx)
 
     def run_ctx(i, k_steps, stagger_s):
@@ -138,6 +150,9 @@ def main():
         if stagger_s > 0 and i:
             time.sleep(stagger_s * i)
         for _ in range(k_steps):
+            if a.from_host:
+                for s_ in range(per_ctx[i]):
+                    rx.stage(s_, host_caps[i][s_])
             rx.process(push_bytes)
             rx.collect()
             lines += rx.lines_count()
@@ -214,6 +229,7 @@ def main():
                                 "region (inside it the 4 contexts' launches overlap: avg %.3f ms each)" % k1_concurrent_ms},
             "stage_ms_last_step": [{k: round(v, 3) if isinstance(v, float) else v for k, v in t.items()} for t in last],
             "setup_s": {"generate": round(t_gen, 1), "alloc_and_h2d": round(t_h2d, 1)},
+            "input": "staged from pinned host memory inside every step (PCIe-inclusive, informational)" if a.from_host else "resident in HBM",
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(caps, n)

@@ -106,6 +106,10 @@ const char *wmbus_last_error(const wmbus_ctx *ctx);
 /* Replaces fread() at rtl_wmbus.c:1301: copy `nbytes` (multiple of 4096) of stream `stream`
  * from host memory into the device input window of the next push. */
 int  wmbus_stage(wmbus_ctx *ctx, unsigned stream, const uint8_t *cu8, size_t nbytes);
+/* Page-locked host memory for wmbus_stage sources (hipHostMalloc): copies from it run at the PCIe
+ * rate and asynchronously; any other host pointer works too, through the driver's bounce buffer. */
+void *wmbus_alloc_pinned(size_t nbytes);
+void  wmbus_free_pinned(void *p);
 /* Same for HBM-resident producers: device address of the stream's input window. */
 void *wmbus_device_input(wmbus_ctx *ctx, unsigned stream);
 

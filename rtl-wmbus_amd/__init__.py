@@ -64,7 +64,7 @@ class Timing(ctypes.Structure):
 
 EXPORTS = ["wmbus_default_cfg", "wmbus_open", "wmbus_close", "wmbus_last_error", "wmbus_stage", "wmbus_device_input",
            "wmbus_process", "wmbus_collect", "wmbus_lines", "wmbus_lines_text", "wmbus_get_timing", "wmbus_read_tap",
-           "wmbus_read_chips", "wmbus_device_count", "wmbus_selftest_math"]
+           "wmbus_read_chips", "wmbus_device_count", "wmbus_selftest_math", "wmbus_alloc_pinned", "wmbus_free_pinned"]
 
 _lib = None
 
@@ -91,6 +91,8 @@ def lib():
         L.wmbus_read_tap.argtypes = [vp, ctypes.c_char_p, ctypes.c_int, u, vp, sz]; L.wmbus_read_tap.restype = ctypes.c_long
         L.wmbus_read_chips.argtypes = [vp, ctypes.c_int, ctypes.c_int, u, vp, vp, sz]; L.wmbus_read_chips.restype = ctypes.c_long
         L.wmbus_device_count.restype = ctypes.c_int
+        L.wmbus_alloc_pinned.argtypes = [sz]; L.wmbus_alloc_pinned.restype = vp
+        L.wmbus_free_pinned.argtypes = [vp]
         L.wmbus_selftest_math.argtypes = [ctypes.c_int] + [vp] * 6 + [sz]
         _lib = L
     return _lib
@@ -98,6 +100,20 @@ def lib():
 
 def device_count():
     return int(lib().wmbus_device_count())
+
+
+def pinned_array(nbytes):
+    """uint8 numpy array over page-locked host memory (kept alive by the array's base object)."""
+    p = lib().wmbus_alloc_pinned(nbytes)
+    if not p:
+        raise WmbusError("wmbus_alloc_pinned failed")
+
+    class _Owner:
+        def __init__(self, ptr): self.ptr = ptr
+        def __del__(self): lib().wmbus_free_pinned(self.ptr)
+    buf = (ctypes.c_uint8 * nbytes).from_address(p)
+    buf._owner = _Owner(p)
+    return np.frombuffer(buf, np.uint8)
 
 
 def selftest_math(a, b, device=0):

@@ -329,6 +329,14 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
     return WMBUS_OK;
 }
 
+void *wmbus_alloc_pinned(size_t nbytes)
+{
+    void *p = nullptr;
+    return hipHostMalloc(&p, nbytes) == hipSuccess ? p : nullptr;
+}
+
+void wmbus_free_pinned(void *p) { if (p) hipHostFree(p); }
+
 void *wmbus_device_input(wmbus_ctx *c, unsigned stream)
 {
     if (!c || stream >= c->S) return nullptr;
