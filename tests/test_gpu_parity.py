@@ -205,6 +205,35 @@ def test_many_streams_in_one_batch(wm, oracle):
         assert texts[s] == oracle.run(caps[s], flags_to_oracle_opts(oracle, ["-v"]))["text"], s
 
 
+@pytest.mark.parametrize("flags", [["-v"], ["-o", "-v"]], ids=lambda f: " ".join(f))
+def test_wave_of_64_captures_takes_the_cooperative_path(wm, oracle, flags):
+    """n_streams a multiple of 64: the clock kernel's wave = 64 consecutive captures of one (chain,
+    segment) and fetches their rows cooperatively through LDS (bench.py's configuration).  Every
+    capture's text, chips and soft symbols against the oracle; several segments per capture, a
+    second push (carried state) and different signal levels per capture."""
+    n_streams, n = 128, 1 << 18
+    caps = [wm.synth_capture(seed=1300 + s, n_samples=n, kinds=15, frames_per_s=100.0, amplitude=[60, 25, 9, 40][s % 4])[0]
+            for s in range(n_streams)]
+    kw = flags_to_kwargs(flags)
+    with wm.Receiver(n_streams=n_streams, max_push_bytes=n, **kw) as rx:      # two pushes of n bytes each
+        texts = rx.run(caps)
+        tim = rx.timing()
+        for s in (0, 63, 64, 127):                                            # taps/chips of the LAST push
+            ref = oracle.run(caps[s], flags_to_oracle_opts(oracle, flags), taps=True, chips=True)
+            m_half = ref["m"] // 2
+            d = rx.read_tap("dphi", 0, s, m_half)
+            assert np.array_equal(d.view(np.uint32), ref["dphi_fir"][0][m_half:].view(np.uint32))
+            for ch in (0, 1):
+                for al in (0, 1):
+                    w, pos = rx.read_chips(ch, al, s)
+                    oc = ref["chips"][(ref["chips"]["chain"] == ch) & (ref["chips"]["algo"] == al) & (ref["chips"]["sample"] >= m_half)]
+                    assert len(w) == len(oc) and np.array_equal(w & 0xFF, oc["value"]) and np.array_equal((w >> 8) & 0xFF, oc["rssi"])
+                    assert np.array_equal(pos, oc["sample"])
+    for s in range(n_streams):
+        assert texts[s] == oracle.run(caps[s], flags_to_oracle_opts(oracle, flags))["text"], s
+    assert sum(len(t.splitlines()) for t in texts) > 4 * n_streams
+
+
 def test_edge_inputs(wm, oracle):
     rng = np.random.default_rng(5)
     cases = {
