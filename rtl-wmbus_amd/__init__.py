@@ -59,7 +59,7 @@ class Timing(ctypes.Structure):
 
     def as_dict(self):
         return {k: getattr(self, k) for k in ("demod_ms", "clock_ms", "rla_ms", "gather_ms", "d2h_ms", "gpu_total_ms",
-                                              "host_decode_ms", "clock_reruns", "rla_reruns", "bursts")}
+                                              "host_decode_ms", "clock_reruns", "rla_reruns", "ema_retries", "bursts")}
 
 
 EXPORTS = ["wmbus_default_cfg", "wmbus_open", "wmbus_close", "wmbus_last_error", "wmbus_stage", "wmbus_device_input",

@@ -44,9 +44,8 @@ struct wmbus_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
     /* geometry */
-    uint32_t d = 2, S = 1, C[2] = {8192, 32768}, Mcap = 0, nseg_cap[2] = {0, 0}, ntiles_cap = 0, RF = 8, T = 1024;
+    uint32_t d = 2, S = 1, C[2] = {8192, 32768}, Mcap = 0, nseg_cap[2] = {0, 0}, ntiles_cap = 0, T = WM_K1_TILE2;
     uint32_t cap[2] = {0, 0}, flags = 0;
-    bool k1_gen2 = false;
     uint64_t in_stride = 0, n0 = 0;
     size_t staged = 0;
     /* device buffers */
@@ -109,44 +108,20 @@ __global__ void k_carry(const uint32_t *fin, uint32_t *carry, uint32_t words, ui
     for (uint32_t k = 0; k < words; k++) carry[(uint64_t)r * words + k] = fin[((uint64_t)r * nseg_cap + nseg - 1) * words + k];
 }
 
-template <int RF> size_t k1_smem(uint32_t d, bool shift)
+template <int D, bool SHIFT> int launch_k1v2(wmbus_ctx *c, const K1Args &a, dim3 grid)
 {
-    constexpr int T = 256 * RF, NA = T + WM_K1_HALO;
-    const size_t stage = ((size_t)(NA * d + 16 + 8 + 7) / 8 * 8 + 4) * 4 * (shift ? 2 : 1);
-    const size_t y = ((size_t)((NA + 8) + (NA + 8) / RF + 4) * 2 + (size_t)((NA + 8) + (NA + 8) / (2 * RF) + 4) * 2 + 512) * 4;
-    return std::max(stage, y) + 64;
-}
-
-template <int RF> int launch_k1(wmbus_ctx *c, const K1Args &a, uint32_t ntiles)
-{
-    const bool shift = c->flags & WM_F_SHIFT;
-    const size_t sm = k1_smem<RF>(c->d, shift);
-    dim3 grid(ntiles, c->S);
-    if (shift) {
-        HIPCHK(c, hipFuncSetAttribute((const void *)k1_demod<RF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-        hipLaunchKernelGGL((k1_demod<RF, true>), grid, dim3(256), sm, c->stream, a);
-    } else {
-        HIPCHK(c, hipFuncSetAttribute((const void *)k1_demod<RF, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-        hipLaunchKernelGGL((k1_demod<RF, false>), grid, dim3(256), sm, c->stream, a);
-    }
-    HIPCHK(c, hipGetLastError());
-    return 0;
-}
-
-template <int D, bool SHIFT> int launch_k1v2(wmbus_ctx *c, const K1Args &a, uint32_t ntiles)
-{
-    const size_t sm = K1Geo<D>::smem(SHIFT);
+    const size_t sm = K1Geo::smem(D ? D : (int)c->d, SHIFT);
     HIPCHK(c, hipFuncSetAttribute((const void *)k1_demod2<D, SHIFT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-    hipLaunchKernelGGL((k1_demod2<D, SHIFT>), dim3(ntiles, c->S), dim3(256), sm, c->stream, a);
+    hipLaunchKernelGGL((k1_demod2<D, SHIFT>), grid, dim3(256), sm, c->stream, a);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
 
-int launch_k1_ppf(wmbus_ctx *c, const K1Args &a, uint32_t ntiles)
+int launch_k1_ppf(wmbus_ctx *c, const K1Args &a, dim3 grid)
 {
     const size_t sm = K1PpfGeo::smem();
     HIPCHK(c, hipFuncSetAttribute((const void *)k1_demod_ppf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-    hipLaunchKernelGGL(k1_demod_ppf, dim3(ntiles, c->S), dim3(256), sm, c->stream, a);
+    hipLaunchKernelGGL(k1_demod_ppf, grid, dim3(256), sm, c->stream, a);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -238,13 +213,7 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
     c->flags = (cfg->simultaneous ? WM_F_SHIFT : 0) | (cfg->accurate_atan ? WM_F_ACCURATE : 0) | (cfg->remove_dc ? WM_F_DC : 0) |
                (cfg->t1c1_enabled ? WM_F_T1C1 : 0) | (cfg->s1_enabled ? WM_F_S1 : 0) | (cfg->rla_enabled ? WM_F_RLA : 0) |
                (cfg->time2_enabled ? WM_F_T2A : 0);
-    /* tile: 2048 decimated samples up to d = 2, fewer for larger d so the staging fits in LDS */
-    c->RF = c->d <= 5 ? 4 : 2;   /* RF = 8 needs 190 VGPRs (2 waves/SIMD) and measured 1.8x slower */
-    if (const char *e = getenv("WMBUS_K1_RF")) { const int v = atoi(e); if (v == 8 || v == 4 || v == 2) c->RF = (uint32_t)v; }
-    /* decimations 2..5 run the second-generation tile kernel (tile 976); others the generic one */
-    c->k1_gen2 = c->d >= 2 && c->d <= 5 && c->RF == 4;
-    if (const char *e = getenv("WMBUS_K1_GEN")) c->k1_gen2 = c->k1_gen2 && atoi(e) != 1;
-    c->T = c->k1_gen2 ? (uint32_t)WM_K1_TILE2 : 256 * c->RF;
+    c->T = (uint32_t)WM_K1_TILE2;
     const uint32_t T = c->T;
     const uint64_t max_samples = cfg->max_push_bytes / 2;
     c->ntiles_cap = (uint32_t)((max_samples / c->d + 1 + 8 + T - 1) / T);
@@ -413,7 +382,8 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
         HIPCHK(c, hipMemsetAsync(c->d_scalars, 0, SC_COUNT * sizeof(uint32_t), c->stream));
         /* K1 */
         const uint32_t T = c->T, ntiles = (g.M + T - 1) / T;
-        K1Args k1{g, c->d_dphi, c->d_rssi, c->d_lut, c->d_lut + 32 * WM_MAX_DECIM, c->d_ema_head, c->d_ema_tail, ntiles, c->d_scalars + SC_ERR};
+        K1Args k1{g, c->d_dphi, c->d_rssi, c->d_lut, c->d_lut + 32 * WM_MAX_DECIM, c->d_ema_head, c->d_ema_tail, ntiles, c->d_scalars + SC_ERR,
+                  nullptr, c->d_ema_carry};
         /* Contexts of one process take turns in the demodulation kernel: it fills the GPU on its own
          * (VALU bound), so two of them side by side only time-slice, while one of them beside the
          * other contexts' latency- and memory-bound framer kernels is complementary.  The turn also
@@ -423,19 +393,37 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
         static const bool take_turns = !(getenv("WMBUS_K1_TURNS") && atoi(getenv("WMBUS_K1_TURNS")) == 0);
         if (take_turns) turn.lock();
         HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-        int rc;
-        const bool sh = c->flags & WM_F_SHIFT;
-        if (c->cfg.prefilter == WMBUS_PREFILTER_POLYPHASE) rc = launch_k1_ppf(c, k1, ntiles);
-        else if (c->k1_gen2 && c->d == 2) rc = sh ? launch_k1v2<2, true>(c, k1, ntiles) : launch_k1v2<2, false>(c, k1, ntiles);
-        else if (c->k1_gen2 && c->d == 3) rc = sh ? launch_k1v2<3, true>(c, k1, ntiles) : launch_k1v2<3, false>(c, k1, ntiles);
-        else if (c->k1_gen2 && c->d == 4) rc = sh ? launch_k1v2<4, true>(c, k1, ntiles) : launch_k1v2<4, false>(c, k1, ntiles);
-        else if (c->k1_gen2 && c->d == 5) rc = sh ? launch_k1v2<5, true>(c, k1, ntiles) : launch_k1v2<5, false>(c, k1, ntiles);
-        else rc = c->RF == 8 ? launch_k1<8>(c, k1, ntiles) : c->RF == 4 ? launch_k1<4>(c, k1, ntiles) : launch_k1<2>(c, k1, ntiles);
+        auto launch = [&](uint32_t n_list) -> int {                  /* n_list = 0: all tiles; else the repair list */
+            const bool sh = c->flags & WM_F_SHIFT;
+            k1.relist = n_list ? c->d_list : nullptr;
+            const dim3 grid = n_list ? dim3(n_list, 1) : dim3(ntiles, c->S);
+            if (c->cfg.prefilter == WMBUS_PREFILTER_POLYPHASE) return launch_k1_ppf(c, k1, grid);
+            if (c->d == 2) return sh ? launch_k1v2<2, true>(c, k1, grid) : launch_k1v2<2, false>(c, k1, grid);
+            if (c->d == 3) return sh ? launch_k1v2<3, true>(c, k1, grid) : launch_k1v2<3, false>(c, k1, grid);
+            if (c->d == 4) return sh ? launch_k1v2<4, true>(c, k1, grid) : launch_k1v2<4, false>(c, k1, grid);
+            if (c->d == 5) return sh ? launch_k1v2<5, true>(c, k1, grid) : launch_k1v2<5, false>(c, k1, grid);
+            return sh ? launch_k1v2<0, true>(c, k1, grid) : launch_k1v2<0, false>(c, k1, grid);      /* any other rate */
+        };
+        int rc = launch(0);
         if (rc) return rc;
-        hipLaunchKernelGGL(k1_verify, dim3((2 * c->S + 63) / 64), dim3(64), 0, c->stream, c->d_ema_head, c->d_ema_tail,
-                           c->d_ema_carry, ntiles, 2 * c->S, c->d_scalars + SC_ERR);
-        HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
-        if (take_turns) { HIPCHK(c, hipEventSynchronize(c->ev[4])); turn.unlock(); }
+        /* EMA hand-offs between tiles; an uncertified tile is re-run sequentially from its
+         * predecessor's exact tail (which may uncover the next one): exact by construction */
+        for (unsigned round = 0;; round++) {
+            hipLaunchKernelGGL(k1_verify, dim3((2 * c->S + 63) / 64), dim3(64), 0, c->stream, c->d_ema_head, c->d_ema_tail,
+                               c->d_ema_carry, ntiles, 2 * c->S, c->S, c->d_list, c->d_scalars + SC_NLIST);
+            if (round == 0) HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, SC_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (turn.owns_lock()) turn.unlock();
+            const uint32_t n = c->h_scalars[SC_NLIST];
+            if (n == 0) break;
+            if (round > ntiles + 1) return fail(c, WMBUS_EDEVICE, "RSSI filter hand-off repair did not converge");
+            c->tim.ema_retries += n;
+            rc = launch(n);
+            if (rc) return rc;
+            HIPCHK(c, hipMemsetAsync(c->d_scalars + SC_NLIST, 0, sizeof(uint32_t), c->stream));
+        }
+        hipLaunchKernelGGL(k1_commit, dim3((2 * c->S + 63) / 64), dim3(64), 0, c->stream, c->d_ema_tail, c->d_ema_carry, ntiles, 2 * c->S);
 
         /* K2: clock recovery + time2 framer (also produces the slicer bits the RLA needs) */
         K2Args k2{};
@@ -479,7 +467,6 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
         HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, SC_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         const uint32_t err = c->h_scalars[SC_ERR];
-        if (err & WM_ERR_EMA) return fail(c, WMBUS_EDEVICE, "RSSI filter hand-off verification failed (raise WM_EMA_WARMUP)");
         if (err & (WM_ERR_CHIP_OVERFLOW | WM_ERR_BURST_OVERFLOW)) return fail(c, WMBUS_EOVERFLOW, "chip/burst buffer overflow (err=%u)", err);
         c->n_hdr = c->h_scalars[SC_NHDR]; c->n_words = c->h_scalars[SC_NWORDS];
         if (c->n_hdr) HIPCHK(c, hipMemcpyAsync(c->h_hdr, c->d_hdr, (size_t)c->n_hdr * sizeof(WmBurstHdr), hipMemcpyDeviceToHost, c->stream));

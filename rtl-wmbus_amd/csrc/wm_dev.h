@@ -19,8 +19,8 @@
 #define WM_IN_SLACK     256u       /* readable slack behind the staged bytes                  */
 #define WM_K1_HALO      48         /* decimated-sample halo: 45 FIR + 1 discriminator, 48 EMA  */
 #define WM_EMA_WARMUP   48
-#define WM_K1_TILE2     976        /* tile of the second-generation K1: tile + halo = 1024      */
-#define WM_MAX_DECIM    32u
+#define WM_K1_TILE2     976        /* K1 tile: tile + halo = 1024 = 256 threads x 4           */
+#define WM_MAX_DECIM    16u        /* staging for d = 16 with -s: 131 KB of the 160 KB LDS */
 
 #define WM_CHIP_VAL(w)   ((w) & 0xFFu)
 #define WM_CHIP_RSSI(w)  (((w) >> 8) & 0xFFu)
@@ -83,7 +83,7 @@ enum {
 };
 
 /* error word bits (device -> host) */
-enum { WM_ERR_EMA = 1, WM_ERR_CHIP_OVERFLOW = 2, WM_ERR_BURST_OVERFLOW = 4 };
+enum { WM_ERR_CHIP_OVERFLOW = 2, WM_ERR_BURST_OVERFLOW = 4 };
 
 /* Burst = the chips a packet decoder needs after one access-code hit. */
 struct WmBurstHdr {

@@ -48,7 +48,7 @@ __device__ static constexpr float FIR_S[46] = {
     -0.001361601657f, -0.0009491938209f, -0.000649081282f};
 
 /* =============================================================================================
- * K1: demodulation tile kernel
+ * K1: demodulation tile kernels
  * ===========================================================================================*/
 struct K1Args {
     WmPush g;
@@ -60,217 +60,16 @@ struct K1Args {
     float *ema_tail;         /* [2][S][ntiles] EMA after the tile's last valid sample      */
     uint32_t ntiles;
     uint32_t *err;
+    /* repair launches: grid.x walks `relist` (stream * ntiles + tile);
+     * the tile's EMA is then run sequentially from its predecessor's exact tail */
+    const uint32_t *relist;
+    const float *ema_carry;  /* [2][S] exact EMA carried in from the previous push */
 };
 
-template <int RF, bool SHIFT>
-__global__ __launch_bounds__(256) void k1_demod(K1Args a)
-{
-    constexpr int T = 256 * RF;                       /* decimated samples per tile       */
-    constexpr int NA = T + WM_K1_HALO;                /* samples needing i/q              */
-    constexpr int RA = (NA + 255) / 256;              /* stage-A samples per thread       */
-    constexpr int RE = 2 * RF;                        /* EMA run per thread               */
-    /* LDS float rows are SKEWED so that the strided per-lane windows below are bank-conflict
-     * free: discriminator row, element a at P(a) = (a+1) + (a+1)/RF (lane stride RF+1 words);
-     * magnitude row, element a at Q(a) = a + a/RE (lane stride RE+1 words).                   */
-    constexpr int YROW_D = (NA + 8) + (NA + 8) / RF + 4;
-    constexpr int YROW_M = (NA + 8) + (NA + 8) / RE + 4;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const WmPush &g = a.g;
-    const int tid = threadIdx.x;
-    const int tile = blockIdx.x, stream = blockIdx.y;
-    const int d = (int)g.d;
-    const int ts = tile * T;                          /* first decimated sample (push-relative) */
-    const int tn = min(T, (int)g.M - ts);             /* valid samples in this tile        */
-    const bool chT = g.flags & WM_F_T1C1, chS = g.flags & WM_F_S1;
-
-    /* ---- stage 0: stage the boxcar inputs in LDS as packed int16 (i,q) ------------------- */
-    /* relative input index (to the first new sample) of the oldest sample needed:
-     * boxcar-16 ending at decimated sample (ts - HALO - 1).                                  */
-    const long r_lo = ((long)(g.m0 + (uint64_t)ts) - (WM_K1_HALO)) * d - 16 - (long)g.n0;
-    const long r_al = r_lo & ~7L;                     /* 16-byte aligned start             */
-    const int off = (int)(r_lo - r_al);
-    const int count = NA * d + 16 + off;              /* samples staged                    */
-    const int nchunk = (count + 7) >> 3;
-    wm_s2 *sT = (wm_s2 *)smem;
-    wm_s2 *sS = SHIFT ? sT + ((nchunk * 8 + 3) & ~3) : sT;
-    const uint8_t *base = g.in + (uint64_t)stream * g.in_stride + WM_HIST_BYTES;
-
-    for (int c = tid; c < nchunk; c += 256) {
-        const long r = r_al + 8L * c;
-        const uint4 v = *(const uint4 *)(base + 2 * r);
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-        uint32_t li = 0;
-        if (SHIFT) {
-            /* LUT index of global sample n: (13 n) mod lut_n, rtl_wmbus.c:1006-1010 */
-            const int L = (int)g.lut_n;
-            int rm = (int)(r % L); if (rm < 0) rm += L;
-            li = (g.lut_phase0 + 13u * (uint32_t)rm) % (uint32_t)L;
-        }
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const uint32_t iq = (w[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
-            const uint32_t bi = iq & 0xFFu, bq = iq >> 8;
-            if (!SHIFT) {
-                wm_s2 x; x.x = (short)wm_quantise(bi); x.y = (short)wm_quantise(bq);
-                sT[8 * c + k] = x;
-            } else {
-                const float fi = wm_sub((float)bi, 127.5f), fq = wm_sub((float)bq, 127.5f);
-                const float x = a.lut_cos[li], z = a.lut_msin[li];
-                li += 13u; if (li >= g.lut_n) li -= g.lut_n;
-                const float ix = wm_mul(fi, x), qx = wm_mul(fq, x), iz = wm_mul(fi, z), qz = wm_mul(fq, z);
-                wm_s2 t, s;
-                t.x = (short)(int)wm_sub(ix, qz); t.y = (short)(int)wm_add(qx, iz);
-                s.x = (short)(int)wm_add(ix, qz); s.y = (short)(int)wm_sub(qx, iz);
-                sT[8 * c + k] = t; sS[8 * c + k] = s;
-            }
-        }
-    }
-    __syncthreads();
-
-    /* ---- stage A: boxcars (sliding packed-int16 sums), discriminator, magnitude ------------ */
-    float drT[RA], drS[RA], mgT[RA], mgS[RA];
-    {
-        const int a0 = RA * tid;                      /* index into [0, NA)                */
-        /* LDS index of decimated sample a: off + a*d + d + 15; start one
-         * decimated sample earlier: the discriminator needs s[a0-1].                        */
-        int l = off + (a0 - 1) * d + d + 15;
-        const bool live = a0 < NA;
-        wm_s2 sumT = {0, 0}, sumS = {0, 0};
-        if (live) {
-#pragma unroll
-            for (int k = 0; k < 8; k++) sumT += sT[l - k];
-#pragma unroll
-            for (int k = 0; k < 16; k++) sumS += sS[l - k];
-        }
-        float piT = (float)sumT.x * 0.125f, pqT = (float)sumT.y * 0.125f;
-        float piS = (float)sumS.x * 0.0625f, pqS = (float)sumS.y * 0.0625f;
-#pragma unroll
-        for (int j = 0; j < RA; j++) {
-            drT[j] = drS[j] = mgT[j] = mgS[j] = 0.0f;
-            if (live && a0 + j < NA) {
-                for (int s = 0; s < d; s++) {
-                    l++;
-                    sumT += sT[l] - sT[l - 8];
-                    sumS += sS[l] - sS[l - 16];
-                }
-                if (chT) {
-                    const float i = (float)sumT.x * 0.125f, q = (float)sumT.y * 0.125f;
-                    drT[j] = (g.flags & WM_F_ACCURATE) ? wm_discriminator(i, q, piT, pqT)
-                                                       : wm_discriminator_fast(i, q, piT, pqT);
-                    mgT[j] = wm_sqrt(wm_add(wm_mul(i, i), wm_mul(q, q)));
-                    piT = i; pqT = q;
-                }
-                if (chS) {
-                    const float i = (float)sumS.x * 0.0625f, q = (float)sumS.y * 0.0625f;
-                    drS[j] = (g.flags & WM_F_ACCURATE) ? wm_discriminator(i, q, piS, pqS)
-                                                       : wm_discriminator_fast(i, q, piS, pqS);
-                    mgS[j] = wm_sqrt(wm_add(wm_mul(i, i), wm_mul(q, q)));
-                    piS = i; pqS = q;
-                }
-            }
-        }
-    }
-    __syncthreads();                                  /* everyone is done with sT/sS       */
-
-    /* float arrays overlay the staging area; element a lives at position a + 1 so that the
-     * 46-tap windows start 16-byte aligned (a = 48 + RF*tid - 45 -> position 4 + RF*tid).   */
-    float *yDrT = (float *)smem, *yDrS = yDrT + YROW_D, *yMgT = yDrS + YROW_D, *yMgS = yMgT + YROW_M;
-    float *sFin = yMgS + YROW_M;                      /* [2][128] EMA finals               */
-    float *sHead = sFin + 256;                        /* [2][128] EMA after warm-up        */
-    auto P = [](int a) { return (a + 1) + (a + 1) / RF; };
-    auto Q = [](int a) { return a + a / RE; };
-    {
-        const int a0 = RA * tid;
-#pragma unroll
-        for (int j = 0; j < RA; j++)
-            if (a0 + j < NA) {
-                yDrT[P(a0 + j)] = drT[j]; yDrS[P(a0 + j)] = drS[j];
-                yMgT[Q(a0 + j)] = mgT[j]; yMgS[Q(a0 + j)] = mgS[j];
-            }
-    }
-    __syncthreads();
-
-    /* ---- stage B1: FIR low-pass, y[n] = sum_k b[k] x[n-k], k ascending (fir.h:48-72) -------- */
-    {
-        const int m0l = RF * tid;                     /* first output of this thread       */
-        const uint64_t row = (uint64_t)stream * g.Mcap + (uint64_t)ts + m0l;
-        if (chT && m0l < tn) {
-            float w[RF + 10];
-#pragma unroll
-            for (int k = 0; k < RF + 10; k++) w[k] = yDrT[P(WM_K1_HALO + m0l - 10 + k)];
-            float acc[RF];
-#pragma unroll
-            for (int j = 0; j < RF; j++) {
-                float s = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 11; k++) s = wm_add(s, wm_mul(FIR_T[k], w[10 + j - k]));
-                acc[j] = s;
-            }
-            float *o = a.dphi + row;
-#pragma unroll
-            for (int j = 0; j < RF; j++) o[j] = acc[j];
-        }
-        if (chS && m0l < tn) {
-            float w[RF + 45];
-#pragma unroll
-            for (int k = 0; k < RF + 45; k++) w[k] = yDrS[P(WM_K1_HALO + m0l - 45 + k)];
-            float acc[RF];
-#pragma unroll
-            for (int j = 0; j < RF; j++) {
-                float s = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 46; k++) s = wm_add(s, wm_mul(FIR_S[k], w[45 + j - k]));
-                acc[j] = s;
-            }
-            float *o = a.dphi + (uint64_t)g.S * g.Mcap + row;
-#pragma unroll
-            for (int j = 0; j < RF; j++) o[j] = acc[j];
-        }
-    }
-
-    /* ---- stage B2: RSSI = EMA(|s|), alpha = 0.6789 (rtl_wmbus.c:475-495) --------------------- */
-    {
-        const int ch = tid >> 7, e = tid & 127;
-        const bool on = ch ? chS : chT;
-        const float *mg = ch ? yMgS : yMgT;
-        const float al = 0.6789f, be = wm_sub(1.0f, 0.6789f);
-        const int m0l = RE * e;
-        float ema = 0.0f, tail = 0.0f;
-        if (on) {
-#pragma unroll 8
-            for (int k = 0; k < WM_EMA_WARMUP; k++)
-                ema = wm_add(wm_mul(al, mg[Q(m0l + k)]), wm_mul(be, ema));
-        }
-        const float head = ema;
-        uint32_t pk[(RE + 3) / 4] = {};
-        if (on) {
-#pragma unroll
-            for (int k = 0; k < RE; k++) {
-                ema = wm_add(wm_mul(al, mg[Q(WM_K1_HALO + m0l + k)]), wm_mul(be, ema));
-                pk[k >> 2] |= ((uint32_t)ema & 0xFFu) << (8 * (k & 3));
-                if (m0l + k == tn - 1) tail = ema;
-            }
-            if (m0l < tn) {
-                uint32_t *o = (uint32_t *)(a.rssi + ((uint64_t)ch * g.S + stream) * g.Mcap + ts + m0l);
-#pragma unroll
-                for (int k = 0; k < (RE + 3) / 4; k++) o[k] = pk[k];
-            }
-        }
-        sFin[tid] = ema; sHead[tid] = head;
-        __syncthreads();
-        if (on) {
-            /* certify: my warm-up must have landed exactly on my predecessor's trajectory */
-            if (e > 0 && m0l < tn && wm_f2u(head) != wm_f2u(sFin[tid - 1])) atomicOr(a.err, WM_ERR_EMA);
-            const uint64_t ti = ((uint64_t)ch * g.S + stream) * a.ntiles + tile;
-            if (e == 0) a.ema_head[ti] = head;
-            if (m0l <= tn - 1 && tn - 1 < m0l + RE) a.ema_tail[ti] = tail;
-        }
-    }
-}
-
 /* =============================================================================================
- * K1 (second generation): same arithmetic, far fewer instructions, balanced waves.
+ * K1, moving-average front end (second generation of this kernel; the first one -- 1024-sample
+ * tiles, five samples per thread, sliding sums, select-based arctangent, 30.7 ms -- is in the git
+ * history): same arithmetic, far fewer instructions, balanced waves.
  *
  * Tile = 976 decimated samples, so that tile + 48-sample halo = 1024 = 256 threads x 4: every
  * thread owns exactly one chunk of 4 consecutive samples in stage A (the first generation spent
@@ -289,25 +88,36 @@ __global__ __launch_bounds__(256) void k1_demod(K1Args a)
  *              overlay the staging area: stage A keeps its 8 magnitudes in registers until the
  *              barrier that retires the staging data.
  * ===========================================================================================*/
-template <int D> struct K1Geo {
+/* D = the decimation as a compile-time constant (2..5: the rates rtl-wmbus documents) or 0: read it
+ * from the push at run time (any 1..WM_MAX_DECIM; same code with loops instead of unrolled runs). */
+struct K1Geo {
     static constexpr int T = WM_K1_TILE2, NA = T + WM_K1_HALO;
-    static constexpr int NSTG = (NA * D + 16 + 8 + 7) / 8 * 8 + 8;   /* 8 slack words in front (stage 0 stores p >= -7) */
     static constexpr int YD = NA + 8, YM = NA + NA / 16 + 4;
-    static constexpr int ustage(bool shift) { return NSTG * (shift ? 2 : 1); }
-    static constexpr int U(bool shift) { return ustage(shift) > 2 * YM ? ustage(shift) : 2 * YM; }
-    static constexpr size_t smem(bool shift)
+    __host__ __device__ static constexpr int nstg(int d) { return (NA * d + 16 + 8 + 7) / 8 * 8 + 8; }   /* 8 slack words in front */
+    __host__ __device__ static constexpr int U(int d, bool shift)
     {
-        return (size_t)(U(shift) + 2 * YD + 256 + WM_ATAN_TAB_WORDS) * 4;
+        return nstg(d) * (shift ? 2 : 1) > 2 * YM ? nstg(d) * (shift ? 2 : 1) : 2 * YM;
     }
+    static constexpr size_t smem(int d, bool shift) { return (size_t)(U(d, shift) + 2 * YD + 256 + WM_ATAN_TAB_WORDS) * 4; }
 };
-static_assert(K1Geo<2>::NA == 1024, "stage A maps one 4-sample chunk to each of the 256 threads");
+static_assert(K1Geo::NA == 1024, "stage A maps one 4-sample chunk to each of the 256 threads");
 
 /* 8- and 16-tap boxcar sums at the five positions a0-1 .. a0+3 of one chunk from the staged
  * samples w[0 .. 4D+16) (w[15] is the newest input of position a0-1). */
 template <int D>
-__device__ __forceinline__ void k1_boxcars(const uint32_t *w, wm_s2 s8[5], wm_s2 s16[5])
+__device__ __forceinline__ void k1_boxcars(const uint32_t *w, int d_rt, wm_s2 s8[5], wm_s2 s16[5])
 {
-    constexpr int N = 4 * D + 16;
+    if (D == 0) {                                             /* run-time decimation: direct sums */
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            const int n = j * d_rt + 15;
+            wm_s2 lo = {0, 0}, hi = {0, 0};
+            for (int k = 0; k < 8; k++) { lo += __builtin_bit_cast(wm_s2, w[n - k]); hi += __builtin_bit_cast(wm_s2, w[n - 8 - k]); }
+            s8[j] = lo; s16[j] = lo + hi;
+        }
+        return;
+    }
+    constexpr int N = 4 * (D ? D : 1) + 16;
     uint32_t x[N];
 #pragma unroll
     for (int k = 0; k < N / 4; k++) {
@@ -386,6 +196,27 @@ __device__ __forceinline__ void k1_stage_b(const K1Args &a, const int tid, const
         const float al = 0.6789f, be = wm_sub(1.0f, 0.6789f);
         const int m0l = 16 * e;
         float ema = 0.0f, tail = 0.0f, head = 0.0f;
+        const uint64_t row = (uint64_t)ch * g.S + stream;
+        const uint64_t ti = row * a.ntiles + tile;
+        if (a.relist != nullptr) {
+            /* REPAIR: a hand-off of this tile could not be certified (e.g. exact-zero input after a
+             * signal: the true state decays through 90 more samples while a 48-sample warm-up from
+             * zero is already at zero).  One lane per chain runs the whole tile sequentially from the
+             * predecessor's exact tail -- slow, exact, and only for the listed tiles. */
+            if (on && e == 0) {
+                const float *mrow = ch ? yMgS : yMgT;
+                ema = tile ? a.ema_tail[ti - 1] : a.ema_carry[row];
+                head = ema;
+                uint8_t *o = a.rssi + row * g.Mcap + ts;
+                for (int m = 0; m < tn; m++) {
+                    const int el = WM_K1_HALO + m;
+                    ema = wm_add(wm_mul(al, mrow[el + (el >> 4)]), wm_mul(be, ema));
+                    o[m] = (uint8_t)((uint32_t)ema & 0xFFu);
+                }
+                a.ema_head[ti] = head; a.ema_tail[ti] = ema;
+            }
+            return;
+        }
         if (on) {
 #pragma unroll
             for (int k = 0; k < WM_EMA_WARMUP; k++)
@@ -408,14 +239,16 @@ __device__ __forceinline__ void k1_stage_b(const K1Args &a, const int tid, const
                 }
             }
             if (m0l < tn)
-                *(uint4 *)(a.rssi + ((uint64_t)ch * g.S + stream) * g.Mcap + ts + m0l) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                *(uint4 *)(a.rssi + row * g.Mcap + ts + m0l) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
             sFin[tid] = ema; sHead[tid] = head;
         }
         __syncthreads();
+        /* certify: a lane's warm-up must have landed exactly on its predecessor's trajectory; a tile
+         * with an uncertified lane publishes a head that cannot match (NaN) and is repaired */
+        const bool bad = on && e > 0 && m0l < tn && wm_f2u(head) != wm_f2u(sFin[tid - 1]);
+        const unsigned long long badT = __ballot(bad);        /* waves 0 and 1 are the two chains */
         if (on) {
-            if (e > 0 && m0l < tn && wm_f2u(head) != wm_f2u(sFin[tid - 1])) atomicOr(a.err, WM_ERR_EMA);
-            const uint64_t ti = ((uint64_t)ch * g.S + stream) * a.ntiles + tile;
-            if (e == 0) a.ema_head[ti] = head;
+            if (e == 0) a.ema_head[ti] = badT ? wm_u2f(0x7FC00000u) : head;
             if (m0l <= tn - 1 && tn - 1 < m0l + 16) a.ema_tail[ti] = tail;
         }
     }
@@ -424,18 +257,21 @@ __device__ __forceinline__ void k1_stage_b(const K1Args &a, const int tid, const
 template <int D, bool SHIFT>
 __global__ __launch_bounds__(256) void k1_demod2(K1Args a)
 {
-    using G = K1Geo<D>;
-    constexpr int T = G::T, NA = G::NA, NSTG = G::NSTG, YD = G::YD, YM = G::YM;
+    using G = K1Geo;
+    constexpr int T = G::T, NA = G::NA, YD = G::YD, YM = G::YM;
+    const WmPush &g = a.g;
+    const int d = D ? D : (int)g.d;
+    const int NSTG = G::nstg(d);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t *stgT = (uint32_t *)smem + 8;                /* word 0 of a row = oldest sample of the tile */
     uint32_t *stgS = SHIFT ? stgT + NSTG : stgT;
     float *yMgT = (float *)smem, *yMgS = yMgT + YM;       /* overlay the staging rows (see stage A) */
-    float *yDrT = (float *)smem + G::U(SHIFT), *yDrS = yDrT + YD;
+    float *yDrT = (float *)smem + G::U(d, SHIFT), *yDrS = yDrT + YD;
     float *sFin = yDrS + YD, *sHead = sFin + 128, *tab = sHead + 128;
 
-    const WmPush &g = a.g;
     const int tid = threadIdx.x;
-    const int tile = blockIdx.x, stream = blockIdx.y;
+    const int tile = a.relist ? (int)(a.relist[blockIdx.x] % a.ntiles) : (int)blockIdx.x;
+    const int stream = a.relist ? (int)(a.relist[blockIdx.x] / a.ntiles) : (int)blockIdx.y;
     const int ts = tile * T;
     const int tn = min(T, (int)g.M - ts);
     const bool chT = g.flags & WM_F_T1C1, chS = g.flags & WM_F_S1;
@@ -447,22 +283,24 @@ __global__ __launch_bounds__(256) void k1_demod2(K1Args a)
      * two-word lane stride (the 16-byte-per-lane variant stored at an 8-word stride: 8-way bank
      * conflicts) ------------------------------------------------------------------------------- */
     {
-        const long r_lo = ((long)(g.m0 + (uint64_t)ts) - WM_K1_HALO) * D - 16 - (long)g.n0;   /* LDS word 0 */
+        const long r_lo = ((long)(g.m0 + (uint64_t)ts) - WM_K1_HALO) * d - 16 - (long)g.n0;   /* LDS word 0 */
         const long r_al = r_lo & ~1L;
         const int off = (int)(r_lo - r_al);                   /* 0 or 1 */
-        constexpr int NDW = (NA * D + 16 + 1 + 1) / 2;        /* dwords covering the staged samples */
+        const int NDW = (NA * d + 16 + 1 + 1) / 2;            /* dwords covering the staged samples */
         const uint8_t *base = g.in + (uint64_t)stream * g.in_stride + WM_HIST_BYTES;
         const uint32_t *src = (const uint32_t *)(base + 2 * r_al);
-        constexpr int NP = (NDW + 255) / 256;
+        constexpr int NP = D ? ((NA * D + 16 + 1 + 1) / 2 + 255) / 256 : 1;     /* loads in flight per lane */
+        const int passes = D ? 1 : (NDW + 255) / 256;
+        for (int ps = 0; ps < passes; ps++) {
         uint32_t wv[NP];
 #pragma unroll
         for (int it = 0; it < NP; it++) {
-            const int u = tid + 256 * it;
+            const int u = tid + 256 * (it + ps);
             wv[it] = u < NDW ? src[u] : 0u;
         }
 #pragma unroll
         for (int it = 0; it < NP; it++) {
-            const int u = tid + 256 * it;
+            const int u = tid + 256 * (it + ps);
             if (u < NDW) {
                 const int p = 2 * u - off;
                 if (!SHIFT) {
@@ -495,6 +333,7 @@ __global__ __launch_bounds__(256) void k1_demod2(K1Args a)
                 }
             }
         }
+        }
     }
     __syncthreads();
 
@@ -503,8 +342,8 @@ __global__ __launch_bounds__(256) void k1_demod2(K1Args a)
     {
         const int c = tid;
         wm_s2 s8[5], s16[5], u8[5], u16[5];
-        k1_boxcars<D>(stgT + 4 * c * D, s8, SHIFT ? u16 : s16);
-        if (SHIFT) k1_boxcars<D>(stgS + 4 * c * D, u8, s16);
+        k1_boxcars<D>(stgT + 4 * c * d, d, s8, SHIFT ? u16 : s16);
+        if (SHIFT) k1_boxcars<D>(stgS + 4 * c * d, d, u8, s16);
         float drT[4], drS[4];
         if (chT) {
             float pi_ = (float)s8[0].x, pq_ = (float)s8[0].y;
@@ -584,7 +423,8 @@ __global__ __launch_bounds__(256) void k1_demod_ppf(K1Args a)
 
     const WmPush &g = a.g;
     const int tid = threadIdx.x;
-    const int tile = blockIdx.x, stream = blockIdx.y;
+    const int tile = a.relist ? (int)(a.relist[blockIdx.x] % a.ntiles) : (int)blockIdx.x;
+    const int stream = a.relist ? (int)(a.relist[blockIdx.x] / a.ntiles) : (int)blockIdx.y;
     const int ts = tile * T;
     const int tn = min(T, (int)g.M - ts);
     const bool chT = g.flags & WM_F_T1C1, chS = g.flags & WM_F_S1;
@@ -654,20 +494,29 @@ __global__ __launch_bounds__(256) void k1_demod_ppf(K1Args a)
     k1_stage_b(a, tid, tile, stream, ts, tn, chT, chS, yDr, yDr, yMg, yMg, sFin, sHead);
 }
 
-/* head[tile] must equal tail[tile-1] (or the value carried from the previous push). */
-__global__ void k1_verify(const float *head, const float *tail, float *carry, uint32_t ntiles,
-                          uint32_t rows, uint32_t *err)
+/* head[tile] must equal tail[tile-1] (or the value carried from the previous push).  The first tile
+ * of a row that does not is appended to the repair list; tiles after it cannot be judged before it
+ * is repaired.  k1_commit stores the new carries once every row verifies. */
+__global__ void k1_verify(const float *head, const float *tail, const float *carry, uint32_t ntiles,
+                          uint32_t rows, uint32_t S, uint32_t *relist, uint32_t *n_relist)
 {
     const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;   /* chain*S + stream */
     if (row >= rows) return;
     float prev = carry[row];
-    bool bad = false;
     for (uint32_t t = 0; t < ntiles; t++) {
-        bad |= wm_f2u(head[(uint64_t)row * ntiles + t]) != wm_f2u(prev);
+        if (wm_f2u(head[(uint64_t)row * ntiles + t]) != wm_f2u(prev)) {
+            relist[atomicAdd(n_relist, 1u)] = (row % S) * ntiles + t;
+            return;
+        }
         prev = tail[(uint64_t)row * ntiles + t];
     }
-    carry[row] = prev;
-    if (bad) atomicOr(err, WM_ERR_EMA);
+}
+
+/* every hand-off certified: the last tile's tail becomes the carry of the next push */
+__global__ void k1_commit(const float *tail, float *carry, uint32_t ntiles, uint32_t rows)
+{
+    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row < rows) carry[row] = tail[(uint64_t)row * ntiles + ntiles - 1];
 }
 
 /* =============================================================================================

@@ -8,12 +8,20 @@
  * wmbus_stage()/wmbus_process()/wmbus_collect() from libwmbus_hip.so.  Plain C; the GPU is only
  * reached through the C ABI in include/wmbus_hip.h.
  * Extensions (letters the reference does not use): -B bytes per GPU push (default 1 MiB),
- * -G HIP device ordinal.
+ * -G HIP device ordinal, -P polyphase pre-filter, -T host:port (cu8 over TCP, e.g. a raw IQ server;
+ * the role of the reference's unused net_support.h:15-44 / rtl_wmbus.c:1281), and
+ *   rtl_wmbus_hip [switches] a.cu8 b.cu8 ...      batch mode: one capture per file, all of them in
+ * lock step on one GPU, lines prefixed "a.cu8: "; a reader thread fills one pinned slab while the
+ * GPU works on the other (double-buffered H2D).
  */
+#include <arpa/inet.h>
+#include <netdb.h>
+#include <pthread.h>
 #include <signal.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/socket.h>
 #include <unistd.h>
 
 #include "wmbus_hip.h"
@@ -37,7 +45,112 @@ static void print_usage(const char *prog)
     fprintf(stdout, "\t-B bytes per GPU push (multiple of 4096, default 1048576)\n");
     fprintf(stdout, "\t-G HIP device ordinal (default 0)\n");
     fprintf(stdout, "\t-P polyphase low-pass (ppf.h) instead of the moving average before decimation (1.6 MS/s, -d 2, no -s)\n");
+    fprintf(stdout, "\t-T host:port read the cu8 stream from a TCP server instead of stdin\n");
+    fprintf(stdout, "\tFILE... batch mode: decode several cu8 files at once (lines prefixed with the file name)\n");
     fprintf(stdout, "\t-h print this help\n");
+}
+
+/* cu8 over TCP: connect and hand back a stdio stream (what net_support.h:15-44 offers the reference). */
+static FILE *open_tcp(const char *hostport)
+{
+    char host[256];
+    const char *colon = strrchr(hostport, ':');
+    if (!colon || colon == hostport || (size_t)(colon - hostport) >= sizeof host) { fprintf(stderr, "rtl_wmbus_hip: -T needs host:port\n"); return NULL; }
+    memcpy(host, hostport, (size_t)(colon - hostport)); host[colon - hostport] = 0;
+    struct addrinfo hints, *res = NULL;
+    memset(&hints, 0, sizeof hints);
+    hints.ai_family = AF_UNSPEC; hints.ai_socktype = SOCK_STREAM;
+    if (getaddrinfo(host, colon + 1, &hints, &res) || !res) { fprintf(stderr, "rtl_wmbus_hip: cannot resolve %s\n", hostport); return NULL; }
+    int fd = -1;
+    for (struct addrinfo *a = res; a; a = a->ai_next) {
+        fd = socket(a->ai_family, a->ai_socktype, a->ai_protocol);
+        if (fd < 0) continue;
+        if (!connect(fd, a->ai_addr, a->ai_addrlen)) break;
+        close(fd); fd = -1;
+    }
+    freeaddrinfo(res);
+    if (fd < 0) { fprintf(stderr, "rtl_wmbus_hip: cannot connect to %s\n", hostport); return NULL; }
+    return fdopen(fd, "rb");
+}
+
+/* ---- batch mode ------------------------------------------------------------------------------ */
+struct batch {
+    int n; FILE **f; int *live; size_t push; unsigned char *slab[2]; size_t filled[2];   /* bytes per stream in slab k */
+};
+
+/* Fill slab k: up to `push` bytes (whole 4096-byte blocks) of every file; a file that has ended
+ * contributes mid-scale bytes (no signal).  filled = longest contribution. */
+static void batch_fill(struct batch *b, int k)
+{
+    size_t most = 0;
+    for (int s = 0; s < b->n; s++) {
+        unsigned char *dst = b->slab[k] + (size_t)s * b->push;
+        size_t got = 0;
+        if (b->live[s]) {
+            got = fread(dst, WMBUS_BLOCK_BYTES, b->push / WMBUS_BLOCK_BYTES, b->f[s]) * WMBUS_BLOCK_BYTES;
+            if (got < b->push) b->live[s] = 0;
+        }
+        memset(dst + got, 128, b->push - got);
+        if (got > most) most = got;
+    }
+    b->filled[k] = most;
+}
+
+struct fill_job { struct batch *b; int k; };
+static void *fill_thread(void *p) { struct fill_job *j = p; batch_fill(j->b, j->k); return NULL; }
+
+static int run_batch(wmbus_cfg cfg, int n, char **names)
+{
+    struct batch b;
+    memset(&b, 0, sizeof b);
+    b.n = n; b.push = cfg.max_push_bytes;
+    b.f = calloc((size_t)n, sizeof *b.f); b.live = calloc((size_t)n, sizeof *b.live);
+    for (int s = 0; s < n; s++) {
+        b.f[s] = fopen(names[s], "rb");
+        if (!b.f[s]) { fprintf(stderr, "rtl_wmbus_hip: cannot open %s\n", names[s]); return EXIT_FAILURE; }
+        b.live[s] = 1;
+    }
+    cfg.n_streams = (unsigned)n;
+    wmbus_ctx *ctx = NULL;
+    if (wmbus_open(&cfg, &ctx)) {
+        fprintf(stderr, "rtl_wmbus_hip: cannot open GPU back end: %s\n", ctx ? wmbus_last_error(ctx) : "out of memory");
+        wmbus_close(ctx);
+        return EXIT_FAILURE;
+    }
+    for (int k = 0; k < 2; k++) {
+        b.slab[k] = wmbus_alloc_pinned((size_t)n * b.push);
+        if (!b.slab[k]) { fprintf(stderr, "rtl_wmbus_hip: cannot allocate pinned staging\n"); return EXIT_FAILURE; }
+    }
+    int rc = 0, cur = 0;
+    batch_fill(&b, cur);
+    while (b.filled[cur] && !rc) {
+        pthread_t th;
+        struct fill_job job = {&b, cur ^ 1};
+        pthread_create(&th, NULL, fill_thread, &job);            /* next slab while the GPU works */
+        const size_t nbytes = b.filled[cur];
+        for (int s = 0; s < n && !rc; s++) rc = wmbus_stage(ctx, (unsigned)s, b.slab[cur] + (size_t)s * b.push, nbytes);
+        if (!rc) rc = wmbus_process(ctx, nbytes);
+        if (!rc) rc = wmbus_collect(ctx);
+        if (rc) fprintf(stderr, "rtl_wmbus_hip: %s\n", wmbus_last_error(ctx));
+        else {
+            const wmbus_line *ln = NULL;
+            const size_t nl = wmbus_lines(ctx, &ln);
+            size_t len = 0;
+            const char *text = wmbus_lines_text(ctx, &len);
+            for (size_t i = 0; i < nl; i++) {
+                fputs(names[ln[i].stream], stdout); fputs(": ", stdout);
+                fwrite(text + ln[i].text_off, 1, ln[i].text_len, stdout);
+            }
+            fflush(stdout);
+        }
+        pthread_join(th, NULL);
+        cur ^= 1;
+    }
+    for (int k = 0; k < 2; k++) wmbus_free_pinned(b.slab[k]);
+    for (int s = 0; s < n; s++) fclose(b.f[s]);
+    free(b.f); free(b.live);
+    wmbus_close(ctx);
+    return rc ? EXIT_FAILURE : EXIT_SUCCESS;
 }
 
 static void on_alarm(int signo)
@@ -68,7 +181,8 @@ int main(int argc, char **argv)
     wmbus_default_cfg(&cfg);
     cfg.max_push_bytes = 1u << 20;
     int check_flow = 0, opt;
-    while ((opt = getopt(argc, argv, "ofad:p:r:vVst:B:G:P")) != -1) {
+    const char *tcp = NULL;
+    while ((opt = getopt(argc, argv, "ofad:p:r:vVst:B:G:PT:")) != -1) {
         switch (opt) {
         case 'o': cfg.remove_dc = 1; break;
         case 'f': check_flow = 1; break;
@@ -87,6 +201,7 @@ int main(int argc, char **argv)
         case 'B': cfg.max_push_bytes = (size_t)strtoull(optarg, NULL, 10) / WMBUS_BLOCK_BYTES * WMBUS_BLOCK_BYTES; break;
         case 'G': cfg.device = atoi(optarg); break;
         case 'P': cfg.prefilter = WMBUS_PREFILTER_POLYPHASE; break;
+        case 'T': tcp = optarg; break;
         default: print_usage(argv[0]); return EXIT_FAILURE;
         }
     }
@@ -101,6 +216,11 @@ int main(int argc, char **argv)
         sigaction(SIGALRM, &sa, NULL);
     }
 
+    if (optind < argc) return run_batch(cfg, argc - optind, argv + optind);
+
+    FILE *input = stdin;
+    if (tcp && !(input = open_tcp(tcp))) return EXIT_FAILURE;
+
     wmbus_ctx *ctx = NULL;
     int rc = wmbus_open(&cfg, &ctx);
     if (rc) {
@@ -114,7 +234,7 @@ int main(int argc, char **argv)
     if (!buf) return EXIT_FAILURE;
     for (;;) {
         if (check_flow) alarm(2);
-        const size_t got = fread(buf + fill, WMBUS_BLOCK_BYTES, 1, stdin);   /* whole blocks only */
+        const size_t got = fread(buf + fill, WMBUS_BLOCK_BYTES, 1, input);   /* whole blocks only */
         if (check_flow) alarm(0);
         if (got != 1) break;                                                 /* EOF: partial tail dropped */
         fill += WMBUS_BLOCK_BYTES;

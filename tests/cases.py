@@ -30,6 +30,9 @@ SYNTH_CASES = [
     dict(id="noise_only", seed=109, n=1 << 19, fs=1600, kinds=0, rate=0.0, amp=0.0, flags=["-v"]),
     dict(id="long_frames", seed=110, n=1 << 20, fs=1600, kinds=ALL, rate=30.0, amp=60.0, lmin=150, lmax=250, flags=["-v"]),
     dict(id="t1_only_r0", seed=111, n=1 << 19, fs=1600, kinds=T1, rate=80.0, amp=40.0, flags=["-r", "0", "-v"]),
+    dict(id="all_4800_d6_s", seed=113, n=1 << 21, fs=4800, kinds=ALL, rate=60.0, amp=60.0, tc=325.0, sc=-325.0,
+         flags=["-d", "6", "-s", "-v"]),                     # a rate outside 2..5: the run-time-decimation kernel
+    dict(id="t1c1_8000_d10", seed=114, n=1 << 21, fs=8000, kinds=T1 | C1A | C1B, rate=60.0, amp=60.0, flags=["-d", "10", "-o", "-v"]),
     dict(id="s1_only_t0", seed=112, n=1 << 19, fs=1600, kinds=S1, rate=40.0, amp=40.0, flags=["-t", "0", "-p", "T", "-v"]),
 ]
 

@@ -10,6 +10,7 @@ import pytest
 
 from cases import BUNDLED_CASES, SYNTH_CASES, flags_to_kwargs, flags_to_oracle_opts, synth_case_capture
 from conftest import GOLDEN, SAMPLES
+from cases import S2 as S2_NAME
 
 pytestmark = pytest.mark.gpu
 
@@ -252,6 +253,28 @@ def test_edge_inputs(wm, oracle):
                 compare_chips(rx, ref)
 
 
+@pytest.mark.parametrize("flags", [["-v"], ["-s", "-v"]], ids=lambda f: " ".join(f))
+def test_signal_followed_by_exact_silence_repairs_the_rssi_filter(wm, oracle, flags):
+    """Exact-zero input after a signal: the RSSI EMA decays through ~90 more samples (down to the
+    subnormals) while a 48-sample warm-up from zero is already at zero, so the tile hand-off cannot be
+    certified.  Such tiles are re-run sequentially from the predecessor's exact state: same bytes as
+    the oracle, and the repair path is seen to have run."""
+    sig, _ = wm.synth_capture(seed=77, n_samples=1 << 17, kinds=15, frames_per_s=120.0, amplitude=50.0)
+    parts = [sig[: 37 * 4096], np.full(21 * 4096 + 2 * 977 * 2, 128, np.uint8), sig[37 * 4096: 90 * 4096],
+             np.full(64 * 4096, 127, np.uint8), sig[90 * 4096:]]
+    cu8 = np.concatenate(parts)
+    cu8 = cu8[: cu8.size // 4096 * 4096]
+    ref = oracle.run(cu8, flags_to_oracle_opts(oracle, flags), taps=True, chips=True)
+    kw = flags_to_kwargs(flags)
+    with wm.Receiver(n_streams=1, max_push_bytes=cu8.size, **kw) as rx:
+        assert rx.run(cu8)[0] == ref["text"]
+        assert rx.timing()["ema_retries"] > 0
+        compare_taps(rx, ref)
+        compare_chips(rx, ref)
+    with wm.Receiver(n_streams=1, max_push_bytes=1 << 16, **kw) as rx:          # and across push boundaries
+        assert rx.run(cu8, push_bytes=1 << 16)[0] == ref["text"]
+
+
 def test_partial_tail_and_empty_input(wm, samples):
     cu8 = samples["samples2"]
     with wm.Receiver(n_streams=1, max_push_bytes=4 << 20) as rx:
@@ -269,6 +292,41 @@ def test_cli_is_a_drop_in(wm, samples):
         p = subprocess.run([wm.CLI_PATH] + flags + ["-B", str(1 << 19)], input=cu8.tobytes(), capture_output=True, env=env)
         assert p.returncode == 0, p.stderr
         assert p.stdout.decode() == BUNDLED[f"{name}|{' '.join(flags)}"]
+
+
+def test_cli_batch_mode_and_tcp_input(wm, oracle, samples, tmp_path):
+    """Extensions of the CLI (SURVEY 8(f) ingest side): several cu8 files decoded in lock step on one
+    GPU through double-buffered pinned staging, and cu8 over TCP.  Each file's lines must be exactly
+    what the same capture gives alone (= the reference's stdout)."""
+    import socket, threading
+    env = dict(os.environ, WMBUS_FIXED_TS="1")
+    caps = {"a.cu8": samples["samples2"],
+            "b.cu8": wm.synth_capture(seed=501, n_samples=3 << 18, kinds=15, frames_per_s=80.0)[0],     # longer than a
+            "c.cu8": samples["samples2"][: 150 * 4096 + 17]}                                            # shorter, ragged tail
+    want = {}
+    for name, cu8 in caps.items():
+        cu8.tofile(tmp_path / name)
+        want[name] = oracle.run(cu8, flags_to_oracle_opts(oracle, ["-v"]))["text"]
+    p = subprocess.run([wm.CLI_PATH, "-v", "-B", str(1 << 19)] + list(caps), cwd=tmp_path, capture_output=True, env=env)
+    assert p.returncode == 0, p.stderr
+    got = {name: "" for name in caps}
+    for line in p.stdout.decode().splitlines(True):
+        name, rest = line.split(": ", 1)
+        got[name] += rest
+    assert got == want
+    assert BUNDLED[f"{S2_NAME}|-v"] == want["a.cu8"]
+
+    srv = socket.socket(); srv.bind(("127.0.0.1", 0)); srv.listen(1)
+    port = srv.getsockname()[1]
+
+    def serve():
+        c, _ = srv.accept()
+        c.sendall(samples["samples2"].tobytes()); c.close()
+    th = threading.Thread(target=serve); th.start()
+    p = subprocess.run([wm.CLI_PATH, "-v", "-T", f"127.0.0.1:{port}"], capture_output=True, env=env, stdin=subprocess.DEVNULL)
+    th.join(); srv.close()
+    assert p.returncode == 0, p.stderr
+    assert p.stdout.decode() == want["a.cu8"]
 
 
 def test_full_size_batch_properties(wm):
