@@ -18,7 +18,8 @@
 #define WM_HIST_BYTES   4096u      /* input history kept in front of each push (2048 samples) */
 #define WM_IN_SLACK     256u       /* readable slack behind the staged bytes                  */
 #define WM_K1_HALO      48         /* decimated-sample halo: 45 FIR + 1 discriminator, 48 EMA  */
-#define WM_EMA_WARMUP   48
+#define WM_EMA_WARMUP   32         /* EMA warm-up before a lane's run: trajectories coalesce bitwise within 23
+                                      samples (measured); an uncertified hand-off is repaired exactly, not an error */
 #define WM_K1_TILE2     976        /* K1 tile: tile + halo = 1024 = 256 threads x 4           */
 #define WM_MAX_DECIM    16u        /* staging for d = 16 with -s: 131 KB of the 160 KB LDS */
 

@@ -219,7 +219,7 @@ __device__ __forceinline__ void k1_stage_b(const K1Args &a, const int tid, const
         }
         if (on) {
 #pragma unroll
-            for (int k = 0; k < WM_EMA_WARMUP; k++)
+            for (int k = WM_K1_HALO - WM_EMA_WARMUP; k < WM_K1_HALO; k++)     /* the last WM_EMA_WARMUP halo samples */
                 ema = wm_add(wm_mul(al, mg[k + (k >> 4)]), wm_mul(be, ema));
             head = ema;
             uint32_t pk[4] = {0u, 0u, 0u, 0u};
