@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--warmup-s1", type=int, default=0)
     ap.add_argument("--warmup-t1c1", type=int, default=0)
     ap.add_argument("--contexts", type=int, default=4, help="receiver contexts per GPU (GPU / host-decode overlap)")
-    ap.add_argument("--stagger", type=float, default=-1.0, help="seconds between context starts (-1: a step / contexts)")
+    ap.add_argument("--stagger", type=float, default=0.0, help="seconds between context starts (the contexts' turns in the demodulation kernel stagger them anyway)")
     ap.add_argument("--from-host", action="store_true",
                     help="informational: stage every capture from pinned host memory inside each step (PCIe-inclusive rate; "
                          "the BASELINE metric keeps the input resident in HBM)")
@@ -150,9 +150,9 @@ def main():
     pool = cf.ThreadPoolExecutor(nctx)
 
     def run_ctx(i, k_steps, stagger_s):
-        """K passes of context i over its captures.  Contexts free-run (no barrier between steps) and
-        start a fraction of a step apart, so that one context's host decoding and re-run tails are
-        covered by the other contexts' kernels instead of all contexts idling in lock step."""
+        """K passes of context i over its captures.  Contexts free-run (no barrier between steps), so
+        that one context's host decoding and re-run tails are covered by the other contexts'
+        kernels instead of all contexts idling in lock step."""
         rx, lines, tims = rxs[i], 0, []
         if stagger_s > 0 and i:
             time.sleep(stagger_s * i)
@@ -170,11 +170,9 @@ def main():
         res = list(pool.map(lambda i: run_ctx(i, k_steps, stagger_s), range(nctx)))
         return sum(r[0] for r in res), [r[1] for r in res]
 
-    t_w = time.perf_counter()
     if a.warmup:
         run_steps(a.warmup, 0.0)
-    step_est = (time.perf_counter() - t_w) / max(1, a.warmup) if a.warmup else 0.06
-    stagger = a.stagger if a.stagger >= 0 else step_est / nctx
+    stagger = max(0.0, a.stagger)
 
     def barrier():
         shard.barrier(dist)

@@ -1148,9 +1148,12 @@ __global__ __launch_bounds__(64) void k3_bursts(K3Args a)
     if (!cont) {                                 /* stale record of a re-run segment?         */
         if (k >= min(cnt[seg], cap) || !(base[(uint64_t)seg * cap + k] & 2u)) return;
     }
-    /* chips before / from the hit in this push's chip stream */
+    /* chips before / from the hit in this push's chip stream: the wave sums the segment counts in
+     * parallel (a serial scan of up to 256 dependent loads per wave was most of this kernel's time) */
     uint32_t before = 0, total = 0;
-    for (uint32_t s = 0; s < nseg; s++) { const uint32_t c = min(cnt[s], cap); if (s < seg) before += c; total += c; }
+    for (uint32_t s = ln; s < nseg; s += 64u) { const uint32_t c = min(cnt[s], cap); if (s < seg) before += c; total += c; }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { before += __shfl_xor(before, off); total += __shfl_xor(total, off); }
     const uint32_t chip0 = before + k;
     if (chip0 >= total) return;
     const uint32_t avail = total - chip0;        /* chips from the hit to the end of the push */
