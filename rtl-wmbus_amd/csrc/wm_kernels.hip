@@ -813,7 +813,15 @@ __global__ __launch_bounds__(64) void k2_clock(K2Args a)
         fetch_x(gx, min(m + 64u, m_last));
         uint32_t bitw, smask;
         clk_block32<DC>(s, c, xrow, bitw, smask);
-        emit_block(m, smask, bitw, false);
+        /* shift-register upkeep, loop-free: at most 8 chips per block, oldest first */
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const bool has = smask != 0u;
+            const uint32_t k = has ? (uint32_t)__ffs((int)smask) - 1u : 0u;
+            smask &= smask - 1u;
+            const uint32_t sr_new = ((s.sr << 1) | ((bitw >> k) & 1u)) & syncm;
+            s.sr = has ? sr_new : s.sr;
+        }
         m += 32;
     };
     if (m < me_full) { fetch_x(gxA, m); fetch_x(gxB, min(m + 32u, m_last)); }
