@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--from-host", action="store_true",
                     help="informational: stage every capture from pinned host memory inside each step (PCIe-inclusive rate; "
                          "the BASELINE metric keeps the input resident in HBM)")
+    ap.add_argument("--host-threads", type=int, default=0, help="packet-decoder threads per context (0: cores / (ranks x contexts), at most 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     return ap.parse_args()
@@ -128,7 +129,7 @@ def main():
     t_h2d = time.perf_counter()
     for i in range(nctx):
         # host decoder threads: share the box fairly between the ranks of a node and their contexts
-        host_threads = max(2, min(16, (os.cpu_count() or 16) // max(1, world * nctx)))
+        host_threads = a.host_threads or max(2, min(32, (os.cpu_count() or 16) // max(1, world * nctx)))
         rx = wm.Receiver(n_streams=per_ctx[i], max_push_bytes=push_bytes, device=local, seg_len=a.seg_len, rla_seg_len=a.rla_seg_len,
                          warmup_s1=a.warmup_s1, warmup_t1c1=a.warmup_t1c1, show_algorithm=True, fixed_timestamp=True,
                          host_threads=host_threads)

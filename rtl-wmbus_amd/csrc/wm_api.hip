@@ -15,6 +15,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -29,6 +32,67 @@ namespace {
 
 struct LineRec {
     uint64_t sample; uint32_t stream; uint8_t chain, algo, crc_ok; uint32_t seq; std::string text;
+};
+
+/* Persistent host worker pool of a context (packet decoders): run(n, f) executes f(0..n-1) on the
+ * workers and the caller; threads are created once, not per push. */
+class WorkerPool {
+public:
+    explicit WorkerPool(unsigned n_workers)
+    {
+        for (unsigned i = 0; i < n_workers; i++) th_.emplace_back([this] { loop(); });
+    }
+    ~WorkerPool()
+    {
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    unsigned size() const { return (unsigned)th_.size(); }
+    template <typename F> void run(unsigned n, F &&f)
+    {
+        std::function<void(unsigned)> fn = f;
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            job_ = &fn; next_ = 0; total_ = n; done_ = 0; gen_++;
+        }
+        cv_.notify_all();
+        work(fn);                                            /* the caller helps */
+        std::unique_lock<std::mutex> lk(m_);
+        cv_done_.wait(lk, [&] { return done_ == total_; });
+        job_ = nullptr;
+    }
+private:
+    void work(const std::function<void(unsigned)> &fn)
+    {
+        for (;;) {
+            unsigned i;
+            { std::lock_guard<std::mutex> lk(m_); if (next_ >= total_) return; i = next_++; }
+            fn(i);
+            { std::lock_guard<std::mutex> lk(m_); if (++done_ == total_) cv_done_.notify_all(); }
+        }
+    }
+    void loop()
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(unsigned)> *fn;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || (gen_ != seen && job_ != nullptr); });
+                if (stop_) return;
+                seen = gen_; fn = job_;
+            }
+            work(*fn);
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_, cv_done_;
+    const std::function<void(unsigned)> *job_ = nullptr;
+    unsigned next_ = 0, total_ = 0, done_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
 };
 
 struct HostDecoder {           /* persistent across pushes */
@@ -64,6 +128,7 @@ struct wmbus_ctx {
     WmBurstHdr *h_hdr = nullptr; uint32_t *h_words = nullptr; uint32_t *h_pending = nullptr;
     uint32_t n_hdr = 0, n_words = 0;
     std::vector<HostDecoder> decs;                      /* [stream][chain][algo] */
+    std::unique_ptr<WorkerPool> pool;                   /* packet-decoder workers, created on first use */
     std::vector<wmbus_line> lines; std::string text;
     WmPush last{}; bool have_last = false, in_flight = false;
     wmbus_timing tim{};
@@ -567,22 +632,21 @@ int wmbus_collect(wmbus_ctx *c)
     }), order.end());
     unsigned nt = c->cfg.host_threads ? c->cfg.host_threads : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     if (order.size() < 4096) nt = 1;
-    std::vector<std::vector<LineRec>> parts(nt);
     const char *tsf = c->cfg.fixed_timestamp ? "TS" : nullptr;
-    if (nt == 1) decode_stream_range(c, order, 0, order.size(), parts[0], tsf);
+    /* more pieces than threads (cut at stream boundaries): the decoders' cost per stream is uneven */
+    const unsigned np = nt == 1 ? 1 : 4 * nt;
+    std::vector<std::vector<LineRec>> parts(np);
+    if (np == 1) decode_stream_range(c, order, 0, order.size(), parts[0], tsf);
     else {
-        /* split at stream boundaries */
-        std::vector<size_t> cut(nt + 1, order.size());
+        std::vector<size_t> cut(np + 1, order.size());
         cut[0] = 0;
-        for (unsigned t = 1; t < nt; t++) {
-            size_t p = order.size() * t / nt;
+        for (unsigned t = 1; t < np; t++) {
+            size_t p = order.size() * t / np;
             while (p < order.size() && p > 0 && c->h_hdr[order[p]].stream == c->h_hdr[order[p - 1]].stream) p++;
             cut[t] = std::max(p, cut[t - 1]);
         }
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < nt; t++)
-            th.emplace_back([&, t] { decode_stream_range(c, order, cut[t], cut[t + 1], parts[t], tsf); });
-        for (auto &x : th) x.join();
+        if (!c->pool || c->pool->size() + 1 != nt) c->pool.reset(new WorkerPool(nt - 1));
+        c->pool->run(np, [&](unsigned t) { decode_stream_range(c, order, cut[t], cut[t + 1], parts[t], tsf); });
     }
     /* stdout order of the reference: by completing sample, then T1/C1 before S1, run-length before time2 */
     std::vector<LineRec> all;
