@@ -119,6 +119,7 @@ struct wmbus_ctx {
     uint32_t *d_chips[2] = {}, *d_counts[2] = {};
     void *d_st_start[2] = {}, *d_st_final[2] = {}, *d_st_carry[2] = {};
     uint32_t *d_list = nullptr, *d_scalars = nullptr;   /* scalars: err, n_list, n_hits, n_hdr, n_words */
+    uint32_t *d_ckpt = nullptr; uint32_t nck = 0;       /* clock kernel checkpoints [2][S][nseg_cap][nck][16] */
     uint2 *d_hits = nullptr; uint32_t hits_cap = 0;
     uint32_t *d_pending = nullptr;
     WmBurstHdr *d_hdr = nullptr; uint32_t hdr_cap = 0;
@@ -235,7 +236,7 @@ void wmbus_close(wmbus_ctx *c)
 {
     if (!c) return;
     if (c->stream) hipStreamSynchronize(c->stream);
-    void *dev[] = {c->d_in, c->d_dphi, c->d_rssi, c->d_bits, c->d_lut, c->d_ema_head, c->d_ema_tail, c->d_ema_carry,
+    void *dev[] = {c->d_ckpt, c->d_in, c->d_dphi, c->d_rssi, c->d_bits, c->d_lut, c->d_ema_head, c->d_ema_tail, c->d_ema_carry,
                    c->d_chips[0], c->d_chips[1], c->d_counts[0], c->d_counts[1], c->d_st_start[0], c->d_st_start[1],
                    c->d_st_final[0], c->d_st_final[1], c->d_st_carry[0], c->d_st_carry[1], c->d_list, c->d_scalars,
                    c->d_hits, c->d_pending, c->d_hdr, c->d_words};
@@ -310,6 +311,8 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
         A(hipMalloc(&c->d_st_carry[a], (size_t)rows * stw[a]));
     }
     A(dalloc(&c->d_list, (size_t)rows * std::max(c->nseg_cap[0], c->nseg_cap[1])));
+    c->nck = c->C[1] / WM_CK_SAMPLES ? c->C[1] / WM_CK_SAMPLES - 1 : 0;
+    A(dalloc(&c->d_ckpt, std::max<size_t>(16, (size_t)rows * c->nseg_cap[1] * c->nck * 16)));
     A(dalloc(&c->d_scalars, (size_t)SC_COUNT));
     const uint64_t dec_total = (uint64_t)c->S * c->Mcap;
     c->hdr_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(65536, dec_total / 1024), 1u << 24);
@@ -494,6 +497,7 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
         K2Args k2{};
         k2.g = g; k2.dphi = c->d_dphi; k2.rssi = c->d_rssi; k2.bits = c->d_bits;
         k2.hits = c->d_hits; k2.n_hits = c->d_scalars + SC_NHITS; k2.hits_cap = c->hits_cap; k2.err = c->d_scalars + SC_ERR;
+        k2.ckpt = c->d_ckpt; k2.nck = c->nck;
         {
             K2Args a = k2; a.algo = WMBUS_ALGO_T2A;
             a.chips = c->d_chips[1]; a.counts = c->d_counts[1];

@@ -21,6 +21,7 @@
 #define WM_EMA_WARMUP   32         /* EMA warm-up before a lane's run: trajectories coalesce bitwise within 23
                                       samples (measured); an uncertified hand-off is repaired exactly, not an error */
 #define WM_K1_TILE2     976        /* K1 tile: tile + halo = 1024 = 256 threads x 4           */
+#define WM_CK_SAMPLES   2048       /* clock kernel: distance of the speculative pass's state checkpoints */
 #define WM_MAX_DECIM    16u        /* staging for d = 16 with -s: 131 KB of the 160 KB LDS */
 
 #define WM_CHIP_VAL(w)   ((w) & 0xFFu)

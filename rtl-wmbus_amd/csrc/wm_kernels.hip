@@ -538,6 +538,10 @@ struct K2Args {
     uint2 *hits;               /* access-code hits: {lane | algo<<31, chip index in region}  */
     uint32_t *n_hits; uint32_t hits_cap;
     uint32_t *err;
+    /* checkpoints of the speculative pass, every WM_CK_SAMPLES inside a segment: lane state + chips so
+     * far (16 words each).  A re-run stops at the first checkpoint it reproduces: from there on the
+     * speculative pass had already been on the exact trajectory. */
+    uint32_t *ckpt; uint32_t nck;
 };
 
 __device__ __forceinline__ void record_hit(const K2Args &a, uint32_t lane, uint32_t k)
@@ -886,9 +890,45 @@ __global__ __launch_bounds__(64) void k2_clock(K2Args a)
         if (pend >= 8u) flush8();
         m += 32;
     };
-    while (m < me_full) {
-        main_block(gxA);
-        if (m < me_full) main_block(gxB);
+    uint32_t *ck = a.ckpt + sidx * (uint64_t)a.nck * 16u;
+    for (uint32_t j = 0; m < me_full; j++) {
+        const uint32_t stop = min(me_full, m + (uint32_t)WM_CK_SAMPLES);     /* an even number of blocks, or the end */
+        while (m < stop) {
+            main_block(gxA);
+            if (m < stop) main_block(gxB);
+        }
+        if (m < me_full && j < a.nck) {                  /* interior checkpoint j */
+            uint32_t *q = ck + 16u * j;
+            const uint32_t *sw = (const uint32_t *)&s;
+            if (!rerun) {
+                *(uint4 *)(q) = make_uint4(sw[0], sw[1], sw[2], sw[3]);
+                *(uint4 *)(q + 4) = make_uint4(sw[4], sw[5], sw[6], sw[7]);
+                *(uint4 *)(q + 8) = make_uint4(sw[8], sw[9], sw[10], sw[11]);
+                q[12] = n_fl + pend;
+            } else {
+                bool same = true;
+#pragma unroll
+                for (int i = 0; i < 12; i++) same &= q[i] == sw[i];
+                const uint32_t n1 = n_fl + pend, n0 = q[12];
+                if (same && n1 <= n0) {
+                    /* Back on the speculative pass's trajectory: everything it produced from here on is
+                     * exact already.  My chips replace its first n0; if they are fewer, its tail moves
+                     * down (and its access-code hits are recorded at their new places).  (More chips
+                     * than it had: its tail is partly overwritten -- run on to the segment's end.) */
+                    for (uint32_t i = 0; i < pend; i++) out[n_fl + i] = my_chip[i];
+                    if (n1 < n0) {
+                        const uint32_t total0 = min(a.counts[sidx], cap_t2);
+                        for (uint32_t i = n0; i < total0; i++) {
+                            const uint32_t w = out[i];
+                            out[n1 + (i - n0)] = w;
+                            if ((w & 2u) && t2a) record_hit(a, lane, n1 + (i - n0));
+                        }
+                        a.counts[sidx] = n1 + (total0 - n0);
+                    }
+                    return;
+                }
+            }
+        }
     }
     for (uint32_t bi = (m >> 5) & ~7u; bi < (m >> 5); bi++) bw[bi] = my_bits[bi & 7u];   /* incomplete last group */
     n_out = n_fl + pend;
