@@ -273,8 +273,8 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
     for (int a = 0; a < 2; a++)
         if (c->C[a] < 1024u || c->C[a] > 65536u || (c->C[a] & (c->C[a] - 1)))
             return bail(fail(c, WMBUS_EINVAL, "seg_len / rla_seg_len must be powers of two in [1024, 65536]"));
-    c->cfg.warmup_t1c1 = cfg->warmup_t1c1 ? (cfg->warmup_t1c1 + 31u) & ~31u : 24576u;   /* whole 32-sample blocks */
-    c->cfg.warmup_s1 = cfg->warmup_s1 ? (cfg->warmup_s1 + 31u) & ~31u : 49152u;
+    c->cfg.warmup_t1c1 = cfg->warmup_t1c1 ? (cfg->warmup_t1c1 + 31u) & ~31u : 12288u;   /* whole 32-sample blocks */
+    c->cfg.warmup_s1 = cfg->warmup_s1 ? (cfg->warmup_s1 + 31u) & ~31u : 24576u;
     c->cfg.rla_lookback = cfg->rla_lookback ? (cfg->rla_lookback + 31u) & ~31u : 1024u;
     c->flags = (cfg->simultaneous ? WM_F_SHIFT : 0) | (cfg->accurate_atan ? WM_F_ACCURATE : 0) | (cfg->remove_dc ? WM_F_DC : 0) |
                (cfg->t1c1_enabled ? WM_F_T1C1 : 0) | (cfg->s1_enabled ? WM_F_S1 : 0) | (cfg->rla_enabled ? WM_F_RLA : 0) |
