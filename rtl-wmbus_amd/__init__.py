@@ -14,7 +14,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libwmbus_hip.so")
+LIB_PATH = os.environ.get("WMBUS_HIP_LIB") or os.path.join(HERE, "libwmbus_hip.so")   # override: A/B of two builds
 SYNTH_PATH = os.path.join(HERE, "libwmbus_synth.so")
 CLI_PATH = os.path.join(HERE, "rtl_wmbus_hip")
 

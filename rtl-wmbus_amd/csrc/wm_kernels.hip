@@ -140,90 +140,102 @@ __device__ __forceinline__ void k1_boxcars(const uint32_t *w, int d_rt, wm_s2 s8
  * moving-average and the polyphase front ends.  Rows: element a of a discriminator row at word
  * a + 4, of a magnitude row at a + a/16 (the two chains' rows may alias when they carry the same
  * data).  Ends with the magnitude rows' barrier already passed by every thread. */
+__device__ __forceinline__ void k1_fir_t(const K1Args &a, const float *yDrT, const int slot, const int stream, const int ts, const int tn)
+{
+    const WmPush &g = a.g;
+    const int m0l = 4 * slot;
+    if (m0l >= tn) return;
+    float w[16];                                              /* w[i] = element 4 slot + 36 + i */
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float4 v = *(const float4 *)(yDrT + 4 * slot + 40 + 4 * k);
+        w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+    }
+    float acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 11; k++) s = wm_add(s, wm_mul(FIR_T[k], w[12 + j - k]));
+        acc[j] = s;
+    }
+    *(float4 *)(a.dphi + (uint64_t)stream * g.Mcap + (uint64_t)ts + m0l) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
+__device__ __forceinline__ void k1_fir_s(const K1Args &a, const float *yDrS, const int slot, const int stream, const int ts, const int tn)
+{
+    const WmPush &g = a.g;
+    const int m0l = 4 * slot;
+    if (m0l >= tn) return;
+    float w[52];                                              /* w[i] = element 4 slot + i */
+#pragma unroll
+    for (int k = 0; k < 13; k++) {
+        const float4 v = *(const float4 *)(yDrS + 4 * slot + 4 + 4 * k);
+        w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+    }
+    float acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 46; k++) s = wm_add(s, wm_mul(FIR_S[k], w[48 + j - k]));
+        acc[j] = s;
+    }
+    *(float4 *)(a.dphi + ((uint64_t)g.S + stream) * g.Mcap + (uint64_t)ts + m0l) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
+/* Stages B1 (FIR low-pass, y[n] = sum_k b[k] x[n-k], k ascending, fir.h:48-72) and B2 (RSSI EMA,
+ * rtl_wmbus.c:475-495, + hand-off certification) of a 976-sample tile; shared by the moving-average
+ * and the polyphase front ends.  Rows: element a of a discriminator row at word a + 4, of a
+ * magnitude row at a + a/16 (the two chains' rows may alias when they carry the same data).
+ * Work split: waves 0 and 1 run one chain's EMA each (16 samples per lane behind the warm-up) and
+ * the 11-tap FIR of half the tile; waves 2 and 3 the 46-tap FIR of half the tile each -- 630 against
+ * 860 instructions, instead of 960 on the EMA waves and 530 on the others. */
 __device__ __forceinline__ void k1_stage_b(const K1Args &a, const int tid, const int tile, const int stream, const int ts, const int tn,
                                            const bool chT, const bool chS, const float *yDrT, const float *yDrS,
                                            const float *yMgT, const float *yMgS, float *sFin, float *sHead)
 {
     constexpr int T = WM_K1_TILE2;
     const WmPush &g = a.g;
-    /* ---- stage B1: FIR low-pass, y[n] = sum_k b[k] x[n-k], k ascending (fir.h:48-72) ---------- */
-    {
-        const int m0l = 4 * tid;
-        const uint64_t row = (uint64_t)stream * g.Mcap + (uint64_t)ts + m0l;
-        if (chT && m0l < tn) {
-            float w[16];                                      /* w[i] = element 4 tid + 36 + i */
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const float4 v = *(const float4 *)(yDrT + 4 * tid + 40 + 4 * k);
-                w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
-            }
-            float acc[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                float s = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 11; k++) s = wm_add(s, wm_mul(FIR_T[k], w[12 + j - k]));
-                acc[j] = s;
-            }
-            *(float4 *)(a.dphi + row) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        }
-        if (chS && m0l < tn) {
-            float w[52];                                      /* w[i] = element 4 tid + i */
-#pragma unroll
-            for (int k = 0; k < 13; k++) {
-                const float4 v = *(const float4 *)(yDrS + 4 * tid + 4 + 4 * k);
-                w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
-            }
-            float acc[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                float s = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 46; k++) s = wm_add(s, wm_mul(FIR_S[k], w[48 + j - k]));
-                acc[j] = s;
-            }
-            *(float4 *)(a.dphi + (uint64_t)g.S * g.Mcap + row) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        }
-    }
-
     __syncthreads();                                          /* magnitude rows complete */
-
-    /* ---- stage B2: RSSI = EMA(|s|), alpha = 0.6789 (rtl_wmbus.c:475-495) --------------------- */
-    {
-        const int ch = tid >> 6, e = tid & 63;               /* wave 0: T1/C1, wave 1: S1 */
-        const bool on = ch < 2 && (ch ? chS : chT) && 16 * e < T;
-        const float *mg = (ch ? yMgS : yMgT) + 17 * e;        /* element 16 e + kk at 17 e + kk + kk/16 */
-        const float al = 0.6789f, be = wm_sub(1.0f, 0.6789f);
-        const int m0l = 16 * e;
-        float ema = 0.0f, tail = 0.0f, head = 0.0f;
-        const uint64_t row = (uint64_t)ch * g.S + stream;
-        const uint64_t ti = row * a.ntiles + tile;
-        if (a.relist != nullptr) {
-            /* REPAIR: a hand-off of this tile could not be certified (e.g. exact-zero input after a
-             * signal: the true state decays through 90 more samples while a 48-sample warm-up from
-             * zero is already at zero).  One lane per chain runs the whole tile sequentially from the
-             * predecessor's exact tail -- slow, exact, and only for the listed tiles. */
-            if (on && e == 0) {
-                const float *mrow = ch ? yMgS : yMgT;
-                ema = tile ? a.ema_tail[ti - 1] : a.ema_carry[row];
-                head = ema;
-                uint8_t *o = a.rssi + row * g.Mcap + ts;
-                for (int m = 0; m < tn; m++) {
-                    const int el = WM_K1_HALO + m;
-                    ema = wm_add(wm_mul(al, mrow[el + (el >> 4)]), wm_mul(be, ema));
-                    o[m] = (uint8_t)((uint32_t)ema & 0xFFu);
-                }
-                a.ema_head[ti] = head; a.ema_tail[ti] = ema;
+    const int wv = tid >> 6, e = tid & 63;
+    const int ch = wv & 1;                                    /* EMA chain of waves 0, 1 */
+    const bool on = wv < 2 && (ch ? chS : chT) && 16 * e < T;
+    const float al = 0.6789f, be = wm_sub(1.0f, 0.6789f);
+    const int m0l = 16 * e;
+    const uint64_t row = (uint64_t)ch * g.S + stream;
+    const uint64_t ti = row * a.ntiles + tile;
+    if (a.relist != nullptr) {
+        /* REPAIR: a hand-off of this tile could not be certified (e.g. exact-zero input after a
+         * signal: the true state decays through 90 more samples while a warm-up from zero is already
+         * at zero).  One lane per chain runs the whole tile sequentially from the predecessor's exact
+         * tail -- slow, exact, and only for the listed tiles. */
+        if (chT) k1_fir_t(a, yDrT, tid, stream, ts, tn);
+        if (chS) k1_fir_s(a, yDrS, tid, stream, ts, tn);
+        if (on && e == 0) {
+            const float *mrow = ch ? yMgS : yMgT;
+            float ema = tile ? a.ema_tail[ti - 1] : a.ema_carry[row];
+            const float head = ema;
+            uint8_t *o = a.rssi + row * g.Mcap + ts;
+            for (int m = 0; m < tn; m++) {
+                const int el = WM_K1_HALO + m;
+                ema = wm_add(wm_mul(al, mrow[el + (el >> 4)]), wm_mul(be, ema));
+                o[m] = (uint8_t)((uint32_t)ema & 0xFFu);
             }
-            return;
+            a.ema_head[ti] = head; a.ema_tail[ti] = ema;
         }
+        return;
+    }
+    float ema = 0.0f, tail = 0.0f, head = 0.0f;
+    if (wv < 2) {
         if (on) {
+            const float *mg = (ch ? yMgS : yMgT) + 17 * e;    /* element 16 e + kk at 17 e + kk + kk/16 */
 #pragma unroll
             for (int k = WM_K1_HALO - WM_EMA_WARMUP; k < WM_K1_HALO; k++)     /* the last WM_EMA_WARMUP halo samples */
                 ema = wm_add(wm_mul(al, mg[k + (k >> 4)]), wm_mul(be, ema));
             head = ema;
             uint32_t pk[4] = {0u, 0u, 0u, 0u};
-            if (tn == T) {                                    /* full tile: the tail is lane 63's last value */
+            if (tn == T) {                                    /* full tile: the tail is lane 60's last value */
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
                     ema = wm_add(wm_mul(al, mg[WM_K1_HALO + k + ((WM_K1_HALO + k) >> 4)]), wm_mul(be, ema));
@@ -242,15 +254,19 @@ __device__ __forceinline__ void k1_stage_b(const K1Args &a, const int tid, const
                 *(uint4 *)(a.rssi + row * g.Mcap + ts + m0l) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
             sFin[tid] = ema; sHead[tid] = head;
         }
-        __syncthreads();
-        /* certify: a lane's warm-up must have landed exactly on its predecessor's trajectory; a tile
-         * with an uncertified lane publishes a head that cannot match (NaN) and is repaired */
-        const bool bad = on && e > 0 && m0l < tn && wm_f2u(head) != wm_f2u(sFin[tid - 1]);
-        const unsigned long long badT = __ballot(bad);        /* waves 0 and 1 are the two chains */
-        if (on) {
-            if (e == 0) a.ema_head[ti] = badT ? wm_u2f(0x7FC00000u) : head;
-            if (m0l <= tn - 1 && tn - 1 < m0l + 16) a.ema_tail[ti] = tail;
-        }
+        if (chT) { k1_fir_t(a, yDrT, 128 * wv + e, stream, ts, tn); k1_fir_t(a, yDrT, 128 * wv + 64 + e, stream, ts, tn); }
+    } else if (chS) {
+        k1_fir_s(a, yDrS, 128 * (wv - 2) + e, stream, ts, tn);
+        k1_fir_s(a, yDrS, 128 * (wv - 2) + 64 + e, stream, ts, tn);
+    }
+    __syncthreads();
+    /* certify: a lane's warm-up must have landed exactly on its predecessor's trajectory; a tile
+     * with an uncertified lane publishes a head that cannot match (NaN) and is repaired */
+    const bool bad = on && e > 0 && m0l < tn && wm_f2u(head) != wm_f2u(sFin[tid - 1]);
+    const unsigned long long badT = __ballot(bad);            /* waves 0 and 1 are the two chains */
+    if (on) {
+        if (e == 0) a.ema_head[ti] = badT ? wm_u2f(0x7FC00000u) : head;
+        if (m0l <= tn - 1 && tn - 1 < m0l + 16) a.ema_tail[ti] = tail;
     }
 }
 
