@@ -360,34 +360,38 @@ __global__ __launch_bounds__(256) void k1_demod2(K1Args a)
         wm_s2 s8[5], s16[5], u8[5], u16[5];
         k1_boxcars<D>(stgT + 4 * c * d, d, s8, SHIFT ? u16 : s16);
         if (SHIFT) k1_boxcars<D>(stgS + 4 * c * d, d, u8, s16);
-        float drT[4], drS[4];
-        if (chT) {
-            float pi_ = (float)s8[0].x, pq_ = (float)s8[0].y;
+        /* the eight arctangents of a thread (4 samples x 2 chains) are independent: computed in one
+         * straight-line region (the accurate / -a choice hoisted out of the loops), the scheduler
+         * interleaves their dependent chains */
+        float drT[4], drS[4], fT[5][2], fS[5][2];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const float i = (float)s8[j + 1].x, q = (float)s8[j + 1].y;       /* 8 x the reference's i, q */
-                drT[j] = accurate ? wm_discriminator_tab(i, q, pi_, pq_, tab)
-                                  : wm_mul(wm_discriminator_fast(i, q, pi_, pq_), 0.015625f);
-                mgT[j] = wm_mul(wm_sqrt_dom(wm_add(wm_mul(i, i), wm_mul(q, q))), 0.125f);
-                pi_ = i; pq_ = q;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; j++) drT[j] = mgT[j] = 0.0f;
+        for (int j = 0; j < 5; j++) {
+            fT[j][0] = (float)s8[j].x; fT[j][1] = (float)s8[j].y;          /* 8 x the reference's i, q */
+            fS[j][0] = (float)s16[j].x; fS[j][1] = (float)s16[j].y;       /* 16 x */
         }
-        if (chS) {
-            float pi_ = (float)s16[0].x, pq_ = (float)s16[0].y;
+        if (accurate && chT && chS) {                        /* default switches: no branch between the eight */
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const float i = (float)s16[j + 1].x, q = (float)s16[j + 1].y;     /* 16 x the reference's i, q */
-                drS[j] = accurate ? wm_discriminator_tab(i, q, pi_, pq_, tab)
-                                  : wm_mul(wm_discriminator_fast(i, q, pi_, pq_), 0.00390625f);
-                mgS[j] = wm_mul(wm_sqrt_dom(wm_add(wm_mul(i, i), wm_mul(q, q))), 0.0625f);
-                pi_ = i; pq_ = q;
+                drT[j] = wm_discriminator_tab(fT[j + 1][0], fT[j + 1][1], fT[j][0], fT[j][1], tab);
+                drS[j] = wm_discriminator_tab(fS[j + 1][0], fS[j + 1][1], fS[j][0], fS[j][1], tab);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float iT = fT[j + 1][0], qT = fT[j + 1][1], iS = fS[j + 1][0], qS = fS[j + 1][1];
+                mgT[j] = wm_mul(wm_sqrt_dom(wm_add(wm_mul(iT, iT), wm_mul(qT, qT))), 0.125f);
+                mgS[j] = wm_mul(wm_sqrt_dom(wm_add(wm_mul(iS, iS), wm_mul(qS, qS))), 0.0625f);
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; j++) drS[j] = mgS[j] = 0.0f;
+            for (int j = 0; j < 4; j++) {
+                const float iT = fT[j + 1][0], qT = fT[j + 1][1], iS = fS[j + 1][0], qS = fS[j + 1][1];
+                drT[j] = !chT ? 0.0f : accurate ? wm_discriminator_tab(iT, qT, fT[j][0], fT[j][1], tab)
+                                                : wm_mul(wm_discriminator_fast(iT, qT, fT[j][0], fT[j][1]), 0.015625f);
+                drS[j] = !chS ? 0.0f : accurate ? wm_discriminator_tab(iS, qS, fS[j][0], fS[j][1], tab)
+                                                : wm_mul(wm_discriminator_fast(iS, qS, fS[j][0], fS[j][1]), 0.00390625f);
+                mgT[j] = chT ? wm_mul(wm_sqrt_dom(wm_add(wm_mul(iT, iT), wm_mul(qT, qT))), 0.125f) : 0.0f;
+                mgS[j] = chS ? wm_mul(wm_sqrt_dom(wm_add(wm_mul(iS, iS), wm_mul(qS, qS))), 0.0625f) : 0.0f;
+            }
         }
         /* element a of a discriminator row lives at word a + 4 */
         *(float4 *)(yDrT + 4 * c + 4) = make_float4(drT[0], drT[1], drT[2], drT[3]);
