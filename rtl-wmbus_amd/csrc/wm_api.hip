@@ -474,15 +474,17 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
         };
         int rc = launch(0);
         if (rc) return rc;
+        HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+        /* the turn ends with the kernel: the step time of four contexts is four times the time the
+         * turn is held */
+        if (take_turns) { HIPCHK(c, hipEventSynchronize(c->ev[4])); turn.unlock(); }
         /* EMA hand-offs between tiles; an uncertified tile is re-run sequentially from its
          * predecessor's exact tail (which may uncover the next one): exact by construction */
         for (unsigned round = 0;; round++) {
             hipLaunchKernelGGL(k1_verify, dim3((2 * c->S + 63) / 64), dim3(64), 0, c->stream, c->d_ema_head, c->d_ema_tail,
                                c->d_ema_carry, ntiles, 2 * c->S, c->S, c->d_list, c->d_scalars + SC_NLIST);
-            if (round == 0) HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
             HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, SC_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
-            if (turn.owns_lock()) turn.unlock();
             const uint32_t n = c->h_scalars[SC_NLIST];
             if (n == 0) break;
             if (round > ntiles + 1) return fail(c, WMBUS_EDEVICE, "RSSI filter hand-off repair did not converge");

@@ -56,8 +56,8 @@ struct K1Args {
     uint8_t *rssi;           /* [2][S][Mcap] */
     const float *lut_cos;    /* [lut_n]  cosf table, built on the host with the host libm */
     const float *lut_msin;   /* [lut_n]  -sinf table                                      */
-    float *ema_head;         /* [2][S][ntiles] EMA after warm-up (= value at tile_start-1) */
-    float *ema_tail;         /* [2][S][ntiles] EMA after the tile's last valid sample      */
+    float *ema_head;         /* [ntiles][2][S] EMA after warm-up (= value at tile_start-1); tile-major so that */
+    float *ema_tail;         /* [ntiles][2][S] EMA after the tile's last valid sample       k1_verify reads coalesced */
     uint32_t ntiles;
     uint32_t *err;
     /* repair launches: grid.x walks `relist` (stream * ntiles + tile);
@@ -204,7 +204,7 @@ __device__ __forceinline__ void k1_stage_b(const K1Args &a, const int tid, const
     const float al = 0.6789f, be = wm_sub(1.0f, 0.6789f);
     const int m0l = 16 * e;
     const uint64_t row = (uint64_t)ch * g.S + stream;
-    const uint64_t ti = row * a.ntiles + tile;
+    const uint64_t rows = 2ull * g.S, ti = (uint64_t)tile * rows + row;
     if (a.relist != nullptr) {
         /* REPAIR: a hand-off of this tile could not be certified (e.g. exact-zero input after a
          * signal: the true state decays through 90 more samples while a warm-up from zero is already
@@ -214,7 +214,7 @@ __device__ __forceinline__ void k1_stage_b(const K1Args &a, const int tid, const
         if (chS) k1_fir_s(a, yDrS, tid, stream, ts, tn);
         if (on && e == 0) {
             const float *mrow = ch ? yMgS : yMgT;
-            float ema = tile ? a.ema_tail[ti - 1] : a.ema_carry[row];
+            float ema = tile ? a.ema_tail[ti - rows] : a.ema_carry[row];
             const float head = ema;
             uint8_t *o = a.rssi + row * g.Mcap + ts;
             for (int m = 0; m < tn; m++) {
@@ -524,11 +524,11 @@ __global__ void k1_verify(const float *head, const float *tail, const float *car
     if (row >= rows) return;
     float prev = carry[row];
     for (uint32_t t = 0; t < ntiles; t++) {
-        if (wm_f2u(head[(uint64_t)row * ntiles + t]) != wm_f2u(prev)) {
+        if (wm_f2u(head[(uint64_t)t * rows + row]) != wm_f2u(prev)) {
             relist[atomicAdd(n_relist, 1u)] = (row % S) * ntiles + t;
             return;
         }
-        prev = tail[(uint64_t)row * ntiles + t];
+        prev = tail[(uint64_t)t * rows + row];
     }
 }
 
@@ -536,7 +536,7 @@ __global__ void k1_verify(const float *head, const float *tail, const float *car
 __global__ void k1_commit(const float *tail, float *carry, uint32_t ntiles, uint32_t rows)
 {
     const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row < rows) carry[row] = tail[(uint64_t)row * ntiles + ntiles - 1];
+    if (row < rows) carry[row] = tail[(uint64_t)(ntiles - 1) * rows + row];
 }
 
 /* =============================================================================================
