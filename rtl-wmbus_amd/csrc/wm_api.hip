@@ -119,6 +119,7 @@ struct wmbus_ctx {
     uint32_t *d_chips[2] = {}, *d_counts[2] = {};
     void *d_st_start[2] = {}, *d_st_final[2] = {}, *d_st_carry[2] = {};
     uint32_t *d_list = nullptr, *d_scalars = nullptr;   /* scalars: err, n_list, n_hits, n_hdr, n_words */
+    uint32_t *d_first_bad = nullptr;                    /* [2][S] first uncertified EMA tile of a row, or ~0 */
     uint32_t *d_ckpt = nullptr; uint32_t nck = 0;       /* clock kernel checkpoints [2][S][nseg_cap][nck][16] */
     uint2 *d_hits = nullptr; uint32_t hits_cap = 0;
     uint32_t *d_pending = nullptr;
@@ -236,7 +237,7 @@ void wmbus_close(wmbus_ctx *c)
 {
     if (!c) return;
     if (c->stream) hipStreamSynchronize(c->stream);
-    void *dev[] = {c->d_ckpt, c->d_in, c->d_dphi, c->d_rssi, c->d_bits, c->d_lut, c->d_ema_head, c->d_ema_tail, c->d_ema_carry,
+    void *dev[] = {c->d_first_bad, c->d_ckpt, c->d_in, c->d_dphi, c->d_rssi, c->d_bits, c->d_lut, c->d_ema_head, c->d_ema_tail, c->d_ema_carry,
                    c->d_chips[0], c->d_chips[1], c->d_counts[0], c->d_counts[1], c->d_st_start[0], c->d_st_start[1],
                    c->d_st_final[0], c->d_st_final[1], c->d_st_carry[0], c->d_st_carry[1], c->d_list, c->d_scalars,
                    c->d_hits, c->d_pending, c->d_hdr, c->d_words};
@@ -302,6 +303,7 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
     A(dalloc(&c->d_ema_head, (size_t)rows * c->ntiles_cap));
     A(dalloc(&c->d_ema_tail, (size_t)rows * c->ntiles_cap));
     A(dalloc(&c->d_ema_carry, (size_t)rows));
+    A(dalloc(&c->d_first_bad, (size_t)rows));
     const size_t stw[2] = {sizeof(WmRlaState), sizeof(WmClkState)};
     for (int a = 0; a < 2; a++) {
         A(dalloc(&c->d_chips[a], (size_t)rows * c->nseg_cap[a] * c->cap[a]));
@@ -330,6 +332,7 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
 
     /* initial state = the reference's zero-initialised statics */
     A(hipMemsetAsync(c->d_ema_carry, 0, rows * sizeof(float), c->stream));
+    A(hipMemsetAsync(c->d_first_bad, 0xFF, rows * sizeof(uint32_t), c->stream));
     A(hipMemsetAsync(c->d_st_carry[1], 0, rows * sizeof(WmClkState), c->stream));
     {
         std::vector<WmRlaState> init(rows, WmRlaState{0, 8 * 256, 0, 0u, 0u, 0u, 24, 24});   /* rtl_wmbus.c:628-637,717-726 */
@@ -481,8 +484,10 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
         /* EMA hand-offs between tiles; an uncertified tile is re-run sequentially from its
          * predecessor's exact tail (which may uncover the next one): exact by construction */
         for (unsigned round = 0;; round++) {
-            hipLaunchKernelGGL(k1_verify, dim3((2 * c->S + 63) / 64), dim3(64), 0, c->stream, c->d_ema_head, c->d_ema_tail,
-                               c->d_ema_carry, ntiles, 2 * c->S, c->S, c->d_list, c->d_scalars + SC_NLIST);
+            hipLaunchKernelGGL(k1_verify, dim3((2 * c->S + 63) / 64, ntiles), dim3(64), 0, c->stream, c->d_ema_head, c->d_ema_tail,
+                               c->d_ema_carry, ntiles, 2 * c->S, c->d_first_bad);
+            hipLaunchKernelGGL(k1_collect, dim3((2 * c->S + 63) / 64), dim3(64), 0, c->stream, c->d_first_bad, ntiles, 2 * c->S, c->S,
+                               c->d_list, c->d_scalars + SC_NLIST);
             HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, SC_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
             const uint32_t n = c->h_scalars[SC_NLIST];

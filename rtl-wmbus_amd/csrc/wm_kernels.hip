@@ -514,22 +514,25 @@ __global__ __launch_bounds__(256) void k1_demod_ppf(K1Args a)
     k1_stage_b(a, tid, tile, stream, ts, tn, chT, chS, yDr, yDr, yMg, yMg, sFin, sHead);
 }
 
-/* head[tile] must equal tail[tile-1] (or the value carried from the previous push).  The first tile
- * of a row that does not is appended to the repair list; tiles after it cannot be judged before it
- * is repaired.  k1_commit stores the new carries once every row verifies. */
+/* head[tile] must equal tail[tile-1] (or the value carried from the previous push).  One thread
+ * per (tile, row) -- a per-row scan over 2150 tiles is a millisecond of dependent latency -- keeps
+ * the FIRST tile of each row that does not in first_bad[row]; k1_collect turns those into the
+ * repair list (tiles after a bad one cannot be judged before it is repaired). */
 __global__ void k1_verify(const float *head, const float *tail, const float *carry, uint32_t ntiles,
-                          uint32_t rows, uint32_t S, uint32_t *relist, uint32_t *n_relist)
+                          uint32_t rows, uint32_t *first_bad)
 {
-    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;   /* chain*S + stream */
+    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;   /* row = chain*S + stream */
     if (row >= rows) return;
-    float prev = carry[row];
-    for (uint32_t t = 0; t < ntiles; t++) {
-        if (wm_f2u(head[(uint64_t)t * rows + row]) != wm_f2u(prev)) {
-            relist[atomicAdd(n_relist, 1u)] = (row % S) * ntiles + t;
-            return;
-        }
-        prev = tail[(uint64_t)t * rows + row];
-    }
+    const float prev = t ? tail[(uint64_t)(t - 1) * rows + row] : carry[row];
+    if (wm_f2u(head[(uint64_t)t * rows + row]) != wm_f2u(prev)) atomicMin(first_bad + row, t);
+}
+
+__global__ void k1_collect(uint32_t *first_bad, uint32_t ntiles, uint32_t rows, uint32_t S, uint32_t *relist, uint32_t *n_relist)
+{
+    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    const uint32_t t = first_bad[row];
+    if (t < ntiles) { relist[atomicAdd(n_relist, 1u)] = (row % S) * ntiles + t; first_bad[row] = 0xFFFFFFFFu; }
 }
 
 /* every hand-off certified: the last tile's tail becomes the carry of the next push */
