@@ -139,8 +139,9 @@ def main():
     rxs, base = [], 0
     t_h2d = time.perf_counter()
     for i in range(nctx):
-        # host decoder threads: share the box fairly between the ranks of a node and their contexts
-        host_threads = a.host_threads or max(2, min(32, (os.cpu_count() or 16) // max(1, world * nctx)))
+        # host decoder threads: share the box between the ranks of a node and their contexts (2x
+        # oversubscribed: the contexts do not decode at the same time)
+        host_threads = a.host_threads or max(4, min(32, 2 * (os.cpu_count() or 16) // max(1, world * nctx)))
         rx = wm.Receiver(n_streams=per_ctx[i], max_push_bytes=push_bytes, device=local, seg_len=a.seg_len, rla_seg_len=a.rla_seg_len,
                          warmup_s1=a.warmup_s1, warmup_t1c1=a.warmup_t1c1, show_algorithm=True, fixed_timestamp=True,
                          host_threads=host_threads)
