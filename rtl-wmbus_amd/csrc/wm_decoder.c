@@ -49,7 +49,7 @@ uint16_t wm_crc16(const uint8_t *data, size_t n)
     uint16_t crc = 0;
     while (n--) {
         crc ^= (uint16_t)(*data++ << 8);
-        for (int k = 0; k < 8; k++) crc = (uint16_t)((crc & 0x8000u) ? ((crc << 1) ^ 0x3D65u) : (crc << 1));
+        for (int k = 0; k < 8; k++) crc = (uint16_t)((crc & 0x8000u) ? (((unsigned)crc << 1) ^ 0x3D65u) : ((unsigned)crc << 1));
     }
     return (uint16_t)~crc;
 }
