@@ -7,7 +7,8 @@
  *   dphi   f32  [2][S][Mcap]      soft symbol (FIR output), one per decimated sample
  *   rssi   u8   [2][S][Mcap]      (unsigned) of the filtered magnitude
  *   bits   u32  [2][S][Mcap/32]   slicer output, bit j of word w = sample 32w+j
- *   chips  u32  [2][2][S][nseg][cap_a]  per time segment; word = pos16<<16 | rssi<<8 | value
+ *   chips  u32  [2][2][S][nseg][cap_a]  per time segment; word = pos16<<16 | value (bit, sync, reset); the RSSI of
+ *                                       a chip is rssi[row][sample of the chip] (K3 / K4 insert it into bits 15:8)
  *   state arrays, burst arena (see structs below)
  */
 #ifndef WM_DEV_H
@@ -17,7 +18,7 @@
 
 #define WM_HIST_BYTES   4096u      /* input history kept in front of each push (2048 samples) */
 #define WM_IN_SLACK     256u       /* readable slack behind the staged bytes                  */
-#define WM_K1_HALO      48         /* decimated-sample halo: 45 FIR + 1 discriminator, 48 EMA  */
+#define WM_K1_HALO      48         /* decimated-sample halo: 45 FIR + 1 discriminator, >= EMA warm-up */
 #define WM_EMA_WARMUP   32         /* EMA warm-up before a lane's run: trajectories coalesce bitwise within 23
                                       samples (measured); an uncertified hand-off is repaired exactly, not an error */
 #define WM_K1_TILE2     976        /* K1 tile: tile + halo = 1024 = 256 threads x 4           */

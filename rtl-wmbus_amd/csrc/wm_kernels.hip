@@ -1,19 +1,23 @@
 /*
  * wm_kernels.hip -- gfx950 kernels for the rtl-wmbus hot path.
  *
- *   k1_demod     time-parallel front end: cu8 -> [+-325 kHz shift] -> integer boxcars ->
- *                decimate -> polar discriminator (exact fdlibm atan2f) -> FIR low-pass ->
- *                soft symbol; |s| -> EMA -> RSSI byte.          (rtl_wmbus.c:1310-1352,
- *                517-586, 369-392, 475-495, 1066-1067)
- *   k1_verify    certifies the EMA hand-offs between tiles.
+ *   k1_demod2    time-parallel front end, one 976-sample tile per block: cu8 -> [+-325 kHz
+ *                shift] -> integer boxcars -> decimate -> polar discriminator (exact fdlibm
+ *                atan2f) -> FIR low-pass -> soft symbol; |s| -> EMA -> RSSI byte.
+ *                                  (rtl_wmbus.c:1310-1352, 517-586, 369-392, 475-495, 1066-1067)
+ *   k1_demod_ppf the same behind the polyphase pre-filter of ppf.h (option; rtl_wmbus.c:258-294).
+ *   k1_verify / k1_collect / k1_commit   certify the EMA hand-offs between tiles; an uncertified
+ *                tile is repaired by a list launch of k1 (one lane per chain, sequential).
  *   k2_clock     lane = (chain, stream, time segment): DC remover, slicer, squared-signal IIR
  *                band-pass, clock lock, time2 framer.            (rtl_wmbus.c:497-515, 1059,
  *                336-365, 1089-1111, 806-852)
  *   k2_rla       lane = (chain, stream, time segment): run-length framer with deglitch and
  *                bit-length tracking.                            (rtl_wmbus.c:617-803)
  *   k2_verify    compares each segment's start state with its predecessor's end state; a
- *                segment whose speculative start was wrong is re-run from the true state.
- *   k3_*         access-code hit search and burst extraction for the host packet decoders.
+ *                segment whose speculative start was wrong is re-run from the true state (and
+ *                stops at the first checkpoint of the speculative pass it reproduces).
+ *   k3_bursts    access-code hits -> the chips (with their RSSI bytes) a host packet decoder
+ *                consumes.   k4_flatten: debug/parity view of a whole chip stream.
  *
  * Exactness: every float operation the reference performs is performed here in the same order
  * with separate roundings (wm_exact.h; the file is also built with -ffp-contract=off).  The
