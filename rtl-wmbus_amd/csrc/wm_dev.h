@@ -36,6 +36,7 @@
 #define WM_SYNC_S1_MASK   0xFFFFFFu
 #define WM_MAXCHIPS_T1C1  (12u * 290u + 1u)
 #define WM_MAXCHIPS_S1    (16u * 290u + 1u)
+#define WM_RLA_RUN_LIMIT   8192u      /* chips materialised per edge (> WM_MAXCHIPS_*: lossless for the decoders) */
 
 /* Clock-recovery lane state (12 words): IIR history (iir.h:36-45, h1/h2 per section), DC
  * remover (rtl_wmbus.c:497-515), clock lock (rtl_wmbus.c:1043-1044), time2 shift register. */

@@ -1093,7 +1093,7 @@ __global__ __launch_bounds__(64) void k2_rla(K2Args a)
                 D = deglitch_block(W, s1);
             } else {
                 int n = 0;
-                while (s.run > half) {                                                       /* :765-779 / :680-694 */
+                while (s.run > half && n < (int)WM_RLA_RUN_LIMIT) {                          /* :765-779 / :680-694 */
                     s.run -= unit;
                     s.sr = ((s.sr << 1) | level) & syncm;
                     if (emit) {
@@ -1104,6 +1104,15 @@ __global__ __launch_bounds__(64) void k2_rla(K2Args a)
                     }
                     s.state &= ~2u;                        /* reset marker travels with the first chip */
                     n++;
+                }
+                if (s.run > half) {
+                    /* A run of more than WM_RLA_RUN_LIMIT chips (exact silence, then an edge): a packet
+                     * decoder consumes at most 16*290 chips after an access code, and identical chips
+                     * cannot complete one, so the rest of the run need not be materialised -- only
+                     * counted, as the reference's loop would. */
+                    const int k = (s.run - half + unit - 1) / unit;
+                    s.run -= k * unit; n += k;
+                    s.sr = level ? syncm : 0u;
                 }
                 if (!s1) {
                     s.cum += s.run;

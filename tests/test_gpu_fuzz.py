@@ -1,0 +1,91 @@
+"""Randomised configurations of the HIP path against the oracle (seeded, so every run checks the same
+24 cases): decimation 1..8, every switch combination, 1 / 3 / 64 captures per batch, pushes cut at
+random multiples of 4096 bytes, weak and strong signals, stretches of exact silence, the polyphase
+pre-filter where it applies, short segments / warm-ups (forced re-runs).  Text byte-for-byte; chips
+and soft symbols of the last push bit-for-bit for one capture."""
+import numpy as np
+import pytest
+
+from cases import flags_to_kwargs, flags_to_oracle_opts
+
+pytestmark = pytest.mark.gpu
+
+FS = {1: 800, 2: 1600, 3: 2400, 4: 3200, 5: 4000, 6: 4800, 8: 6400}
+
+
+def make_case(k):
+    rng = np.random.default_rng(20260 + k)
+    d = int(rng.choice([1, 2, 2, 2, 3, 4, 5, 6, 8]))
+    flags = ["-v"] if rng.random() < 0.8 else []
+    if d != 2: flags += ["-d", str(d)]
+    simultaneous = rng.random() < 0.3 and d >= 2
+    if simultaneous: flags.append("-s")
+    if rng.random() < 0.3: flags.append("-o")
+    if rng.random() < 0.2: flags.append("-a")
+    if rng.random() < 0.15: flags += ["-r", "0"]
+    elif rng.random() < 0.15: flags += ["-t", "0"]
+    if rng.random() < 0.15: flags += ["-p", "S" if rng.random() < 0.5 else "T"]
+    prefilter = int(d == 2 and not simultaneous and rng.random() < 0.3)
+    n_streams = int(rng.choice([1, 1, 3, 64]))
+    n = int(rng.choice([1 << 17, 1 << 18, 3 << 17])) * (1 if n_streams < 64 else 1)
+    if n_streams == 64: n = 1 << 17
+    push = int(rng.integers(1, 40)) * 4096 if rng.random() < 0.6 else n * 2
+    tune = dict(seg_len=int(rng.choice([1024, 4096, 32768])), rla_seg_len=int(rng.choice([1024, 8192])),
+                warmup_t1c1=int(rng.choice([512, 4096, 12288])), warmup_s1=int(rng.choice([512, 8192, 24576])),
+                rla_lookback=int(rng.choice([64, 256, 1024]))) if rng.random() < 0.5 else {}
+    return dict(k=k, d=d, flags=flags, simultaneous=simultaneous, prefilter=prefilter, n_streams=n_streams, n=n, push=push, tune=tune,
+                amp=float(rng.choice([8.0, 25.0, 60.0])), silence=rng.random() < 0.3, seed=int(rng.integers(1, 1 << 30)))
+
+
+import os
+def truncate_runs(oc, limit=8192):
+    """The run-length kernel materialises at most WM_RLA_RUN_LIMIT chips per edge (a run of identical
+    chips that long only arises from exact silence; no decoder can consume more than 16*290 of them):
+    drop the oracle's chips beyond that from each edge (= same sample index)."""
+    if len(oc) == 0:
+        return oc
+    new_edge = np.concatenate([[True], oc["sample"][1:] != oc["sample"][:-1]])
+    start = np.maximum.accumulate(np.where(new_edge, np.arange(len(oc)), 0))
+    return oc[np.arange(len(oc)) - start < limit]
+
+
+CASES = [make_case(k) for k in range(int(os.environ.get("WMBUS_FUZZ_N", "24")))]      # more for a bug hunt
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c['k']}:d{c['d']}:{' '.join(c['flags'])}:S{c['n_streams']}:P{c['prefilter']}")
+def test_random_configuration_matches_oracle(wm, oracle, case):
+    c = case
+    rng = np.random.default_rng(c["seed"])
+    caps = []
+    for s in range(c["n_streams"]):
+        kw = dict(seed=c["seed"] + s, n_samples=c["n"], fs_khz=FS[c["d"]], kinds=15, frames_per_s=90.0, amplitude=c["amp"])
+        if c["simultaneous"]: kw.update(t1c1_center_khz=325.0, s1_center_khz=-325.0)
+        cu8 = wm.synth_capture(**kw)[0]
+        if c["silence"]:
+            a = int(rng.integers(0, cu8.size // 2)) & ~1
+            cu8[a:a + int(rng.integers(4096, cu8.size // 3))] = int(rng.choice([127, 128]))
+        caps.append(cu8)
+    oo = flags_to_oracle_opts(oracle, c["flags"])
+    oo.prefilter = c["prefilter"]
+    kw = flags_to_kwargs(c["flags"])
+    with wm.Receiver(n_streams=c["n_streams"], max_push_bytes=max(c["push"], 4096), prefilter=c["prefilter"], **kw, **c["tune"]) as rx:
+        texts = rx.run(caps, push_bytes=c["push"])
+        s = c["n_streams"] - 1
+        ref = oracle.run(caps[s], oo, taps=True, chips=True)
+        total = caps[s].size // 4096 * 4096
+        last = (total - 1) // c["push"] * c["push"] if c["push"] < total else 0      # byte offset of the last push
+        m_first = (last // 2) // c["d"]                                                # decimated samples before it
+        chains = [ch for ch, on in ((0, kw.get("t1c1", True)), (1, kw.get("s1", True))) if on]
+        algos = [al for al, on in ((0, kw.get("rla", True)), (1, kw.get("time2", True))) if on]
+        for ch in chains:
+            d = rx.read_tap("dphi", ch, s, ref["m"] - m_first)
+            assert np.array_equal(d.view(np.uint32), ref["dphi_fir"][ch][m_first:].view(np.uint32)), ("dphi", ch)
+            for al in algos:
+                w, pos = rx.read_chips(ch, al, s)
+                oc = ref["chips"][(ref["chips"]["chain"] == ch) & (ref["chips"]["algo"] == al) & (ref["chips"]["sample"] >= m_first)]
+                oc = truncate_runs(oc)
+                assert len(w) == len(oc), ("chips", ch, al)
+                assert np.array_equal(w & 0xFF, oc["value"]) and np.array_equal((w >> 8) & 0xFF, oc["rssi"]) and np.array_equal(pos, oc["sample"])
+    for s in range(c["n_streams"]):
+        want = ref["text"] if s == c["n_streams"] - 1 else oracle.run(caps[s], oo)["text"]
+        assert texts[s] == want, s

@@ -275,6 +275,20 @@ def test_signal_followed_by_exact_silence_repairs_the_rssi_filter(wm, oracle, fl
         assert rx.run(cu8, push_bytes=1 << 16)[0] == ref["text"]
 
 
+def test_very_long_exact_silence_does_not_overflow_the_chip_regions(wm, oracle):
+    """A run of identical chips as long as the silence before it ends at one edge (the reference's
+    loop emits them all: 131 072 chips after a million silent samples).  The kernel materialises
+    8192 per edge -- more than any decoder consumes after an access code -- and counts the rest;
+    datagrams and RSSI are unaffected and nothing overflows."""
+    sig, _ = wm.synth_capture(seed=91, n_samples=1 << 18, kinds=15, frames_per_s=120.0, amplitude=50.0)
+    cu8 = np.concatenate([sig[: 1 << 17], np.full(1 << 21, 128, np.uint8), sig[1 << 17:]])
+    for flags in (["-v"], ["-p", "T", "-v"]):
+        want = oracle.run(cu8, flags_to_oracle_opts(oracle, flags))["text"]
+        with wm.Receiver(n_streams=1, max_push_bytes=1 << 20, **flags_to_kwargs(flags)) as rx:
+            assert rx.run(cu8, push_bytes=1 << 20)[0] == want
+        assert len(want.splitlines()) >= 2
+
+
 def test_partial_tail_and_empty_input(wm, samples):
     cu8 = samples["samples2"]
     with wm.Receiver(n_streams=1, max_push_bytes=4 << 20) as rx:
