@@ -119,6 +119,7 @@ struct wmbus_ctx {
     uint32_t *d_chips[2] = {}, *d_counts[2] = {};
     void *d_st_start[2] = {}, *d_st_final[2] = {}, *d_st_carry[2] = {};
     uint32_t *d_list = nullptr, *d_scalars = nullptr;   /* scalars: err, n_list, n_hits, n_hdr, n_words */
+    uint32_t *d_sync_seen[2] = {};                      /* per framer: [2][S][nseg_cap] access-code chip seen in region */
     uint32_t *d_first_bad = nullptr;                    /* [2][S] first uncertified EMA tile of a row, or ~0 */
     uint32_t *d_ckpt = nullptr; uint32_t nck = 0;       /* clock kernel checkpoints [2][S][nseg_cap][nck][16] */
     uint2 *d_hits = nullptr; uint32_t hits_cap = 0;
@@ -237,7 +238,7 @@ void wmbus_close(wmbus_ctx *c)
 {
     if (!c) return;
     if (c->stream) hipStreamSynchronize(c->stream);
-    void *dev[] = {c->d_first_bad, c->d_ckpt, c->d_in, c->d_dphi, c->d_rssi, c->d_bits, c->d_lut, c->d_ema_head, c->d_ema_tail, c->d_ema_carry,
+    void *dev[] = {c->d_sync_seen[0], c->d_sync_seen[1], c->d_first_bad, c->d_ckpt, c->d_in, c->d_dphi, c->d_rssi, c->d_bits, c->d_lut, c->d_ema_head, c->d_ema_tail, c->d_ema_carry,
                    c->d_chips[0], c->d_chips[1], c->d_counts[0], c->d_counts[1], c->d_st_start[0], c->d_st_start[1],
                    c->d_st_final[0], c->d_st_final[1], c->d_st_carry[0], c->d_st_carry[1], c->d_list, c->d_scalars,
                    c->d_hits, c->d_pending, c->d_hdr, c->d_words};
@@ -308,6 +309,7 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
     for (int a = 0; a < 2; a++) {
         A(dalloc(&c->d_chips[a], (size_t)rows * c->nseg_cap[a] * c->cap[a]));
         A(dalloc(&c->d_counts[a], (size_t)rows * c->nseg_cap[a]));
+        A(dalloc(&c->d_sync_seen[a], (size_t)rows * c->nseg_cap[a]));
         A(hipMalloc(&c->d_st_start[a], (size_t)rows * c->nseg_cap[a] * stw[a]));
         A(hipMalloc(&c->d_st_final[a], (size_t)rows * c->nseg_cap[a] * stw[a]));
         A(hipMalloc(&c->d_st_carry[a], (size_t)rows * stw[a]));
@@ -503,18 +505,20 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
         /* K2: clock recovery + time2 framer (also produces the slicer bits the RLA needs) */
         K2Args k2{};
         k2.g = g; k2.dphi = c->d_dphi; k2.rssi = c->d_rssi; k2.bits = c->d_bits;
-        k2.hits = c->d_hits; k2.n_hits = c->d_scalars + SC_NHITS; k2.hits_cap = c->hits_cap; k2.err = c->d_scalars + SC_ERR;
+        k2.err = c->d_scalars + SC_ERR;
+        for (int al = 0; al < 2; al++)
+            HIPCHK(c, hipMemsetAsync(c->d_sync_seen[al], 0, (size_t)2 * c->S * c->nseg_cap[al] * sizeof(uint32_t), c->stream));
         k2.ckpt = c->d_ckpt; k2.nck = c->nck;
         {
             K2Args a = k2; a.algo = WMBUS_ALGO_T2A;
-            a.chips = c->d_chips[1]; a.counts = c->d_counts[1];
+            a.chips = c->d_chips[1]; a.counts = c->d_counts[1]; a.sync_seen = c->d_sync_seen[1];
             a.st_start = c->d_st_start[1]; a.st_final = c->d_st_final[1]; a.st_carry = c->d_st_carry[1];
             rc = run_segments(c, WMBUS_ALGO_T2A, a, &c->tim.clock_ms, &c->tim.clock_reruns);
             if (rc) return rc;
         }
         if (c->flags & WM_F_RLA) {
             K2Args a = k2; a.algo = WMBUS_ALGO_RLA;
-            a.chips = c->d_chips[0]; a.counts = c->d_counts[0];
+            a.chips = c->d_chips[0]; a.counts = c->d_counts[0]; a.sync_seen = c->d_sync_seen[0];
             a.st_start = c->d_st_start[0]; a.st_final = c->d_st_final[0]; a.st_carry = c->d_st_carry[0];
             rc = run_segments(c, WMBUS_ALGO_RLA, a, &c->tim.rla_ms, &c->tim.rla_reruns);
             if (rc) return rc;
@@ -522,8 +526,11 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
             HIPCHK(c, hipMemsetAsync(c->d_counts[0], 0, (size_t)2 * c->S * c->nseg_cap[0] * sizeof(uint32_t), c->stream));
         }
 
-        /* K3: bursts */
+        /* K3: access-code hits of the settled chip streams, then bursts */
         HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
+        hipLaunchKernelGGL(k3_scan, dim3(2u * (g.nseg[0] + g.nseg[1]) * g.S), dim3(64), 0, c->stream, g, c->d_chips[0], c->d_chips[1],
+                           c->d_counts[0], c->d_counts[1], c->d_sync_seen[0], c->d_sync_seen[1], c->d_hits, c->d_scalars + SC_NHITS,
+                           c->hits_cap, c->d_scalars + SC_ERR);
         HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, SC_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         const uint32_t n_hits = std::min(c->h_scalars[SC_NHITS], c->hits_cap);

@@ -561,22 +561,14 @@ struct K2Args {
     void *st_carry;            /* [2][S] exact state carried from the previous push         */
     const uint32_t *list;      /* re-run list of lane ids, or nullptr                       */
     uint32_t n_lanes;
-    uint32_t algo;             /* WMBUS_ALGO_* of this launch (tags the hit records)        */
-    uint2 *hits;               /* access-code hits: {lane | algo<<31, chip index in region}  */
-    uint32_t *n_hits; uint32_t hits_cap;
+    uint32_t algo;             /* WMBUS_ALGO_* of this launch                              */
     uint32_t *err;
+    uint32_t *sync_seen;       /* [2][S][nseg_cap]: set when a pass emitted an access-code chip into the region */
     /* checkpoints of the speculative pass, every WM_CK_SAMPLES inside a segment: lane state + chips so
      * far (16 words each).  A re-run stops at the first checkpoint it reproduces: from there on the
      * speculative pass had already been on the exact trajectory. */
     uint32_t *ckpt; uint32_t nck;
 };
-
-__device__ __forceinline__ void record_hit(const K2Args &a, uint32_t lane, uint32_t k)
-{
-    const uint32_t i = atomicAdd(a.n_hits, 1u);
-    if (i < a.hits_cap) a.hits[i] = make_uint2(lane | (a.algo << 31), k);
-    else atomicOr(a.err, WM_ERR_BURST_OVERFLOW);
-}
 
 __device__ __forceinline__ void lane_decode(const WmPush &g, uint32_t algo, uint32_t lane, uint32_t &ch, uint32_t &stream, uint32_t &seg)
 {
@@ -792,7 +784,7 @@ __global__ __launch_bounds__(64) void k2_clock(K2Args a)
     const uint32_t syncw = ch ? WM_SYNC_S1 : WM_SYNC_T1C1, syncm = ch ? WM_SYNC_S1_MASK : WM_SYNC_T1C1_MASK;
     uint32_t *out = a.chips + sidx * cap_t2;
     uint32_t *bw = a.bits + row * (g.Mcap / 32);
-    uint32_t n_out = 0;
+    uint32_t n_out = 0, saw_sync = 0;
 
     /* chips of one 32-sample block: walk the set bits of the sample mask (ragged tail, shift
      * register upkeep during warm-up) */
@@ -804,8 +796,8 @@ __global__ __launch_bounds__(64) void k2_clock(K2Args a)
             s.sr = ((s.sr << 1) | bit) & syncm;                       /* rtl_wmbus.c:818-828 */
             if (emit && t2a) {
                 const uint32_t val = bit | (s.sr == syncw ? 2u : 0u);
+                saw_sync |= val & 2u;
                 if (n_out < cap_t2) out[n_out] = ((m0 + k - mb) << 16) | val;
-                if (val & 2u) record_hit(a, lane, n_out);
                 n_out++;
             }
         }
@@ -900,8 +892,8 @@ __global__ __launch_bounds__(64) void k2_clock(K2Args a)
             const uint32_t sr_new = ((s.sr << 1) | bit) & syncm;          /* rtl_wmbus.c:818-828 */
             s.sr = has ? sr_new : s.sr;
             const uint32_t val = bit | (sr_new == syncw ? 2u : 0u);
+            saw_sync |= has ? (val & 2u) : 0u;
             my_chip[pend + i] = ((m + k - mb) << 16) | val;                 /* slots beyond the block's chips are rewritten */
-            if (has && (val & 2u) && t2a) record_hit(a, lane, n_fl + pend + (uint32_t)i);
             cnt += has;
         }
         pend += t2a ? cnt : 0u;
@@ -940,7 +932,7 @@ __global__ __launch_bounds__(64) void k2_clock(K2Args a)
                 if (same && n1 <= n0) {
                     /* Back on the speculative pass's trajectory: everything it produced from here on is
                      * exact already.  My chips replace its first n0; if they are fewer, its tail moves
-                     * down (and its access-code hits are recorded at their new places).  (More chips
+                     * down.  (More chips
                      * than it had: its tail is partly overwritten -- run on to the segment's end.) */
                     for (uint32_t i = 0; i < pend; i++) out[n_fl + i] = my_chip[i];
                     if (n1 < n0) {
@@ -948,10 +940,10 @@ __global__ __launch_bounds__(64) void k2_clock(K2Args a)
                         for (uint32_t i = n0; i < total0; i++) {
                             const uint32_t w = out[i];
                             out[n1 + (i - n0)] = w;
-                            if ((w & 2u) && t2a) record_hit(a, lane, n1 + (i - n0));
                         }
                         a.counts[sidx] = n1 + (total0 - n0);
                     }
+                    if (saw_sync) a.sync_seen[sidx] = 1u;       /* the tail's flag, if any, is already set */
                     return;
                 }
             }
@@ -975,6 +967,7 @@ __global__ __launch_bounds__(64) void k2_clock(K2Args a)
     }
     stF[sidx] = s;
     a.counts[sidx] = n_out;
+    if (saw_sync) a.sync_seen[sidx] = 1u;
     if (n_out > cap_t2) atomicOr(a.err, WM_ERR_CHIP_OVERFLOW);
 }
 
@@ -1038,7 +1031,7 @@ __global__ __launch_bounds__(64) void k2_rla(K2Args a)
      * partially written lines do not stay in L2; 4-byte stores (or unaligned 16-byte ones) turn
      * into read-modify-write traffic at the memory side and cost 3 of the kernel's 8.4 ms. */
     uint32_t *my_chip = s_chip + threadIdx.x * WM_RLA_CROW;
-    uint32_t pend = 0, n_fl = 0;                             /* staged chips; chips already in HBM (multiple of 8) */
+    uint32_t pend = 0, n_fl = 0, saw_sync = 0;               /* staged chips; chips already in HBM (multiple of 8) */
     auto flush8 = [&]() {                                    /* the oldest 8 staged words -> HBM */
         uint32_t w[8];
 #pragma unroll
@@ -1098,8 +1091,8 @@ __global__ __launch_bounds__(64) void k2_rla(K2Args a)
                     s.sr = ((s.sr << 1) | level) & syncm;
                     if (emit) {
                         const uint32_t val = level | (s.sr == syncw ? 2u : 0u) | ((s.state & 2u) ? 4u : 0u);
+                        saw_sync |= val & 2u;
                         my_chip[pend] = ((m + k - mb) << 16) | val;
-                        if (val & 2u) record_hit(a, lane, n_fl + pend);
                         if (++pend == 16u) flush8();         /* a long run can emit many chips at one edge */
                     }
                     s.state &= ~2u;                        /* reset marker travels with the first chip */
@@ -1138,6 +1131,7 @@ __global__ __launch_bounds__(64) void k2_rla(K2Args a)
     while (pend) flush8();                               /* last group: the slots beyond n_out are never read */
     stF[sidx] = s;
     a.counts[sidx] = n_out;
+    if (saw_sync) a.sync_seen[sidx] = 1u;
     if (n_out > cap_rl) atomicOr(a.err, WM_ERR_CHIP_OVERFLOW);
 }
 
@@ -1204,6 +1198,39 @@ __device__ uint32_t burst_need(uint32_t chain, uint32_t hb, uint32_t nb)
         L = (L << 1) | (pair == 1u ? 1u : 0u);
     }
     return 16u * full_len_a(L);
+}
+
+/* Access-code hits = chips with the sync flag, collected AFTER both framers have settled (re-runs
+ * included): one wave per (framer, chain, capture, segment) region scans its chips and appends
+ * {lane | algo << 31, chip index}.  (The framer kernels used to append hits as they went; every
+ * re-run then left stale and duplicate records behind, each of which cost a burst copy.)  The
+ * framers only leave a per-region flag "an access-code chip was emitted here by some pass". */
+__global__ __launch_bounds__(64) void k3_scan(WmPush g, const uint32_t *chips0, const uint32_t *chips1, const uint32_t *counts0,
+                                              const uint32_t *counts1, const uint32_t *seen0, const uint32_t *seen1,
+                                              uint2 *hits, uint32_t *n_hits, uint32_t hits_cap, uint32_t *err)
+{
+    const uint32_t n0 = 2u * g.nseg[0] * g.S;                /* run-length lanes first */
+    uint32_t lane = blockIdx.x, algo = 0;
+    if (lane >= n0) { lane -= n0; algo = 1; }
+    if (lane >= 2u * g.nseg[algo] * g.S) return;
+    uint32_t ch, stream, seg;
+    lane_decode(g, algo, lane, ch, stream, seg);
+    if (!(g.flags & (ch ? WM_F_S1 : WM_F_T1C1)) || !(g.flags & (algo ? WM_F_T2A : WM_F_RLA))) return;
+    const uint64_t sidx = ((uint64_t)ch * g.S + stream) * g.nseg_cap[algo] + seg;
+    if (!(algo ? seen1 : seen0)[sidx]) return;               /* no pass emitted an access-code chip here (~98 % of regions) */
+    const uint32_t cap = g.cap[algo], cnt = min((algo ? counts1 : counts0)[sidx], cap);
+    const uint32_t *w = (algo ? chips1 : chips0) + sidx * cap;
+    for (uint32_t k4 = 4u * threadIdx.x; k4 < cnt; k4 += 256u) {        /* regions are 32-byte aligned, cap % 8 == 0 */
+        const uint4 v = *(const uint4 *)(w + k4);
+        const uint32_t q[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++)
+            if (k4 + j < cnt && (q[j] & 2u)) {
+                const uint32_t i = atomicAdd(n_hits, 1u);
+                if (i < hits_cap) hits[i] = make_uint2(lane | (algo << 31), k4 + j);
+                else atomicOr(err, WM_ERR_BURST_OVERFLOW);
+            }
+    }
 }
 
 /* One wave per hit (or per pending continuation). */
