@@ -55,7 +55,7 @@ typedef struct wmbus_cfg {
     int device;                 /* HIP device ordinal                                */
     size_t max_push_bytes;      /* capacity per stream per push, multiple of 4096    */
     /* tuning (0 = default) */
-    unsigned seg_len;           /* clock-recovery time segment, decimated samples (<= 65536) */
+    unsigned seg_len;           /* clock-recovery time segment, decimated samples (power of two, 1024 ... 2^20) */
     unsigned rla_seg_len;       /* run-length framer time segment                    */
     unsigned warmup_t1c1;       /* IIR warm-up before a segment, T1/C1 chain         */
     unsigned warmup_s1;         /* IIR warm-up before a segment, S1 chain            */

@@ -7,7 +7,7 @@
  *   dphi   f32  [2][S][Mcap]      soft symbol (FIR output), one per decimated sample
  *   rssi   u8   [2][S][Mcap]      (unsigned) of the filtered magnitude
  *   bits   u32  [2][S][Mcap/32]   slicer output, bit j of word w = sample 32w+j
- *   chips  u32  [2][2][S][nseg][cap_a]  per time segment; word = pos16<<16 | value (bit, sync, reset); the RSSI of
+ *   chips  u32  [2][2][S][nseg][cap_a]  per time segment; word = pos<<3 | value (bit, sync, reset); the RSSI of
  *                                       a chip is rssi[row][sample of the chip] (K3 / K4 insert it into bits 15:8)
  *   state arrays, burst arena (see structs below)
  */
@@ -25,9 +25,9 @@
 #define WM_CK_SAMPLES   2048       /* clock kernel: distance of the speculative pass's state checkpoints */
 #define WM_MAX_DECIM    16u        /* staging for d = 16 with -s: 131 KB of the 160 KB LDS */
 
-#define WM_CHIP_VAL(w)   ((w) & 0xFFu)
-#define WM_CHIP_RSSI(w)  (((w) >> 8) & 0xFFu)
-#define WM_CHIP_POS(w)   ((w) >> 16)
+#define WM_CHIP_WORD(pos, val) (((pos) << 3) | (val))
+#define WM_CHIP_VAL(w)   ((w) & 7u)
+#define WM_CHIP_POS(w)   ((w) >> 3)
 
 /* Sync words and window lengths (rtl_wmbus.c:97-103; longest frames t1_c1_packet_decoder.h:95). */
 #define WM_SYNC_T1C1      0x543Du

@@ -797,7 +797,7 @@ __global__ __launch_bounds__(64) void k2_clock(K2Args a)
             if (emit && t2a) {
                 const uint32_t val = bit | (s.sr == syncw ? 2u : 0u);
                 saw_sync |= val & 2u;
-                if (n_out < cap_t2) out[n_out] = ((m0 + k - mb) << 16) | val;
+                if (n_out < cap_t2) out[n_out] = WM_CHIP_WORD(m0 + k - mb, val);
                 n_out++;
             }
         }
@@ -893,7 +893,7 @@ __global__ __launch_bounds__(64) void k2_clock(K2Args a)
             s.sr = has ? sr_new : s.sr;
             const uint32_t val = bit | (sr_new == syncw ? 2u : 0u);
             saw_sync |= has ? (val & 2u) : 0u;
-            my_chip[pend + i] = ((m + k - mb) << 16) | val;                 /* slots beyond the block's chips are rewritten */
+            my_chip[pend + i] = WM_CHIP_WORD(m + k - mb, val);                /* slots beyond the block's chips are rewritten */
             cnt += has;
         }
         pend += t2a ? cnt : 0u;
@@ -1092,7 +1092,7 @@ __global__ __launch_bounds__(64) void k2_rla(K2Args a)
                     if (emit) {
                         const uint32_t val = level | (s.sr == syncw ? 2u : 0u) | ((s.state & 2u) ? 4u : 0u);
                         saw_sync |= val & 2u;
-                        my_chip[pend] = ((m + k - mb) << 16) | val;
+                        my_chip[pend] = WM_CHIP_WORD(m + k - mb, val);
                         if (++pend == 16u) flush8();         /* a long run can emit many chips at one edge */
                     }
                     s.state &= ~2u;                        /* reset marker travels with the first chip */
@@ -1318,7 +1318,7 @@ __global__ void k4_flatten(WmPush g, uint32_t algo, const uint32_t *chips, const
         for (uint32_t k = 0; k < c; k++, n++)
             if (n < max_out) {
                 const uint32_t w = chips[(row * g.nseg_cap[algo] + s) * (uint64_t)cap + k];
-                dst[n] = w | ((uint32_t)rssi[row * g.Mcap + s * g.seg_len[algo] + WM_CHIP_POS(w)] << 8);
+                dst[n] = WM_CHIP_VAL(w) | ((uint32_t)rssi[row * g.Mcap + s * g.seg_len[algo] + WM_CHIP_POS(w)] << 8);
                 if (pos) pos[n] = g.m0 + (uint64_t)s * g.seg_len[algo] + WM_CHIP_POS(w);
             }
     }

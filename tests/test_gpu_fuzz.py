@@ -32,7 +32,7 @@ def make_case(k):
     n = int(rng.choice([1 << 17, 1 << 18, 3 << 17])) * (1 if n_streams < 64 else 1)
     if n_streams == 64: n = 1 << 17
     push = int(rng.integers(1, 40)) * 4096 if rng.random() < 0.6 else n * 2
-    tune = dict(seg_len=int(rng.choice([1024, 4096, 32768])), rla_seg_len=int(rng.choice([1024, 8192])),
+    tune = dict(seg_len=int(rng.choice([1024, 4096, 32768, 131072])), rla_seg_len=int(rng.choice([1024, 8192])),
                 warmup_t1c1=int(rng.choice([512, 4096, 12288])), warmup_s1=int(rng.choice([512, 8192, 24576])),
                 rla_lookback=int(rng.choice([64, 256, 1024]))) if rng.random() < 0.5 else {}
     return dict(k=k, d=d, flags=flags, simultaneous=simultaneous, prefilter=prefilter, n_streams=n_streams, n=n, push=push, tune=tune,

@@ -158,12 +158,13 @@ def test_polyphase_prefilter_streams_and_rejects_other_rates(wm, oracle):
         wm.Receiver(n_streams=1, simultaneous=True, prefilter=1)
 
 
-@pytest.mark.parametrize("seg_len,w0,w1,lb", [(4096, 1024, 1024, 64), (8192, 4096, 8192, 256), (65536, 24576, 49152, 1024)])
+@pytest.mark.parametrize("seg_len,w0,w1,lb", [(4096, 1024, 1024, 64), (8192, 4096, 8192, 256), (65536, 24576, 49152, 1024),
+                                               (262144, 12288, 24576, 1024)])
 def test_result_independent_of_segmentation(wm, oracle, samples, seg_len, w0, w1, lb):
     """Short warm-ups force hand-off verification failures: the re-run path must restore exactness."""
     cu8 = samples["samples2"]
     ref = oracle.run(cu8, flags_to_oracle_opts(oracle, ["-v"]), taps=True, chips=True)
-    with wm.Receiver(n_streams=1, max_push_bytes=cu8.size, seg_len=seg_len, rla_seg_len=max(1024, seg_len // 4),
+    with wm.Receiver(n_streams=1, max_push_bytes=cu8.size, seg_len=seg_len, rla_seg_len=min(65536, max(1024, seg_len // 4)),
                      warmup_t1c1=w0, warmup_s1=w1, rla_lookback=lb) as rx:
         text = rx.run(cu8)[0]
         tim = rx.timing()
