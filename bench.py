@@ -111,7 +111,10 @@ def main():
     a = parse()
     shard = importlib.import_module("rtl-wmbus_amd.shard")
     rank, world, local = shard.rank_env()
-    dist = shard.init(world, local)       # imports torch BEFORE the HIP library: one HIP runtime per process
+    # WMBUS_BENCH_BACKEND=gloo WMBUS_BENCH_DEVICE=0: several ranks on ONE GPU, to exercise the N > 1
+    # code path on a single-GPU box (RCCL refuses two ranks on one device); never set by the driver
+    dist = shard.init(world, local, backend=os.environ.get("WMBUS_BENCH_BACKEND"))   # imports torch BEFORE the HIP library
+    local = int(os.environ.get("WMBUS_BENCH_DEVICE", local))
     wm = importlib.import_module("rtl-wmbus_amd")
     if wm.device_count() < 1:
         raise SystemExit("bench.py: no HIP device (the back end has no CPU fallback)")
@@ -243,6 +246,9 @@ def main():
                          "algorithmic_bytes_per_launch": int(BYTES_PER_SAMPLE * samples_per_launch),
                          "avg_launch_ms": round(k1_avg_s * 1e3, 3),
                          "launches_timed": len(alone_ms),
+                         "in_timed_region": {"avg_launch_ms": round(k1_concurrent_ms, 3), "launches": k1_launches,
+                                             "achieved": round(BYTES_PER_SAMPLE * samples_per_launch / max(k1_concurrent_ms, 1e-9) / 1e6, 1),
+                                             "frac": round(BYTES_PER_SAMPLE * samples_per_launch / max(k1_concurrent_ms, 1e-9) / 1e6 / HBM_PEAK_GBPS, 4)},
                          "how": "HIP events around k1_demod2 on the library's stream, one context at a time after the timed "
                                 "region (inside it a launch runs beside the other contexts' kernels: avg %.3f ms each)" % k1_concurrent_ms},
             "stage_ms_last_step": [{k: round(v, 3) if isinstance(v, float) else v for k, v in t.items()} for t in last],

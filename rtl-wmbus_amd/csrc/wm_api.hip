@@ -528,7 +528,7 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
 
         /* K3: access-code hits of the settled chip streams, then bursts */
         HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
-        hipLaunchKernelGGL(k3_scan, dim3(2u * (g.nseg[0] + g.nseg[1]) * g.S), dim3(64), 0, c->stream, g, c->d_chips[0], c->d_chips[1],
+        hipLaunchKernelGGL(k3_scan, dim3((2u * (g.nseg[0] + g.nseg[1]) * g.S + 255u) / 256u), dim3(256), 0, c->stream, g, c->d_chips[0], c->d_chips[1],
                            c->d_counts[0], c->d_counts[1], c->d_sync_seen[0], c->d_sync_seen[1], c->d_hits, c->d_scalars + SC_NHITS,
                            c->hits_cap, c->d_scalars + SC_ERR);
         HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, SC_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));

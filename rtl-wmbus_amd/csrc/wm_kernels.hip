@@ -1201,35 +1201,44 @@ __device__ uint32_t burst_need(uint32_t chain, uint32_t hb, uint32_t nb)
 }
 
 /* Access-code hits = chips with the sync flag, collected AFTER both framers have settled (re-runs
- * included): one wave per (framer, chain, capture, segment) region scans its chips and appends
- * {lane | algo << 31, chip index}.  (The framer kernels used to append hits as they went; every
- * re-run then left stale and duplicate records behind, each of which cost a burst copy.)  The
- * framers only leave a per-region flag "an access-code chip was emitted here by some pass". */
-__global__ __launch_bounds__(64) void k3_scan(WmPush g, const uint32_t *chips0, const uint32_t *chips1, const uint32_t *counts0,
-                                              const uint32_t *counts1, const uint32_t *seen0, const uint32_t *seen1,
-                                              uint2 *hits, uint32_t *n_hits, uint32_t hits_cap, uint32_t *err)
+ * included).  (The framer kernels used to append hits as they went; every re-run then left stale
+ * and duplicate records behind, each of which cost a burst copy.)  The framers only leave a
+ * per-region flag "an access-code chip was emitted here by some pass"; each lane of a wave looks at
+ * the flag of one (framer, chain, capture, segment) region, and the wave then scans the flagged
+ * regions (~2 %) together, appending {lane | algo << 31, chip index}. */
+__global__ __launch_bounds__(256) void k3_scan(WmPush g, const uint32_t *chips0, const uint32_t *chips1, const uint32_t *counts0,
+                                               const uint32_t *counts1, const uint32_t *seen0, const uint32_t *seen1,
+                                               uint2 *hits, uint32_t *n_hits, uint32_t hits_cap, uint32_t *err)
 {
     const uint32_t n0 = 2u * g.nseg[0] * g.S;                /* run-length lanes first */
-    uint32_t lane = blockIdx.x, algo = 0;
+    const uint32_t ln = threadIdx.x & 63u;
+    uint32_t lane = blockIdx.x * 256u + threadIdx.x, algo = 0;
     if (lane >= n0) { lane -= n0; algo = 1; }
-    if (lane >= 2u * g.nseg[algo] * g.S) return;
-    uint32_t ch, stream, seg;
-    lane_decode(g, algo, lane, ch, stream, seg);
-    if (!(g.flags & (ch ? WM_F_S1 : WM_F_T1C1)) || !(g.flags & (algo ? WM_F_T2A : WM_F_RLA))) return;
-    const uint64_t sidx = ((uint64_t)ch * g.S + stream) * g.nseg_cap[algo] + seg;
-    if (!(algo ? seen1 : seen0)[sidx]) return;               /* no pass emitted an access-code chip here (~98 % of regions) */
-    const uint32_t cap = g.cap[algo], cnt = min((algo ? counts1 : counts0)[sidx], cap);
-    const uint32_t *w = (algo ? chips1 : chips0) + sidx * cap;
-    for (uint32_t k4 = 4u * threadIdx.x; k4 < cnt; k4 += 256u) {        /* regions are 32-byte aligned, cap % 8 == 0 */
-        const uint4 v = *(const uint4 *)(w + k4);
-        const uint32_t q[4] = {v.x, v.y, v.z, v.w};
+    uint32_t my_cnt = 0, my_sidx = 0;
+    if (lane < 2u * g.nseg[algo] * g.S) {
+        uint32_t ch, stream, seg;
+        lane_decode(g, algo, lane, ch, stream, seg);
+        const uint32_t sidx = (ch * g.S + stream) * g.nseg_cap[algo] + seg;
+        if ((g.flags & (ch ? WM_F_S1 : WM_F_T1C1)) && (g.flags & (algo ? WM_F_T2A : WM_F_RLA)) && (algo ? seen1 : seen0)[sidx]) {
+            my_sidx = sidx;
+            my_cnt = min((algo ? counts1 : counts0)[sidx], g.cap[algo]);
+        }
+    }
+    for (uint64_t todo = __ballot(my_cnt != 0u); todo; todo &= todo - 1ull) {
+        const int src = __ffsll((long long)todo) - 1;
+        const uint32_t cnt = __shfl(my_cnt, src), sidx = __shfl(my_sidx, src), r_lane = __shfl(lane, src), r_algo = __shfl(algo, src);
+        const uint32_t *w = (r_algo ? chips1 : chips0) + (uint64_t)sidx * g.cap[r_algo];
+        for (uint32_t k4 = 4u * ln; k4 < cnt; k4 += 256u) {             /* regions are 32-byte aligned, cap % 8 == 0 */
+            const uint4 v = *(const uint4 *)(w + k4);
+            const uint32_t q[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (uint32_t j = 0; j < 4; j++)
-            if (k4 + j < cnt && (q[j] & 2u)) {
-                const uint32_t i = atomicAdd(n_hits, 1u);
-                if (i < hits_cap) hits[i] = make_uint2(lane | (algo << 31), k4 + j);
-                else atomicOr(err, WM_ERR_BURST_OVERFLOW);
-            }
+            for (uint32_t j = 0; j < 4; j++)
+                if (k4 + j < cnt && (q[j] & 2u)) {
+                    const uint32_t i = atomicAdd(n_hits, 1u);
+                    if (i < hits_cap) hits[i] = make_uint2(r_lane | (r_algo << 31), k4 + j);
+                    else atomicOr(err, WM_ERR_BURST_OVERFLOW);
+                }
+        }
     }
 }
 

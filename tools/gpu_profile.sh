@@ -5,6 +5,9 @@ mkdir -p gpurun_out/prof; export TMPDIR=/tmp; cd /tmp
 R=$GRAFT_REPO_ROOT
 timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof/trace -o bench --output-format csv -- python $R/bench.py --steps 5 --warmup 1 > $R/gpurun_out/prof/bench_under_rocprof.json 2> $R/gpurun_out/prof/trace.log
 tail -1 $R/gpurun_out/prof/bench_under_rocprof.json | cut -c1-400
+# (1b) the same kernels un-overlapped: one context of 1024 captures, nothing runs beside anything
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof/trace1 -o single --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --contexts 1 --no-cpu-baseline --no-check > $R/gpurun_out/prof/single_context_under_rocprof.json 2> $R/gpurun_out/prof/trace1.log
+tail -1 $R/gpurun_out/prof/single_context_under_rocprof.json | cut -c1-300
 for ctr in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $ctr --kernel-trace --stats -d $R/gpurun_out/prof/pmc_$ctr -o pmc --output-format csv -- python $R/bench.py --steps 1 --warmup 0 --contexts 1 --no-cpu-baseline --no-check > $R/gpurun_out/prof/pmc_$ctr.log 2>&1
   echo "$ctr rc=$?"
