@@ -480,7 +480,7 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
         int rc = launch(0);
         if (rc) return rc;
         HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
-        /* the turn ends with the kernel: the step time of four contexts is four times the time the
+        /* the turn ends with the kernel: the step time of n contexts is n times the time the
          * turn is held */
         if (take_turns) { HIPCHK(c, hipEventSynchronize(c->ev[4])); turn.unlock(); }
         /* EMA hand-offs between tiles; an uncertified tile is re-run sequentially from its
