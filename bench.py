@@ -176,10 +176,15 @@ def main():
             if a.from_host:
                 for s_ in range(per_ctx[i]):
                     rx.stage(s_, host_caps[i][s_])
+            t_a = time.perf_counter()
             rx.process(push_bytes)
+            t_b = time.perf_counter()
             rx.collect()
             lines += rx.lines_count()
-            tims.append(rx.timing())
+            tm = rx.timing()
+            tm["process_wall_ms"] = (t_b - t_a) * 1e3
+            tm["collect_wall_ms"] = (time.perf_counter() - t_b) * 1e3
+            tims.append(tm)
         return lines, tims
 
     def run_steps(k_steps, stagger_s):
@@ -252,6 +257,7 @@ def main():
                          "how": "HIP events around k1_demod2 on the library's stream, one context at a time after the timed "
                                 "region (inside it a launch runs beside the other contexts' kernels: avg %.3f ms each)" % k1_concurrent_ms},
             "stage_ms_last_step": [{k: round(v, 3) if isinstance(v, float) else v for k, v in t.items()} for t in last],
+            "stage_ms_mid_step": [{k: round(v, 3) if isinstance(v, float) else v for k, v in t.items()} for t in tim_acc[a.steps // 2]],
             "setup_s": {"generate": round(t_gen, 1), "alloc_and_h2d": round(t_h2d, 1)},
             "input": "staged from pinned host memory inside every step (PCIe-inclusive, informational)" if a.from_host else "resident in HBM",
         }

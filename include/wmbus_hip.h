@@ -94,6 +94,7 @@ typedef struct wmbus_timing {
     unsigned clock_reruns, rla_reruns, ema_retries;
     uint64_t chips[2][2];       /* chips produced per chain/algo                      */
     uint64_t bursts;            /* candidate bursts handed to the host decoders       */
+    float turn_wait_ms;         /* host time spent waiting for this process's turn in the demodulation kernel */
 } wmbus_timing;
 
 void wmbus_default_cfg(wmbus_cfg *cfg);
@@ -130,7 +131,7 @@ int  wmbus_get_timing(const wmbus_ctx *ctx, wmbus_timing *t);
 long wmbus_read_tap(wmbus_ctx *ctx, const char *what, int chain, unsigned stream,
                     void *dst, size_t max_elems);
 /* All chips of the last push for one stream/chain/algo as u32 words
- * [31:16] offset-in-segment, [15:8] rssi, [7:0] value (bit0 data, bit1 sync, bit2 framer reset
+ * [15:8] rssi, [7:0] value (bit0 data, bit1 sync, bit2 framer reset
  * before this chip); `pos` (optional) receives the global decimated-sample index per chip. */
 long wmbus_read_chips(wmbus_ctx *ctx, int chain, int algo, unsigned stream,
                       uint32_t *dst, uint64_t *pos, size_t max_elems);

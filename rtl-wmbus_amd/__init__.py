@@ -55,11 +55,12 @@ class Timing(ctypes.Structure):
     _fields_ = [("demod_ms", ctypes.c_float), ("clock_ms", ctypes.c_float), ("rla_ms", ctypes.c_float),
                 ("gather_ms", ctypes.c_float), ("d2h_ms", ctypes.c_float), ("gpu_total_ms", ctypes.c_float),
                 ("host_decode_ms", ctypes.c_float), ("clock_reruns", ctypes.c_uint), ("rla_reruns", ctypes.c_uint),
-                ("ema_retries", ctypes.c_uint), ("chips", (ctypes.c_uint64 * 2) * 2), ("bursts", ctypes.c_uint64)]
+                ("ema_retries", ctypes.c_uint), ("chips", (ctypes.c_uint64 * 2) * 2), ("bursts", ctypes.c_uint64),
+                ("turn_wait_ms", ctypes.c_float)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k in ("demod_ms", "clock_ms", "rla_ms", "gather_ms", "d2h_ms", "gpu_total_ms",
-                                              "host_decode_ms", "clock_reruns", "rla_reruns", "ema_retries", "bursts")}
+                                              "host_decode_ms", "clock_reruns", "rla_reruns", "ema_retries", "bursts", "turn_wait_ms")}
 
 
 EXPORTS = ["wmbus_default_cfg", "wmbus_open", "wmbus_close", "wmbus_last_error", "wmbus_stage", "wmbus_device_input",

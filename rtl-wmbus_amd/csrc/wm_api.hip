@@ -106,7 +106,7 @@ struct wmbus_ctx {
     wmbus_cfg cfg{};
     char err[256] = {0};
     hipStream_t stream = nullptr;
-    hipEvent_t ev[8] = {};
+    hipEvent_t ev[9] = {};
     /* geometry */
     uint32_t d = 2, S = 1, C[2] = {8192, 32768}, Mcap = 0, nseg_cap[2] = {0, 0}, ntiles_cap = 0, T = WM_K1_TILE2;
     uint32_t cap[2] = {0, 0}, flags = 0;
@@ -118,6 +118,7 @@ struct wmbus_ctx {
     float *d_ema_head = nullptr, *d_ema_tail = nullptr, *d_ema_carry = nullptr;
     uint32_t *d_chips[2] = {}, *d_counts[2] = {};
     void *d_st_start[2] = {}, *d_st_final[2] = {}, *d_st_carry[2] = {};
+    uint32_t *d_list2 = nullptr;                        /* run-length re-run list of the fused framer launches */
     uint32_t *d_list = nullptr, *d_scalars = nullptr;   /* scalars: err, n_list, n_hits, n_hdr, n_words */
     uint32_t *d_sync_seen[2] = {};                      /* per framer: [2][S][nseg_cap] access-code chip seen in region */
     uint32_t *d_first_bad = nullptr;                    /* [2][S] first uncertified EMA tile of a row, or ~0 */
@@ -152,7 +153,7 @@ int fail(wmbus_ctx *c, int code, const char *fmt, ...)
 
 template <typename T> hipError_t dalloc(T **p, size_t n) { return hipMalloc((void **)p, n * sizeof(T)); }
 
-enum { SC_ERR = 0, SC_NLIST = 1, SC_NHITS = 2, SC_NHDR = 3, SC_NWORDS = 4, SC_COUNT = 8 };
+enum { SC_ERR = 0, SC_NLIST = 1, SC_NHITS = 2, SC_NHDR = 3, SC_NWORDS = 4, SC_NLIST2 = 5, SC_COUNT = 8 };
 
 __global__ void k_roll_history(uint8_t *in, uint64_t stride, uint32_t nbytes)
 {
@@ -238,7 +239,7 @@ void wmbus_close(wmbus_ctx *c)
 {
     if (!c) return;
     if (c->stream) hipStreamSynchronize(c->stream);
-    void *dev[] = {c->d_sync_seen[0], c->d_sync_seen[1], c->d_first_bad, c->d_ckpt, c->d_in, c->d_dphi, c->d_rssi, c->d_bits, c->d_lut, c->d_ema_head, c->d_ema_tail, c->d_ema_carry,
+    void *dev[] = {c->d_list2, c->d_sync_seen[0], c->d_sync_seen[1], c->d_first_bad, c->d_ckpt, c->d_in, c->d_dphi, c->d_rssi, c->d_bits, c->d_lut, c->d_ema_head, c->d_ema_tail, c->d_ema_carry,
                    c->d_chips[0], c->d_chips[1], c->d_counts[0], c->d_counts[1], c->d_st_start[0], c->d_st_start[1],
                    c->d_st_final[0], c->d_st_final[1], c->d_st_carry[0], c->d_st_carry[1], c->d_list, c->d_scalars,
                    c->d_hits, c->d_pending, c->d_hdr, c->d_words};
@@ -270,7 +271,7 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
     if (hipSetDevice(cfg->device) != hipSuccess) return bail(fail(c, WMBUS_EDEVICE, "hipSetDevice(%d) failed", cfg->device));
 
     c->d = cfg->decimation; c->S = cfg->n_streams;
-    c->C[1] = cfg->seg_len ? cfg->seg_len : 65536u;    /* A/B on MI355X: 32768 -4.5 %, 131072 -5 % (too few lanes) */
+    c->C[1] = cfg->seg_len ? cfg->seg_len : 32768u;    /* in-box A/B with the fused framer launches: 65536 -3 %, 16384 -4 % */
     c->C[0] = cfg->rla_seg_len ? cfg->rla_seg_len : 8192u;
     for (int a = 0; a < 2; a++)
         if (c->C[a] < 1024u || c->C[a] > (1u << 20) || (c->C[a] & (c->C[a] - 1)))
@@ -315,6 +316,7 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
         A(hipMalloc(&c->d_st_carry[a], (size_t)rows * stw[a]));
     }
     A(dalloc(&c->d_list, (size_t)rows * std::max(c->nseg_cap[0], c->nseg_cap[1])));
+    A(dalloc(&c->d_list2, (size_t)rows * c->nseg_cap[0]));
     c->nck = c->C[1] / WM_CK_SAMPLES ? c->C[1] / WM_CK_SAMPLES - 1 : 0;
     A(dalloc(&c->d_ckpt, std::max<size_t>(16, (size_t)rows * c->nseg_cap[1] * c->nck * 16)));
     A(dalloc(&c->d_scalars, (size_t)SC_COUNT));
@@ -400,9 +402,9 @@ static int run_segments(wmbus_ctx *c, int algo, K2Args a, float *ms, unsigned *r
     const uint32_t words = (algo == WMBUS_ALGO_RLA ? sizeof(WmRlaState) : sizeof(WmClkState)) / 4;
     auto launch = [&](const uint32_t *list, uint32_t n) {
         a.list = list; a.n_lanes = n;
-        if (algo == WMBUS_ALGO_RLA) hipLaunchKernelGGL(k2_rla, dim3((n + 63) / 64), dim3(64), 0, c->stream, a);
-        else if (c->flags & WM_F_DC) hipLaunchKernelGGL(k2_clock<true>, dim3((n + 63) / 64), dim3(64), 0, c->stream, a);
-        else hipLaunchKernelGGL(k2_clock<false>, dim3((n + 63) / 64), dim3(64), 0, c->stream, a);
+        if (algo == WMBUS_ALGO_RLA) hipLaunchKernelGGL(k2_rla, dim3((n + 64 * WM_RLA_WPB - 1) / (64 * WM_RLA_WPB)), dim3(64 * WM_RLA_WPB), 0, c->stream, a);
+        else if (c->flags & WM_F_DC) hipLaunchKernelGGL(k2_clock<true>, dim3((n + 64 * WM_CLK_WPB - 1) / (64 * WM_CLK_WPB)), dim3(64 * WM_CLK_WPB), 0, c->stream, a);
+        else hipLaunchKernelGGL(k2_clock<false>, dim3((n + 64 * WM_CLK_WPB - 1) / (64 * WM_CLK_WPB)), dim3(64 * WM_CLK_WPB), 0, c->stream, a);
     };
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     launch(nullptr, lanes);
@@ -425,6 +427,55 @@ static int run_segments(wmbus_ctx *c, int algo, K2Args a, float *ms, unsigned *r
     const uint32_t rows = 2u * g.S;
     hipLaunchKernelGGL(k_carry, dim3((rows + 255) / 256), dim3(256), 0, c->stream, (const uint32_t *)a.st_final,
                        (uint32_t *)a.st_carry, words, rows, g.nseg_cap[algo], g.nseg[algo]);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+/* Both framers when the slicer words do not depend on filter state (no DC remover): the clock
+ * kernel's first pass, then launches that carry the clock re-run lanes AND the run-length framer
+ * (main pass first, its own re-run lists afterwards) until both have converged. */
+static int run_framers_fused(wmbus_ctx *c, K2Args clk, K2Args rla)
+{
+    const WmPush &g = clk.g;
+    const uint32_t lanes_c = 2u * g.nseg[1] * g.S, lanes_r = 2u * g.nseg[0] * g.S;
+    const uint32_t wc = sizeof(WmClkState) / 4, wr = sizeof(WmRlaState) / 4, B = 64 * WM_CLK_WPB;
+    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    clk.list = nullptr; clk.n_lanes = lanes_c;
+    hipLaunchKernelGGL(k2_clock<false>, dim3((lanes_c + B - 1) / B), dim3(B), 0, c->stream, clk);
+    bool clk_done = false, rla_started = false, rla_done = false;
+    for (unsigned round = 0;; round++) {
+        HIPCHK(c, hipMemsetAsync(c->d_scalars + SC_NLIST, 0, sizeof(uint32_t), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_scalars + SC_NLIST2, 0, sizeof(uint32_t), c->stream));
+        if (!clk_done)
+            hipLaunchKernelGGL(k2_verify, dim3((lanes_c + 255) / 256), dim3(256), 0, c->stream, g, (uint32_t)WMBUS_ALGO_T2A,
+                               (const uint32_t *)clk.st_start, (const uint32_t *)clk.st_final, wc, c->d_list, c->d_scalars + SC_NLIST);
+        if (rla_started && !rla_done)
+            hipLaunchKernelGGL(k2_verify, dim3((lanes_r + 255) / 256), dim3(256), 0, c->stream, g, (uint32_t)WMBUS_ALGO_RLA,
+                               (const uint32_t *)rla.st_start, (const uint32_t *)rla.st_final, wr, c->d_list2, c->d_scalars + SC_NLIST2);
+        HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, SC_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        const uint32_t n_c = clk_done ? 0u : c->h_scalars[SC_NLIST], n_r = c->h_scalars[SC_NLIST2];
+        if (!clk_done && n_c == 0) { clk_done = true; HIPCHK(c, hipEventRecord(c->ev[8], c->stream)); }
+        if (rla_started && n_r == 0) rla_done = true;
+        if (clk_done && rla_done) break;
+        if (round > std::max(g.nseg[0], g.nseg[1]) + 2) return fail(c, WMBUS_EDEVICE, "segment verification did not converge");
+        K2Args ca = clk, ra = rla;
+        ca.list = c->d_list; ca.n_lanes = n_c;
+        c->tim.clock_reruns += n_c;
+        if (!rla_started) { ra.list = nullptr; ra.n_lanes = lanes_r; rla_started = true; }
+        else { ra.list = c->d_list2; ra.n_lanes = n_r; c->tim.rla_reruns += n_r; }
+        const uint32_t cb = (n_c + B - 1) / B, rb = (ra.n_lanes + B - 1) / B;
+        hipLaunchKernelGGL(k2_clock_rla, dim3(cb + rb), dim3(B), 0, c->stream, ca, ra, cb);
+    }
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev[1]));
+    HIPCHK(c, hipEventElapsedTime(&c->tim.clock_ms, c->ev[0], c->ev[8]));      /* until the clock kernel had converged */
+    HIPCHK(c, hipEventElapsedTime(&c->tim.rla_ms, c->ev[8], c->ev[1]));        /* what the run-length framer added   */
+    const uint32_t rows = 2u * g.S;
+    hipLaunchKernelGGL(k_carry, dim3((rows + 255) / 256), dim3(256), 0, c->stream, (const uint32_t *)clk.st_final,
+                       (uint32_t *)clk.st_carry, wc, rows, g.nseg_cap[1], g.nseg[1]);
+    hipLaunchKernelGGL(k_carry, dim3((rows + 255) / 256), dim3(256), 0, c->stream, (const uint32_t *)rla.st_final,
+                       (uint32_t *)rla.st_carry, wr, rows, g.nseg_cap[0], g.nseg[0]);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -464,7 +515,11 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
         static std::mutex k1_turn[16];
         std::unique_lock<std::mutex> turn(k1_turn[c->cfg.device & 15], std::defer_lock);
         static const bool take_turns = !(getenv("WMBUS_K1_TURNS") && atoi(getenv("WMBUS_K1_TURNS")) == 0);
-        if (take_turns) turn.lock();
+        if (take_turns) {
+            const auto t_wait = std::chrono::steady_clock::now();
+            turn.lock();
+            c->tim.turn_wait_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_wait).count();
+        }
         HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
         auto launch = [&](uint32_t n_list) -> int {                  /* n_list = 0: all tiles; else the repair list */
             const bool sh = c->flags & WM_F_SHIFT;
@@ -509,21 +564,26 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
         for (int al = 0; al < 2; al++)
             HIPCHK(c, hipMemsetAsync(c->d_sync_seen[al], 0, (size_t)2 * c->S * c->nseg_cap[al] * sizeof(uint32_t), c->stream));
         k2.ckpt = c->d_ckpt; k2.nck = c->nck;
-        {
-            K2Args a = k2; a.algo = WMBUS_ALGO_T2A;
-            a.chips = c->d_chips[1]; a.counts = c->d_counts[1]; a.sync_seen = c->d_sync_seen[1];
-            a.st_start = c->d_st_start[1]; a.st_final = c->d_st_final[1]; a.st_carry = c->d_st_carry[1];
-            rc = run_segments(c, WMBUS_ALGO_T2A, a, &c->tim.clock_ms, &c->tim.clock_reruns);
-            if (rc) return rc;
-        }
-        if (c->flags & WM_F_RLA) {
-            K2Args a = k2; a.algo = WMBUS_ALGO_RLA;
-            a.chips = c->d_chips[0]; a.counts = c->d_counts[0]; a.sync_seen = c->d_sync_seen[0];
-            a.st_start = c->d_st_start[0]; a.st_final = c->d_st_final[0]; a.st_carry = c->d_st_carry[0];
-            rc = run_segments(c, WMBUS_ALGO_RLA, a, &c->tim.rla_ms, &c->tim.rla_reruns);
+        K2Args ka = k2, kr = k2;
+        ka.algo = WMBUS_ALGO_T2A;
+        ka.chips = c->d_chips[1]; ka.counts = c->d_counts[1]; ka.sync_seen = c->d_sync_seen[1];
+        ka.st_start = c->d_st_start[1]; ka.st_final = c->d_st_final[1]; ka.st_carry = c->d_st_carry[1];
+        kr.algo = WMBUS_ALGO_RLA;
+        kr.chips = c->d_chips[0]; kr.counts = c->d_counts[0]; kr.sync_seen = c->d_sync_seen[0];
+        kr.st_start = c->d_st_start[0]; kr.st_final = c->d_st_final[0]; kr.st_carry = c->d_st_carry[0];
+        static const bool fuse = !(getenv("WMBUS_FUSE_FRAMERS") && atoi(getenv("WMBUS_FUSE_FRAMERS")) == 0);   /* tuning aid */
+        if ((c->flags & WM_F_RLA) && !(c->flags & WM_F_DC) && fuse) {
+            rc = run_framers_fused(c, ka, kr);
             if (rc) return rc;
         } else {
-            HIPCHK(c, hipMemsetAsync(c->d_counts[0], 0, (size_t)2 * c->S * c->nseg_cap[0] * sizeof(uint32_t), c->stream));
+            rc = run_segments(c, WMBUS_ALGO_T2A, ka, &c->tim.clock_ms, &c->tim.clock_reruns);
+            if (rc) return rc;
+            if (c->flags & WM_F_RLA) {
+                rc = run_segments(c, WMBUS_ALGO_RLA, kr, &c->tim.rla_ms, &c->tim.rla_reruns);
+                if (rc) return rc;
+            } else {
+                HIPCHK(c, hipMemsetAsync(c->d_counts[0], 0, (size_t)2 * c->S * c->nseg_cap[0] * sizeof(uint32_t), c->stream));
+            }
         }
 
         /* K3: access-code hits of the settled chip streams, then bursts */
@@ -545,7 +605,11 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
         k3.hits = c->d_hits; k3.n_hits = c->d_scalars + SC_NHITS; k3.hits_cap = c->hits_cap; k3.pending = c->d_pending;
         k3.hdr = c->d_hdr; k3.hdr_cap = c->hdr_cap; k3.words = c->d_words; k3.words_cap = c->words_cap;
         k3.n_hdr = c->d_scalars + SC_NHDR; k3.n_words = c->d_scalars + SC_NWORDS; k3.err = c->d_scalars + SC_ERR;
-        hipLaunchKernelGGL(k3_bursts, dim3(4 * c->S + n_hits), dim3(64), 0, c->stream, k3);
+        {
+            static const uint32_t max_blocks = getenv("WMBUS_K3_BLOCKS") ? (uint32_t)atoi(getenv("WMBUS_K3_BLOCKS")) : 256u;   /* tuning aid; 128 ... 512 are within 2 % of each other */
+            const uint32_t n_items = 4 * c->S + n_hits;
+            hipLaunchKernelGGL(k3_bursts, dim3(std::max(1u, std::min((n_items + 3u) / 4u, max_blocks))), dim3(256), 0, c->stream, k3, n_items);
+        }
         HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
         HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, SC_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));

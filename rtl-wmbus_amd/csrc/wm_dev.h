@@ -22,6 +22,12 @@
 #define WM_EMA_WARMUP   32         /* EMA warm-up before a lane's run: trajectories coalesce bitwise within 23
                                       samples (measured); an uncertified hand-off is repaired exactly, not an error */
 #define WM_K1_TILE2     976        /* K1 tile: tile + halo = 1024 = 256 threads x 4           */
+#ifndef WM_CLK_WPB
+#define WM_CLK_WPB      4          /* clock kernel: independent waves per block (see k2_clock) */
+#endif
+#ifndef WM_RLA_WPB
+#define WM_RLA_WPB      4          /* run-length kernel: waves per block, for the same reason */
+#endif
 #define WM_CK_SAMPLES   2048       /* clock kernel: distance of the speculative pass's state checkpoints */
 #define WM_MAX_DECIM    16u        /* staging for d = 16 with -s: 131 KB of the 160 KB LDS */
 

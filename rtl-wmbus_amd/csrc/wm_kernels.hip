@@ -742,14 +742,24 @@ __device__ __forceinline__ void clk_block32(WmClkState &s, const IirCoef &c, con
  * WM_CLK_XROW).  Lane-private 16-byte loads of the same data touch 64 lines per instruction and
  * re-fetch each line from L2 several times.  Re-run launches and odd stream counts take the
  * lane-private path. */
+struct ClkLds {                          /* per block: WM_CLK_WPB independent waves */
+    float x[WM_CLK_WPB][64 * WM_CLK_XROW];
+    uint32_t chip[WM_CLK_WPB][64 * WM_CLK_CROW];
+    uint32_t bits[WM_CLK_WPB][64 * WM_CLK_BROW];
+};
+
+/* WM_CLK_WPB independent waves per block (no block-wide barrier anywhere): a block's waves land on
+ * the CU's four SIMDs, so the framer loads every SIMD of the CUs it is on equally.  A lone
+ * long-running wave on ONE SIMD slows every 4-wave K1 block of that CU down to the pace of the K1
+ * wave that shares the SIMD with it (measured: two clock launches in flight, one wave per CU, cost
+ * K1 60 %). */
 template <bool DC>
-__global__ __launch_bounds__(64) void k2_clock(K2Args a)
+__device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t block, ClkLds &lds)
 {
-    __shared__ __attribute__((aligned(16))) float s_x[64 * WM_CLK_XROW];
-    __shared__ uint32_t s_chip[64 * WM_CLK_CROW];
-    __shared__ uint32_t s_bits[64 * WM_CLK_BROW];
-    const uint32_t ln = threadIdx.x;
-    uint32_t lane = blockIdx.x * 64 + ln;
+    const uint32_t ln = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    float *s_x = lds.x[wv];
+    uint32_t *s_chip = lds.chip[wv], *s_bits = lds.bits[wv];
+    uint32_t lane = (block * WM_CLK_WPB + wv) * 64 + ln;
     const bool rerun = a.list != nullptr;
     const WmPush &g = a.g;
     const bool coop = !rerun && (g.S % 64u) == 0u;         /* wave = 64 consecutive streams, lock step */
@@ -971,6 +981,13 @@ __global__ __launch_bounds__(64) void k2_clock(K2Args a)
     if (n_out > cap_t2) atomicOr(a.err, WM_ERR_CHIP_OVERFLOW);
 }
 
+template <bool DC>
+__global__ __launch_bounds__(64 * WM_CLK_WPB) void k2_clock(K2Args a)
+{
+    __shared__ __attribute__((aligned(16))) ClkLds lds;
+    clock_lanes<DC>(a, blockIdx.x, lds);
+}
+
 /* Deglitch filter for a whole 32-sample block, bit-parallel.  W holds raw slicer bits in time
  * order: bit 5+k = sample k of the block, bits 0..4 = the five samples before it.
  *   T1/C1 (rtl_wmbus.c:126-144,733): level = popcount(last 6 raw bits) >= 3, by a bit-sliced adder;
@@ -995,10 +1012,12 @@ __device__ __forceinline__ uint32_t deglitch_block(uint64_t W, bool s1)
  * the lane only iterates over the EDGES of the deglitched signal.  A framer reset clears the raw
  * history (rtl_wmbus.c:632,723), so after one the remaining levels of the block are recomputed
  * from the masked history.  WmRlaState.raw keeps the last five raw bits in time order. */
-__global__ __launch_bounds__(64) void k2_rla(K2Args a)
+struct RlaLds { uint32_t chip[64 * WM_RLA_WPB * WM_RLA_CROW]; };     /* lane-private staging; the block's waves are independent */
+
+__device__ __forceinline__ void rla_lanes(const K2Args &a, const uint32_t block_id, RlaLds &lds)
 {
-    __shared__ uint32_t s_chip[64 * WM_RLA_CROW];
-    uint32_t lane = blockIdx.x * 64 + threadIdx.x;
+    uint32_t *s_chip = lds.chip;
+    uint32_t lane = block_id * (64 * WM_RLA_WPB) + threadIdx.x;
     if (lane >= a.n_lanes) return;
     const bool rerun = a.list != nullptr;
     if (rerun) lane = a.list[lane];
@@ -1135,6 +1154,25 @@ __global__ __launch_bounds__(64) void k2_rla(K2Args a)
     if (n_out > cap_rl) atomicOr(a.err, WM_ERR_CHIP_OVERFLOW);
 }
 
+__global__ __launch_bounds__(64 * WM_RLA_WPB) void k2_rla(K2Args a)
+{
+    __shared__ RlaLds lds;
+    rla_lanes(a, blockIdx.x, lds);
+}
+
+/* One launch for two independent pieces of work: the clock kernel's re-run lanes (few, long) and
+ * the run-length framer (its main pass or its own re-run list).  Without the DC remover the slicer
+ * words are final after the clock kernel's FIRST pass (sign of the soft symbol, no state), so the
+ * run-length framer need not wait for the clock re-runs; sharing a launch keeps both on the
+ * context's one stream (more streams than hardware queues serialise against each other). */
+static_assert(WM_CLK_WPB == WM_RLA_WPB, "the fused launch uses one block size");
+__global__ __launch_bounds__(64 * WM_CLK_WPB) void k2_clock_rla(K2Args clk, K2Args rla, uint32_t clk_blocks)
+{
+    __shared__ __attribute__((aligned(16))) union { ClkLds c; RlaLds r; } lds;
+    if (blockIdx.x < clk_blocks) clock_lanes<false>(clk, blockIdx.x, lds.c);
+    else rla_lanes(rla, blockIdx.x - clk_blocks, lds.r);
+}
+
 /* start[seg] must equal final[seg-1]; mismatching lanes are appended to `list`. */
 __global__ void k2_verify(WmPush g, uint32_t algo, const uint32_t *st_start, const uint32_t *st_final, uint32_t words,
                           uint32_t *list, uint32_t *n_list)
@@ -1242,12 +1280,11 @@ __global__ __launch_bounds__(256) void k3_scan(WmPush g, const uint32_t *chips0,
     }
 }
 
-/* One wave per hit (or per pending continuation). */
-__global__ __launch_bounds__(64) void k3_bursts(K3Args a)
+/* One access-code hit (or pending continuation), handled by one wave. */
+__device__ void burst_item(const K3Args &a, const uint32_t item, const uint32_t ln)
 {
     const WmPush &g = a.g;
     const uint32_t n_hits = min(*a.n_hits, a.hits_cap);
-    const uint32_t item = blockIdx.x, ln = threadIdx.x;
     uint32_t algo, ch, stream, seg, k, cont = 0, want;
     if (item < 4u * g.S) {                       /* continuation slots come first            */
         algo = item / (2u * g.S); ch = (item / g.S) & 1u; stream = item % g.S;
@@ -1313,6 +1350,16 @@ __global__ __launch_bounds__(64) void k3_bursts(K3Args a)
         h.chip0 = chip0; h.n_chips = n; h.pos0 = pos0; h.word_off = woff; h.avail = avail;
         a.hdr[hslot] = h;
     }
+}
+
+/* A bounded number of waves walks the items (continuation slots, then hits).  One wave per item
+ * -- 14 000 single-wave blocks per 128 captures, each a chain of dependent loads -- took every wave
+ * slot of the chip for the kernel's duration and stalled the demodulation kernel of the next
+ * context (measured: K1 ran at a quarter of its speed while this kernel was resident). */
+__global__ __launch_bounds__(256) void k3_bursts(K3Args a, uint32_t n_items)
+{
+    const uint32_t ln = threadIdx.x & 63u;
+    for (uint32_t item = blockIdx.x * 4u + (threadIdx.x >> 6); item < n_items; item += gridDim.x * 4u) burst_item(a, item, ln);
 }
 
 /* Debug/parity helper: flatten one (chain, algo, stream) chip stream. */

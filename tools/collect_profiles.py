@@ -44,7 +44,8 @@ fetch, write = per_kernel("pmc_fetch_size.csv"), per_kernel("pmc_write_size.csv"
 def pick(d, prefix):
     n = s = 0
     for k, (ln, kb) in d.items():
-        if k.replace("void ", "").startswith(prefix):
+        base = k.replace("void ", "").split("(")[0].split("<")[0]
+        if base == prefix:
             n += ln
             s += kb
     return n, s
@@ -69,7 +70,7 @@ if n_k1:
         "algorithmic_bytes_per_input_sample": 2,
         "other_kernels_KB_per_step_as_reported": {},
     }
-    for pre in ("k2_clock", "k2_rla", "k3_scan", "k3_bursts"):
+    for pre in ("k2_clock", "k2_clock_rla", "k2_rla", "k3_scan", "k3_bursts"):
         traffic["other_kernels_KB_per_step_as_reported"][pre + "_fetch"] = round(pick(fetch, pre)[1] / 2, 1)   # two passes per run
         traffic["other_kernels_KB_per_step_as_reported"][pre + "_write"] = round(pick(write, pre)[1] / 2, 1)
     json.dump(traffic, open(os.path.join(DST, "traffic.json"), "w"), indent=1)
