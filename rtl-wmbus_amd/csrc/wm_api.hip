@@ -438,7 +438,7 @@ static int run_framers_fused(wmbus_ctx *c, K2Args clk, K2Args rla)
 {
     const WmPush &g = clk.g;
     const uint32_t lanes_c = 2u * g.nseg[1] * g.S, lanes_r = 2u * g.nseg[0] * g.S;
-    const uint32_t wc = sizeof(WmClkState) / 4, wr = sizeof(WmRlaState) / 4, B = 64 * WM_CLK_WPB;
+    const uint32_t wc = sizeof(WmClkState) / 4, wr = sizeof(WmRlaState) / 4, B = 64 * WM_CLK_WPB, Br = 64 * WM_RLA_WPB;
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     clk.list = nullptr; clk.n_lanes = lanes_c;
     hipLaunchKernelGGL(k2_clock<false>, dim3((lanes_c + B - 1) / B), dim3(B), 0, c->stream, clk);
@@ -464,8 +464,8 @@ static int run_framers_fused(wmbus_ctx *c, K2Args clk, K2Args rla)
         c->tim.clock_reruns += n_c;
         if (!rla_started) { ra.list = nullptr; ra.n_lanes = lanes_r; rla_started = true; }
         else { ra.list = c->d_list2; ra.n_lanes = n_r; c->tim.rla_reruns += n_r; }
-        const uint32_t cb = (n_c + B - 1) / B, rb = (ra.n_lanes + B - 1) / B;
-        hipLaunchKernelGGL(k2_clock_rla, dim3(cb + rb), dim3(B), 0, c->stream, ca, ra, cb);
+        const uint32_t cb = (n_c + 63u) / 64u, rb = (ra.n_lanes + Br - 1) / Br;     /* one clock wave per block here */
+        hipLaunchKernelGGL(k2_clock_rla, dim3(cb + rb), dim3(Br), 0, c->stream, ca, ra, cb);
     }
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     HIPCHK(c, hipEventSynchronize(c->ev[1]));

@@ -742,10 +742,10 @@ __device__ __forceinline__ void clk_block32(WmClkState &s, const IirCoef &c, con
  * WM_CLK_XROW).  Lane-private 16-byte loads of the same data touch 64 lines per instruction and
  * re-fetch each line from L2 several times.  Re-run launches and odd stream counts take the
  * lane-private path. */
-struct ClkLds {                          /* per block: WM_CLK_WPB independent waves */
-    float x[WM_CLK_WPB][64 * WM_CLK_XROW];
-    uint32_t chip[WM_CLK_WPB][64 * WM_CLK_CROW];
-    uint32_t bits[WM_CLK_WPB][64 * WM_CLK_BROW];
+template <int W> struct ClkLds {         /* per block: W independent waves */
+    float x[W][64 * WM_CLK_XROW];
+    uint32_t chip[W][64 * WM_CLK_CROW];
+    uint32_t bits[W][64 * WM_CLK_BROW];
 };
 
 /* WM_CLK_WPB independent waves per block (no block-wide barrier anywhere): a block's waves land on
@@ -753,13 +753,14 @@ struct ClkLds {                          /* per block: WM_CLK_WPB independent wa
  * long-running wave on ONE SIMD slows every 4-wave K1 block of that CU down to the pace of the K1
  * wave that shares the SIMD with it (measured: two clock launches in flight, one wave per CU, cost
  * K1 60 %). */
-template <bool DC>
-__device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t block, ClkLds &lds)
+template <bool DC, int W>
+__device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t block, ClkLds<W> &lds)
 {
     const uint32_t ln = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    if (wv >= (uint32_t)W) return;           /* W < waves of the block: the fused launch (see k2_clock_rla) */
     float *s_x = lds.x[wv];
     uint32_t *s_chip = lds.chip[wv], *s_bits = lds.bits[wv];
-    uint32_t lane = (block * WM_CLK_WPB + wv) * 64 + ln;
+    uint32_t lane = (block * W + wv) * 64 + ln;
     const bool rerun = a.list != nullptr;
     const WmPush &g = a.g;
     const bool coop = !rerun && (g.S % 64u) == 0u;         /* wave = 64 consecutive streams, lock step */
@@ -984,8 +985,8 @@ __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t bloc
 template <bool DC>
 __global__ __launch_bounds__(64 * WM_CLK_WPB) void k2_clock(K2Args a)
 {
-    __shared__ __attribute__((aligned(16))) ClkLds lds;
-    clock_lanes<DC>(a, blockIdx.x, lds);
+    __shared__ __attribute__((aligned(16))) ClkLds<WM_CLK_WPB> lds;
+    clock_lanes<DC, WM_CLK_WPB>(a, blockIdx.x, lds);
 }
 
 /* Deglitch filter for a whole 32-sample block, bit-parallel.  W holds raw slicer bits in time
@@ -1164,12 +1165,15 @@ __global__ __launch_bounds__(64 * WM_RLA_WPB) void k2_rla(K2Args a)
  * the run-length framer (its main pass or its own re-run list).  Without the DC remover the slicer
  * words are final after the clock kernel's FIRST pass (sign of the soft symbol, no state), so the
  * run-length framer need not wait for the clock re-runs; sharing a launch keeps both on the
- * context's one stream (more streams than hardware queues serialise against each other). */
-static_assert(WM_CLK_WPB == WM_RLA_WPB, "the fused launch uses one block size");
-__global__ __launch_bounds__(64 * WM_CLK_WPB) void k2_clock_rla(K2Args clk, K2Args rla, uint32_t clk_blocks)
+ * context's one stream (more streams than hardware queues serialise against each other).
+ * Every block of a launch gets the same LDS allocation, and a block that needs a quarter of a CU's
+ * LDS cannot be placed while K1 refills the CU with its small blocks (and, once placed, costs K1
+ * three of its eight blocks): the few clock blocks of this launch therefore run ONE wave each, in
+ * the footprint of a run-length block (17 KB instead of 63 KB). */
+__global__ __launch_bounds__(64 * WM_RLA_WPB) void k2_clock_rla(K2Args clk, K2Args rla, uint32_t clk_blocks)
 {
-    __shared__ __attribute__((aligned(16))) union { ClkLds c; RlaLds r; } lds;
-    if (blockIdx.x < clk_blocks) clock_lanes<false>(clk, blockIdx.x, lds.c);
+    __shared__ __attribute__((aligned(16))) union { ClkLds<1> c; RlaLds r; } lds;
+    if (blockIdx.x < clk_blocks) clock_lanes<false, 1>(clk, blockIdx.x, lds.c);
     else rla_lanes(rla, blockIdx.x - clk_blocks, lds.r);
 }
 
