@@ -28,6 +28,19 @@ for src, dst in COPIES:
         print("MISSING", src)
 
 
+# slim copy of the kernel trace of the default bench command (what tools/k1_overlap.py analyses)
+tr = os.path.join(SRC, "trace", "bench_kernel_trace.csv")
+if os.path.exists(tr):
+    cols = ["Queue_Id", "Kernel_Name", "Start_Timestamp", "End_Timestamp", "LDS_Block_Size", "VGPR_Count", "Workgroup_Size_X", "Grid_Size_X"]
+    with open(tr) as f, open(os.path.join(DST, f"{tag}_bench_kernel_trace.csv"), "w", newline="") as g:
+        w = csv.DictWriter(g, fieldnames=cols)
+        w.writeheader()
+        for row in csv.DictReader(f):
+            row["Kernel_Name"] = row["Kernel_Name"].split("(")[0]
+            w.writerow({k: row[k] for k in cols})
+    print("copied slim kernel trace")
+
+
 def per_kernel(name):
     out = {}
     p = os.path.join(SRC, name)
