@@ -953,10 +953,22 @@ __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t bloc
                             out[n1 + (i - n0)] = w;
                         }
                         a.counts[sidx] = n1 + (total0 - n0);
+                        /* this and the later checkpoints describe the tail, which has moved: a later
+                         * round may re-run this segment again and meet them */
+                        for (uint32_t jj = j; jj < a.nck; jj++) ck[16u * jj + 12u] -= n0 - n1;
                     }
                     if (saw_sync) a.sync_seen[sidx] = 1u;       /* the tail's flag, if any, is already set */
                     return;
                 }
+                /* Not on the recorded trajectory: from here on the region holds MY chips (and all of it
+                 * if I run to the end), so the checkpoint must describe me -- a later round that re-runs
+                 * this segment once more compares against what is in memory, not against the
+                 * speculative pass.  (Found by the randomised tests: two chips lost after a second
+                 * round met a checkpoint whose chip count predated the first round's move.) */
+                *(uint4 *)(q) = make_uint4(sw[0], sw[1], sw[2], sw[3]);
+                *(uint4 *)(q + 4) = make_uint4(sw[4], sw[5], sw[6], sw[7]);
+                *(uint4 *)(q + 8) = make_uint4(sw[8], sw[9], sw[10], sw[11]);
+                q[12] = n1;
             }
         }
     }
