@@ -37,6 +37,10 @@ def make_case(k, seed_offset=None):
     tune = dict(seg_len=int(rng.choice([1024, 4096, 32768, 131072])), rla_seg_len=int(rng.choice([1024, 8192])),
                 warmup_t1c1=int(rng.choice([512, 4096, 12288])), warmup_s1=int(rng.choice([512, 8192, 24576])),
                 rla_lookback=int(rng.choice([64, 256, 1024]))) if rng.random() < 0.5 else {}
+    if os.environ.get("WMBUS_FUZZ_STRESS"):            # bug hunts: always short segments and warm-ups (cascading re-run rounds)
+        tune = dict(seg_len=int(rng.choice([1024, 4096, 8192])), rla_seg_len=int(rng.choice([1024, 2048])),
+                    warmup_t1c1=int(rng.choice([128, 512, 2048])), warmup_s1=int(rng.choice([128, 512, 4096])),
+                    rla_lookback=int(rng.choice([32, 64, 256])))
     return dict(k=k, d=d, flags=flags, simultaneous=simultaneous, prefilter=prefilter, n_streams=n_streams, n=n, push=push, tune=tune,
                 amp=float(rng.choice([8.0, 25.0, 60.0])), silence=rng.random() < 0.3, seed=int(rng.integers(1, 1 << 30)))
 
