@@ -1259,7 +1259,7 @@ __device__ uint32_t burst_need(uint32_t chain, uint32_t hb, uint32_t nb)
  * and duplicate records behind, each of which cost a burst copy.)  The framers only leave a
  * per-region flag "an access-code chip was emitted here by some pass"; each lane of a wave looks at
  * the flag of one (framer, chain, capture, segment) region, and the wave then scans the flagged
- * regions (~2 %) together, appending {lane | algo << 31, chip index}. */
+ * regions (a minority) together, appending {lane | algo << 31, chip index}. */
 __global__ __launch_bounds__(256) void k3_scan(WmPush g, const uint32_t *chips0, const uint32_t *chips1, const uint32_t *counts0,
                                                const uint32_t *counts1, const uint32_t *seen0, const uint32_t *seen1,
                                                uint2 *hits, uint32_t *n_hits, uint32_t hits_cap, uint32_t *err)
