@@ -661,54 +661,52 @@ __device__ __forceinline__ void clk_block32(WmClkState &s, const IirCoef &c, con
     float soft = 0.0f;                                     /* DC stage output waiting for section 0 */
     uint32_t sgn = 0, low = 0;                             /* MSB-first: sample n ends up in bit 31 - n */
     const float al = 0.999f, kk = wm_div(wm_add(1.0f, al), 2.0f);
-    /* One tick.  `live(n)`: does sample n exist at this tick?  The first four and the draining ticks
-     * are peeled with compile-time t (the conditions fold away); ticks 4..31, where every stage is
-     * busy, run as a ROLLED loop of seven groups of four (113 VALU instructions per group, no
-     * register moves at the back edge).  Fully unrolled, the block was 6.5 KB of code and the kernel
-     * held four copies of it (30 KB, now 16 KB; k2_clock_rla 38 -> 24 KB).  Same speed: the suspicion
-     * that K1 (25 KB) and the framers overflow the 64 KB instruction cache two CUs share was not
-     * confirmed (K1 beside the framers 3.95 ms either way). */
-    auto tick = [&](const int t, const int j, const bool steady) {       /* j = t & 3 */
-        auto live = [&](const int n) { return steady || (n >= 0 && n < 32); };
-        const bool fresh = steady || t < 32;                                /* a new input sample at this tick */
+#pragma unroll
+    for (int t = 0; t < 32 + P + 2; t++) {
         float m1[3], m2[3], p1[3], p2[3], tt[3], h0[3], u[3], o[3];
         float d1 = 0.0f, d2 = 0.0f, d3 = 0.0f;
-        if (fresh && j == 0) xq = *(const float4 *)(xrow + t);
-        const float xt = j == 0 ? xq.x : j == 1 ? xq.y : j == 2 ? xq.z : xq.w;   /* sample t (t < 32) */
+        if (t < 32 && (t & 3) == 0) xq = *(const float4 *)(xrow + t);
+        const float xt = (t & 3) == 0 ? xq.x : (t & 3) == 1 ? xq.y : (t & 3) == 2 ? xq.z : xq.w;   /* sample t (t < 32) */
         /* level 1: every product that only needs last tick's state */
-        if (DC && fresh) { d1 = wm_sub(xt, dcx); d2 = wm_mul(al, dcy); }
-        if (live(t - P)) {   /* section 0's input: the (DC-filtered) soft symbol, squared */
-            const float sf = DC ? soft : xt;
-            sgn = __builtin_amdgcn_alignbit(sgn, wm_f2u(sf), 31);      /* (sgn << 1) | signbit */
-            in[0] = wm_mul(sf, sf);
+        if (DC && t < 32) { d1 = wm_sub(xt, dcx); d2 = wm_mul(al, dcy); }
+        {   /* section 0's input: the (DC-filtered) soft symbol, squared */
+            const int n0 = t - P;
+            if (n0 >= 0 && n0 < 32) {
+                const float sf = DC ? soft : xt;
+                sgn = __builtin_amdgcn_alignbit(sgn, wm_f2u(sf), 31);      /* (sgn << 1) | signbit */
+                in[0] = wm_mul(sf, sf);
+            }
         }
 #pragma unroll
-        for (int k = 0; k < 3; k++)
-            if (live(t - P - k)) {
+        for (int k = 0; k < 3; k++) {
+            const int n = t - P - k;
+            if (n >= 0 && n < 32) {
                 m1[k] = wm_mul(c.a1[k], h1[k]); m2[k] = wm_mul(c.a2[k], h2[k]);
                 p1[k] = wm_mul(c.b1[k], h1[k]); p2[k] = wm_mul(c.b2[k], h2[k]);
             }
+        }
         __builtin_amdgcn_sched_barrier(0);
         /* level 2 */
-        if (DC && fresh) d3 = wm_mul(kk, d1);
+        if (DC && t < 32) d3 = wm_mul(kk, d1);
 #pragma unroll
-        for (int k = 0; k < 3; k++) if (live(t - P - k)) tt[k] = wm_add(m1[k], m2[k]);
+        for (int k = 0; k < 3; k++) { const int n = t - P - k; if (n >= 0 && n < 32) tt[k] = wm_add(m1[k], m2[k]); }
         __builtin_amdgcn_sched_barrier(0);
         /* level 3 */
-        if (DC && fresh) { const float y = wm_add(d3, d2); dcx = xt; dcy = y; soft = y; }
+        if (DC && t < 32) { const float y = wm_add(d3, d2); dcx = xt; dcy = y; soft = y; }
 #pragma unroll
-        for (int k = 0; k < 3; k++) if (live(t - P - k)) h0[k] = wm_sub(in[k], tt[k]);
+        for (int k = 0; k < 3; k++) { const int n = t - P - k; if (n >= 0 && n < 32) h0[k] = wm_sub(in[k], tt[k]); }
         __builtin_amdgcn_sched_barrier(0);
         /* level 4, 5 */
 #pragma unroll
-        for (int k = 0; k < 3; k++) if (live(t - P - k)) u[k] = wm_add(h0[k], p1[k]);
+        for (int k = 0; k < 3; k++) { const int n = t - P - k; if (n >= 0 && n < 32) u[k] = wm_add(h0[k], p1[k]); }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < 3; k++) if (live(t - P - k)) o[k] = wm_add(u[k], p2[k]);
+        for (int k = 0; k < 3; k++) { const int n = t - P - k; if (n >= 0 && n < 32) o[k] = wm_add(u[k], p2[k]); }
         /* hand over: section k's output is section k+1's input at the next tick */
 #pragma unroll
-        for (int k = 2; k >= 0; k--)
-            if (live(t - P - k)) {
+        for (int k = 2; k >= 0; k--) {
+            const int n = t - P - k;
+            if (n >= 0 && n < 32) {
                 h2[k] = h1[k]; h1[k] = h0[k];
                 if (k < 2) in[k + 1] = o[k];
                 else {
@@ -717,16 +715,9 @@ __device__ __forceinline__ void clk_block32(WmClkState &s, const IirCoef &c, con
                         : "+v"(low), "=&v"(tmp) : "v"(wm_f2u(o[2])), "s"(WM_LEVEL_CARRY) : "vcc");
                 }
             }
+        }
         __builtin_amdgcn_sched_barrier(0);
-    };
-#pragma unroll
-    for (int t = 0; t < 4; t++) tick(t, t, false);                  /* the pipeline fills */
-#pragma unroll 1
-    for (int t = 4; t < 32; t += 4) {                                /* every stage busy */
-        tick(t, 0, true); tick(t + 1, 1, true); tick(t + 2, 2, true); tick(t + 3, 3, true);
     }
-#pragma unroll
-    for (int t = 32; t < 32 + P + 2; t++) tick(t, t & 3, false);    /* ... and drains */
     s.h[0] = h1[0]; s.h[1] = h2[0]; s.h[2] = h1[1]; s.h[3] = h2[1]; s.h[4] = h1[2]; s.h[5] = h2[2];
     s.dc_x = dcx; s.dc_y = dcy;
     bitw = ~__builtin_bitreverse32(sgn);
