@@ -1,0 +1,521 @@
+/* wm_k1_demod.h -- K1: demodulation tile kernels (front end, discriminator, FIR, RSSI) and their hand-off checks.
+ * Device code, included by wm_kernels.hip (one translation unit, see the overview there). */
+#ifndef WM_K1_DEMOD_H
+#define WM_K1_DEMOD_H
+
+typedef short wm_s2 __attribute__((ext_vector_type(2)));
+
+/* ---------------------------------------------------------------------------------------------
+ * Filter constants (rtl_wmbus.c:372, 384, 338-341, 353-356) as decimal literals, converted by the
+ * compiler to the same floats the reference's arrays hold.
+ * ------------------------------------------------------------------------------------------- */
+__device__ static constexpr float FIR_T[11] = {
+    -0.00456638213f, -0.002571450348f, 0.02689425925f, 0.1141330398f, 0.2264456422f, 0.2793297826f,
+    0.2264456422f, 0.1141330398f, 0.02689425925f, -0.002571450348f, -0.00456638213f};
+__device__ static constexpr float FIR_S[46] = {
+    -0.000649081282f, -0.0009491938209f, -0.001361601657f, -0.001910785234f, -0.002570133495f,
+    -0.003251218426f, -0.003801634695f, -0.004012672882f, -0.003636803575f, -0.002413585945f,
+    -0.0001013597693f, 0.003488892085f, 0.008461671287f, 0.01481127545f, 0.02240598045f,
+    0.03098477999f, 0.0401679839f, 0.04948137286f, 0.05839197924f, 0.06635211627f, 0.07284719662f,
+    0.07744230649f, 0.07982251613f, 0.07982251613f, 0.07744230649f, 0.07284719662f, 0.06635211627f,
+    0.05839197924f, 0.04948137286f, 0.0401679839f, 0.03098477999f, 0.02240598045f, 0.01481127545f,
+    0.008461671287f, 0.003488892085f, -0.0001013597693f, -0.002413585945f, -0.003636803575f,
+    -0.004012672882f, -0.003801634695f, -0.003251218426f, -0.002570133495f, -0.001910785234f,
+    -0.001361601657f, -0.0009491938209f, -0.000649081282f};
+
+/* =============================================================================================
+ * K1: demodulation tile kernels
+ * ===========================================================================================*/
+struct K1Args {
+    WmPush g;
+    float *dphi;             /* [2][S][Mcap] */
+    uint8_t *rssi;           /* [2][S][Mcap] */
+    const float *lut_cos;    /* [lut_n]  cosf table, built on the host with the host libm */
+    const float *lut_msin;   /* [lut_n]  -sinf table                                      */
+    float *ema_head;         /* [ntiles][2][S] EMA after warm-up (= value at tile_start-1); tile-major so that */
+    float *ema_tail;         /* [ntiles][2][S] EMA after the tile's last valid sample       k1_verify reads coalesced */
+    uint32_t ntiles;
+    uint32_t *err;
+    /* repair launches: grid.x walks `relist` (stream * ntiles + tile);
+     * the tile's EMA is then run sequentially from its predecessor's exact tail */
+    const uint32_t *relist;
+    const float *ema_carry;  /* [2][S] exact EMA carried in from the previous push */
+};
+
+/* =============================================================================================
+ * K1, moving-average front end (second generation of this kernel; the first one -- 1024-sample
+ * tiles, five samples per thread, sliding sums, select-based arctangent, 30.7 ms -- is in the git
+ * history): same arithmetic, far fewer instructions, balanced waves.
+ *
+ * Tile = 976 decimated samples, so that tile + 48-sample halo = 1024 = 256 threads x 4: every
+ * thread owns exactly one chunk of 4 consecutive samples in stage A (the first generation spent
+ * 20 wave-iterations on 1072 samples; this one 16 on 1024).
+ *   stage 0  cu8 -> packed int16 (i,q) in LDS, stored so that LDS word 0 is the oldest sample the
+ *            tile needs; quantisation with byte-permute + packed-int16 arithmetic.
+ *   stage A  a chunk needs the 4D+16 staged samples [4cD, 4cD+4D+16): aligned ds_read_b128, packed
+ *            int16 prefix sums, every boxcar (8 and 16 taps, 5 positions) one packed subtract.
+ *            Discriminator on the table-driven atan2 (wm_exact.h) fed with the unscaled sums.
+ *   stage B1 FIR from unskewed rows with aligned ds_read_b128 windows (13 + 4 loads instead of
+ *            49 + 14 dword loads).
+ *   stage B2 RSSI EMA: one wave per chain, 16 samples per lane behind a 48-sample warm-up
+ *            (first generation: all four waves, 8 samples per lane behind the same warm-up).
+ * LDS (words): U[max(staging, 2 magnitude rows)] | yDrT[YD] yDrS[YD] | sFin[128] sHead[128] |
+ *              atan table[64] = 18.3 KB at d = 2 (8 workgroups per CU).  The magnitude rows
+ *              overlay the staging area: stage A keeps its 8 magnitudes in registers until the
+ *              barrier that retires the staging data.
+ * ===========================================================================================*/
+/* D = the decimation as a compile-time constant (2..5: the rates rtl-wmbus documents) or 0: read it
+ * from the push at run time (any 1..WM_MAX_DECIM; same code with loops instead of unrolled runs). */
+struct K1Geo {
+    static constexpr int T = WM_K1_TILE2, NA = T + WM_K1_HALO;
+    static constexpr int YD = NA + 8, YM = NA + NA / 16 + 4;
+    __host__ __device__ static constexpr int nstg(int d) { return (NA * d + 16 + 8 + 7) / 8 * 8 + 8; }   /* 8 slack words in front */
+    __host__ __device__ static constexpr int U(int d, bool shift)
+    {
+        return nstg(d) * (shift ? 2 : 1) > 2 * YM ? nstg(d) * (shift ? 2 : 1) : 2 * YM;
+    }
+    static constexpr size_t smem(int d, bool shift) { return (size_t)(U(d, shift) + 2 * YD + 256 + WM_ATAN_TAB_WORDS) * 4; }
+};
+static_assert(K1Geo::NA == 1024, "stage A maps one 4-sample chunk to each of the 256 threads");
+
+/* 8- and 16-tap boxcar sums at the five positions a0-1 .. a0+3 of one chunk from the staged
+ * samples w[0 .. 4D+16) (w[15] is the newest input of position a0-1). */
+template <int D>
+__device__ __forceinline__ void k1_boxcars(const uint32_t *w, int d_rt, wm_s2 s8[5], wm_s2 s16[5])
+{
+    if (D == 0) {                                             /* run-time decimation: direct sums */
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            const int n = j * d_rt + 15;
+            wm_s2 lo = {0, 0}, hi = {0, 0};
+            for (int k = 0; k < 8; k++) { lo += __builtin_bit_cast(wm_s2, w[n - k]); hi += __builtin_bit_cast(wm_s2, w[n - 8 - k]); }
+            s8[j] = lo; s16[j] = lo + hi;
+        }
+        return;
+    }
+    constexpr int N = 4 * (D ? D : 1) + 16;
+    uint32_t x[N];
+#pragma unroll
+    for (int k = 0; k < N / 4; k++) {
+        const uint4 v = *(const uint4 *)(w + 4 * k);
+        x[4 * k] = v.x; x[4 * k + 1] = v.y; x[4 * k + 2] = v.z; x[4 * k + 3] = v.w;
+    }
+    wm_s2 P[N];
+    P[0] = __builtin_bit_cast(wm_s2, x[0]);
+#pragma unroll
+    for (int k = 1; k < N; k++) P[k] = P[k - 1] + __builtin_bit_cast(wm_s2, x[k]);
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const int n = j * D + 15;
+        s8[j] = P[n] - P[n - 8];
+        s16[j] = n >= 16 ? P[n] - P[n - 16] : P[n];
+    }
+}
+
+/* Stages B1 (FIR) and B2 (RSSI EMA + hand-off certification) of a 976-sample tile; shared by the
+ * moving-average and the polyphase front ends.  Rows: element a of a discriminator row at word
+ * a + 4, of a magnitude row at a + a/16 (the two chains' rows may alias when they carry the same
+ * data).  Ends with the magnitude rows' barrier already passed by every thread. */
+__device__ __forceinline__ void k1_fir_t(const K1Args &a, const float *yDrT, const int slot, const int stream, const int ts, const int tn)
+{
+    const WmPush &g = a.g;
+    const int m0l = 4 * slot;
+    if (m0l >= tn) return;
+    float w[16];                                              /* w[i] = element 4 slot + 36 + i */
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float4 v = *(const float4 *)(yDrT + 4 * slot + 40 + 4 * k);
+        w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+    }
+    float acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 11; k++) s = wm_add(s, wm_mul(FIR_T[k], w[12 + j - k]));
+        acc[j] = s;
+    }
+    *(float4 *)(a.dphi + (uint64_t)stream * g.Mcap + (uint64_t)ts + m0l) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
+__device__ __forceinline__ void k1_fir_s(const K1Args &a, const float *yDrS, const int slot, const int stream, const int ts, const int tn)
+{
+    const WmPush &g = a.g;
+    const int m0l = 4 * slot;
+    if (m0l >= tn) return;
+    float w[52];                                              /* w[i] = element 4 slot + i */
+#pragma unroll
+    for (int k = 0; k < 13; k++) {
+        const float4 v = *(const float4 *)(yDrS + 4 * slot + 4 + 4 * k);
+        w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+    }
+    float acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 46; k++) s = wm_add(s, wm_mul(FIR_S[k], w[48 + j - k]));
+        acc[j] = s;
+    }
+    *(float4 *)(a.dphi + ((uint64_t)g.S + stream) * g.Mcap + (uint64_t)ts + m0l) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
+/* Stages B1 (FIR low-pass, y[n] = sum_k b[k] x[n-k], k ascending, fir.h:48-72) and B2 (RSSI EMA,
+ * rtl_wmbus.c:475-495, + hand-off certification) of a 976-sample tile; shared by the moving-average
+ * and the polyphase front ends.  Rows: element a of a discriminator row at word a + 4, of a
+ * magnitude row at a + a/16 (the two chains' rows may alias when they carry the same data).
+ * Work split: waves 0 and 1 run one chain's EMA each (16 samples per lane behind the warm-up) and
+ * the 11-tap FIR of half the tile; waves 2 and 3 the 46-tap FIR of half the tile each -- 630 against
+ * 860 instructions, instead of 960 on the EMA waves and 530 on the others. */
+__device__ __forceinline__ void k1_stage_b(const K1Args &a, const int tid, const int tile, const int stream, const int ts, const int tn,
+                                           const bool chT, const bool chS, const float *yDrT, const float *yDrS,
+                                           const float *yMgT, const float *yMgS, float *sFin, float *sHead)
+{
+    constexpr int T = WM_K1_TILE2;
+    const WmPush &g = a.g;
+    __syncthreads();                                          /* magnitude rows complete */
+    const int wv = tid >> 6, e = tid & 63;
+    const int ch = wv & 1;                                    /* EMA chain of waves 0, 1 */
+    const bool on = wv < 2 && (ch ? chS : chT) && 16 * e < T;
+    const float al = 0.6789f, be = wm_sub(1.0f, 0.6789f);
+    const int m0l = 16 * e;
+    const uint64_t row = (uint64_t)ch * g.S + stream;
+    const uint64_t rows = 2ull * g.S, ti = (uint64_t)tile * rows + row;
+    if (a.relist != nullptr) {
+        /* REPAIR: a hand-off of this tile could not be certified (e.g. exact-zero input after a
+         * signal: the true state decays through 90 more samples while a warm-up from zero is already
+         * at zero).  One lane per chain runs the whole tile sequentially from the predecessor's exact
+         * tail -- slow, exact, and only for the listed tiles. */
+        if (chT) k1_fir_t(a, yDrT, tid, stream, ts, tn);
+        if (chS) k1_fir_s(a, yDrS, tid, stream, ts, tn);
+        if (on && e == 0) {
+            const float *mrow = ch ? yMgS : yMgT;
+            float ema = tile ? a.ema_tail[ti - rows] : a.ema_carry[row];
+            const float head = ema;
+            uint8_t *o = a.rssi + row * g.Mcap + ts;
+            for (int m = 0; m < tn; m++) {
+                const int el = WM_K1_HALO + m;
+                ema = wm_add(wm_mul(al, mrow[el + (el >> 4)]), wm_mul(be, ema));
+                o[m] = (uint8_t)((uint32_t)ema & 0xFFu);
+            }
+            a.ema_head[ti] = head; a.ema_tail[ti] = ema;
+        }
+        return;
+    }
+    float ema = 0.0f, tail = 0.0f, head = 0.0f;
+    if (wv < 2) {
+        if (on) {
+            const float *mg = (ch ? yMgS : yMgT) + 17 * e;    /* element 16 e + kk at 17 e + kk + kk/16 */
+#pragma unroll
+            for (int k = WM_K1_HALO - WM_EMA_WARMUP; k < WM_K1_HALO; k++)     /* the last WM_EMA_WARMUP halo samples */
+                ema = wm_add(wm_mul(al, mg[k + (k >> 4)]), wm_mul(be, ema));
+            head = ema;
+            uint32_t pk[4] = {0u, 0u, 0u, 0u};
+            if (tn == T) {                                    /* full tile: the tail is lane 60's last value */
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    ema = wm_add(wm_mul(al, mg[WM_K1_HALO + k + ((WM_K1_HALO + k) >> 4)]), wm_mul(be, ema));
+                    pk[k >> 2] |= ((uint32_t)ema & 0xFFu) << (8 * (k & 3));
+                }
+                tail = ema;
+            } else {                                          /* last tile of a push */
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    ema = wm_add(wm_mul(al, mg[WM_K1_HALO + k + ((WM_K1_HALO + k) >> 4)]), wm_mul(be, ema));
+                    pk[k >> 2] |= ((uint32_t)ema & 0xFFu) << (8 * (k & 3));
+                    if (m0l + k == tn - 1) tail = ema;
+                }
+            }
+            if (m0l < tn)
+                *(uint4 *)(a.rssi + row * g.Mcap + ts + m0l) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            sFin[tid] = ema; sHead[tid] = head;
+        }
+        if (chT) { k1_fir_t(a, yDrT, 128 * wv + e, stream, ts, tn); k1_fir_t(a, yDrT, 128 * wv + 64 + e, stream, ts, tn); }
+    } else if (chS) {
+        k1_fir_s(a, yDrS, 128 * (wv - 2) + e, stream, ts, tn);
+        k1_fir_s(a, yDrS, 128 * (wv - 2) + 64 + e, stream, ts, tn);
+    }
+    __syncthreads();
+    /* certify: a lane's warm-up must have landed exactly on its predecessor's trajectory; a tile
+     * with an uncertified lane publishes a head that cannot match (NaN) and is repaired */
+    const bool bad = on && e > 0 && m0l < tn && wm_f2u(head) != wm_f2u(sFin[tid - 1]);
+    const unsigned long long badT = __ballot(bad);            /* waves 0 and 1 are the two chains */
+    if (on) {
+        if (e == 0) a.ema_head[ti] = badT ? wm_u2f(0x7FC00000u) : head;
+        if (m0l <= tn - 1 && tn - 1 < m0l + 16) a.ema_tail[ti] = tail;
+    }
+}
+
+template <int D, bool SHIFT>
+__global__ __launch_bounds__(256) void k1_demod2(K1Args a)
+{
+    using G = K1Geo;
+    constexpr int T = G::T, NA = G::NA, YD = G::YD, YM = G::YM;
+    const WmPush &g = a.g;
+    const int d = D ? D : (int)g.d;
+    const int NSTG = G::nstg(d);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t *stgT = (uint32_t *)smem + 8;                /* word 0 of a row = oldest sample of the tile */
+    uint32_t *stgS = SHIFT ? stgT + NSTG : stgT;
+    float *yMgT = (float *)smem, *yMgS = yMgT + YM;       /* overlay the staging rows (see stage A) */
+    float *yDrT = (float *)smem + G::U(d, SHIFT), *yDrS = yDrT + YD;
+    float *sFin = yDrS + YD, *sHead = sFin + 128, *tab = sHead + 128;
+
+    const int tid = threadIdx.x;
+    const int tile = a.relist ? (int)(a.relist[blockIdx.x] % a.ntiles) : (int)blockIdx.x;
+    const int stream = a.relist ? (int)(a.relist[blockIdx.x] / a.ntiles) : (int)blockIdx.y;
+    const int ts = tile * T;
+    const int tn = min(T, (int)g.M - ts);
+    const bool chT = g.flags & WM_F_T1C1, chS = g.flags & WM_F_S1;
+    const bool accurate = g.flags & WM_F_ACCURATE;
+
+    if (tid < WM_ATAN_TAB_WORDS) wm_atan_tab_word(tid, tab);   /* 5 range rows + range LUT */
+
+    /* ---- stage 0: one dword (two IQ samples) per lane and pass: coalesced loads, LDS stores at a
+     * two-word lane stride (the 16-byte-per-lane variant stored at an 8-word stride: 8-way bank
+     * conflicts) ------------------------------------------------------------------------------- */
+    {
+        const long r_lo = ((long)(g.m0 + (uint64_t)ts) - WM_K1_HALO) * d - 16 - (long)g.n0;   /* LDS word 0 */
+        const long r_al = r_lo & ~1L;
+        const int off = (int)(r_lo - r_al);                   /* 0 or 1 */
+        const int NDW = (NA * d + 16 + 1 + 1) / 2;            /* dwords covering the staged samples */
+        const uint8_t *base = g.in + (uint64_t)stream * g.in_stride + WM_HIST_BYTES;
+        const uint32_t *src = (const uint32_t *)(base + 2 * r_al);
+        constexpr int NP = D ? ((NA * D + 16 + 1 + 1) / 2 + 255) / 256 : 1;     /* loads in flight per lane */
+        const int passes = D ? 1 : (NDW + 255) / 256;
+        for (int ps = 0; ps < passes; ps++) {
+        uint32_t wv[NP];
+#pragma unroll
+        for (int it = 0; it < NP; it++) {
+            const int u = tid + 256 * (it + ps);
+            wv[it] = u < NDW ? src[u] : 0u;
+        }
+#pragma unroll
+        for (int it = 0; it < NP; it++) {
+            const int u = tid + 256 * (it + ps);
+            if (u < NDW) {
+                const int p = 2 * u - off;
+                if (!SHIFT) {
+                    /* bytes (i,q) -> halfwords, then u - 127 - (u >> 7) per halfword
+                     * (= (int)((float)u - 127.5f), rtl_wmbus.c:1312-1313 + moving_average_filter.h:47) */
+                    const wm_s2 c127 = {127, 127};
+#pragma unroll
+                    for (int k = 0; k < 2; k++) {
+                        const uint32_t h = __builtin_amdgcn_perm(0u, wv[it], k ? 0x0c030c02u : 0x0c010c00u);
+                        const wm_s2 q = __builtin_bit_cast(wm_s2, h) - c127 - __builtin_bit_cast(wm_s2, (h >> 7) & 0x00010001u);
+                        stgT[p + k] = __builtin_bit_cast(uint32_t, q);
+                    }
+                } else {
+                    /* LUT index of global sample n: (13 n) mod lut_n, rtl_wmbus.c:1006-1010 */
+                    const int L = (int)g.lut_n;
+                    int rm = (int)((r_al + 2L * u) % L); if (rm < 0) rm += L;
+                    uint32_t li = (g.lut_phase0 + 13u * (uint32_t)rm) % (uint32_t)L;
+#pragma unroll
+                    for (int k = 0; k < 2; k++) {
+                        const uint32_t iq = (wv[it] >> (16 * k)) & 0xFFFFu;
+                        const float fi = wm_sub((float)(iq & 0xFFu), 127.5f), fq = wm_sub((float)(iq >> 8), 127.5f);
+                        const float x = a.lut_cos[li], z = a.lut_msin[li];
+                        li += 13u; if (li >= g.lut_n) li -= g.lut_n;
+                        const float ix = wm_mul(fi, x), qx = wm_mul(fq, x), iz = wm_mul(fi, z), qz = wm_mul(fq, z);
+                        wm_s2 t, sv;
+                        t.x = (short)(int)wm_sub(ix, qz); t.y = (short)(int)wm_add(qx, iz);
+                        sv.x = (short)(int)wm_add(ix, qz); sv.y = (short)(int)wm_sub(qx, iz);
+                        stgT[p + k] = __builtin_bit_cast(uint32_t, t); stgS[p + k] = __builtin_bit_cast(uint32_t, sv);
+                    }
+                }
+            }
+        }
+        }
+    }
+    __syncthreads();
+
+    /* ---- stage A: thread = chunk ------------------------------------------------------------- */
+    float mgT[4], mgS[4];
+    {
+        const int c = tid;
+        wm_s2 s8[5], s16[5], u8[5], u16[5];
+        k1_boxcars<D>(stgT + 4 * c * d, d, s8, SHIFT ? u16 : s16);
+        if (SHIFT) k1_boxcars<D>(stgS + 4 * c * d, d, u8, s16);
+        /* the eight arctangents of a thread (4 samples x 2 chains) are independent: computed in one
+         * straight-line region (the accurate / -a choice hoisted out of the loops), the scheduler
+         * interleaves their dependent chains */
+        float drT[4], drS[4], fT[5][2], fS[5][2];
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            fT[j][0] = (float)s8[j].x; fT[j][1] = (float)s8[j].y;          /* 8 x the reference's i, q */
+            fS[j][0] = (float)s16[j].x; fS[j][1] = (float)s16[j].y;       /* 16 x */
+        }
+        if (accurate && chT && chS) {                        /* default switches: no branch between the eight */
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                drT[j] = wm_discriminator_tab(fT[j + 1][0], fT[j + 1][1], fT[j][0], fT[j][1], tab);
+                drS[j] = wm_discriminator_tab(fS[j + 1][0], fS[j + 1][1], fS[j][0], fS[j][1], tab);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float iT = fT[j + 1][0], qT = fT[j + 1][1], iS = fS[j + 1][0], qS = fS[j + 1][1];
+                mgT[j] = wm_mul(wm_sqrt_dom(wm_add(wm_mul(iT, iT), wm_mul(qT, qT))), 0.125f);
+                mgS[j] = wm_mul(wm_sqrt_dom(wm_add(wm_mul(iS, iS), wm_mul(qS, qS))), 0.0625f);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float iT = fT[j + 1][0], qT = fT[j + 1][1], iS = fS[j + 1][0], qS = fS[j + 1][1];
+                drT[j] = !chT ? 0.0f : accurate ? wm_discriminator_tab(iT, qT, fT[j][0], fT[j][1], tab)
+                                                : wm_mul(wm_discriminator_fast(iT, qT, fT[j][0], fT[j][1]), 0.015625f);
+                drS[j] = !chS ? 0.0f : accurate ? wm_discriminator_tab(iS, qS, fS[j][0], fS[j][1], tab)
+                                                : wm_mul(wm_discriminator_fast(iS, qS, fS[j][0], fS[j][1]), 0.00390625f);
+                mgT[j] = chT ? wm_mul(wm_sqrt_dom(wm_add(wm_mul(iT, iT), wm_mul(qT, qT))), 0.125f) : 0.0f;
+                mgS[j] = chS ? wm_mul(wm_sqrt_dom(wm_add(wm_mul(iS, iS), wm_mul(qS, qS))), 0.0625f) : 0.0f;
+            }
+        }
+        /* element a of a discriminator row lives at word a + 4 */
+        *(float4 *)(yDrT + 4 * c + 4) = make_float4(drT[0], drT[1], drT[2], drT[3]);
+        *(float4 *)(yDrS + 4 * c + 4) = make_float4(drS[0], drS[1], drS[2], drS[3]);
+    }
+    __syncthreads();                                          /* staging data retired */
+    {   /* element a of a magnitude row lives at word a + a/16 (conflict-free 17-word lane stride in B2) */
+        const int qb = 4 * tid + (tid >> 2);
+#pragma unroll
+        for (int j = 0; j < 4; j++) { yMgT[qb + j] = mgT[j]; yMgS[qb + j] = mgS[j]; }
+    }
+
+    k1_stage_b(a, tid, tile, stream, ts, tn, chT, chS, yDrT, yDrS, yMgT, yMgS, sFin, sHead);
+}
+
+/* =============================================================================================
+ * K1 with the POLYPHASE pre-filter: ppf.h:46-59 driven as the reference's
+ * lp_ppf_butter_1600kHz_160kHz_200kHz does (rtl_wmbus.c:258-294): even input samples through the
+ * 12 taps b[1], odd ones through b[0], y[m] = (0 + F_even[m]) + F_odd[m] taken after the odd
+ * sample -- in place of the two moving averages.  The reference defines this filter but never calls
+ * it, so it is an OPTION here (cfg.prefilter = 1, d = 2, no -s) and is pinned at stage level: the
+ * reference's own function, driven by oracle/ref_probe.c, against the oracle, and the oracle against
+ * this kernel.  One filtered (i,q) pair feeds both chains, so discriminator and magnitude are
+ * computed once; the operands are arbitrary floats, hence the general wm_atan2f / wm_sqrt.
+ * LDS (words): float2 staging[2 NA + 24] (the magnitude row overlays it) | yDr[YD] | sFin, sHead.
+ * ===========================================================================================*/
+__device__ static constexpr float PPF_EVEN[12] = {1.102280392e-05f, 0.001356012537f, 0.01499414005f, 0.05525973093f,
+    0.1099887688f, 0.1366692652f, 0.1099887688f, 0.05525973093f, 0.01499414005f, 0.001356012537f, 1.102280392e-05f, 0.0f};
+__device__ static constexpr float PPF_ODD[12] = {0.000140535927f, 0.0001309279731f, 0.00551787474f, 0.03160167988f,
+    0.08315031015f, 0.1295143636f, 0.1295143636f, 0.08315031015f, 0.03160167988f, 0.00551787474f, 0.0001309279731f,
+    0.000140535927f};
+
+struct K1PpfGeo {
+    static constexpr int T = WM_K1_TILE2, NA = T + WM_K1_HALO;
+    static constexpr int NSTG = 2 * (2 * NA + 24);                    /* words: float2 per input sample */
+    static constexpr int YD = NA + 8, YM = NA + NA / 16 + 4;
+    static constexpr size_t smem() { return (size_t)(NSTG + YD + 256) * 4; }
+};
+
+__global__ __launch_bounds__(256) void k1_demod_ppf(K1Args a)
+{
+    using G = K1PpfGeo;
+    constexpr int T = G::T, NA = G::NA;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2 *stg = (float2 *)smem;                            /* element 0 = input sample 2 (m_first - 12) */
+    float *yMg = (float *)smem;                              /* overlays the staging after stage A */
+    float *yDr = (float *)smem + G::NSTG;
+    float *sFin = yDr + G::YD, *sHead = sFin + 128;
+
+    const WmPush &g = a.g;
+    const int tid = threadIdx.x;
+    const int tile = a.relist ? (int)(a.relist[blockIdx.x] % a.ntiles) : (int)blockIdx.x;
+    const int stream = a.relist ? (int)(a.relist[blockIdx.x] / a.ntiles) : (int)blockIdx.y;
+    const int ts = tile * T;
+    const int tn = min(T, (int)g.M - ts);
+    const bool chT = g.flags & WM_F_T1C1, chS = g.flags & WM_F_S1;
+    const bool accurate = g.flags & WM_F_ACCURATE;
+
+    /* ---- stage 0: bytes -> floats (rtl_wmbus.c:1312-1313), no truncation on this path; samples
+     * before the start of the stream are the filters' zero history, not the byte the input window
+     * was pre-filled with ---------------------------------------------------------------------- */
+    {
+        const long n_first = 2L * ((long)(g.m0 + (uint64_t)ts) - WM_K1_HALO - 1 - 11);     /* global input index of element 0 */
+        const long r_lo = n_first - (long)g.n0;                                            /* even: n0 is a multiple of 2048 */
+        const uint8_t *base = g.in + (uint64_t)stream * g.in_stride + WM_HIST_BYTES;
+        const uint32_t *src = (const uint32_t *)(base + 2 * r_lo);
+        constexpr int NDW = (2 * NA + 24) / 2;
+        for (int u = tid; u < NDW; u += 256) {
+            const uint32_t w = src[u];
+            const bool live = n_first + 2L * u >= 0;
+            float4 v;
+            v.x = live ? wm_sub((float)(w & 0xFFu), 127.5f) : 0.0f;
+            v.y = live ? wm_sub((float)((w >> 8) & 0xFFu), 127.5f) : 0.0f;
+            v.z = live ? wm_sub((float)((w >> 16) & 0xFFu), 127.5f) : 0.0f;
+            v.w = live ? wm_sub((float)(w >> 24), 127.5f) : 0.0f;
+            *(float4 *)(stg + 2 * u) = v;
+        }
+    }
+    __syncthreads();
+
+    /* ---- stage A: thread = 4 consecutive decimated samples (+ the one before, for the
+     * discriminator); output j (a = 4 tid - 1 + j) uses staged samples 2 (j + 11 - k) [+ 1] of the
+     * thread's 32-sample window ---------------------------------------------------------------- */
+    float mg[4];
+    {
+        float2 x[32];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const float4 v = *(const float4 *)(stg + 8 * tid + 2 * k);
+            x[2 * k] = make_float2(v.x, v.y); x[2 * k + 1] = make_float2(v.z, v.w);
+        }
+        float fi[5], fq[5];
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            float ei = 0.0f, eq = 0.0f, oi = 0.0f, oq = 0.0f;        /* fir.h:58-67: accumulate from 0, taps ascending */
+#pragma unroll
+            for (int k = 0; k < 12; k++) {
+                const float2 e = x[2 * (j + 11 - k)], o = x[2 * (j + 11 - k) + 1];
+                ei = wm_add(ei, wm_mul(PPF_EVEN[k], e.x)); eq = wm_add(eq, wm_mul(PPF_EVEN[k], e.y));
+                oi = wm_add(oi, wm_mul(PPF_ODD[k], o.x)); oq = wm_add(oq, wm_mul(PPF_ODD[k], o.y));
+            }
+            fi[j] = wm_add(wm_add(0.0f, ei), oi);                     /* ppf.h:49-54: sum = 0; sum += even; sum += odd */
+            fq[j] = wm_add(wm_add(0.0f, eq), oq);
+        }
+        float dr[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float i = fi[j + 1], q = fq[j + 1], pi_ = fi[j], pq_ = fq[j];
+            dr[j] = accurate ? wm_discriminator(i, q, pi_, pq_) : wm_discriminator_fast(i, q, pi_, pq_);
+            mg[j] = wm_sqrt(wm_add(wm_mul(i, i), wm_mul(q, q)));
+        }
+        *(float4 *)(yDr + 4 * tid + 4) = make_float4(dr[0], dr[1], dr[2], dr[3]);
+    }
+    __syncthreads();                                          /* staging data retired */
+    {
+        const int qb = 4 * tid + (tid >> 2);
+#pragma unroll
+        for (int j = 0; j < 4; j++) yMg[qb + j] = mg[j];
+    }
+    k1_stage_b(a, tid, tile, stream, ts, tn, chT, chS, yDr, yDr, yMg, yMg, sFin, sHead);
+}
+
+/* head[tile] must equal tail[tile-1] (or the value carried from the previous push).  One thread
+ * per (tile, row) -- a per-row scan over 2150 tiles is a millisecond of dependent latency -- keeps
+ * the FIRST tile of each row that does not in first_bad[row]; k1_collect turns those into the
+ * repair list (tiles after a bad one cannot be judged before it is repaired). */
+__global__ void k1_verify(const float *head, const float *tail, const float *carry, uint32_t ntiles,
+                          uint32_t rows, uint32_t *first_bad)
+{
+    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;   /* row = chain*S + stream */
+    if (row >= rows) return;
+    const float prev = t ? tail[(uint64_t)(t - 1) * rows + row] : carry[row];
+    if (wm_f2u(head[(uint64_t)t * rows + row]) != wm_f2u(prev)) atomicMin(first_bad + row, t);
+}
+
+__global__ void k1_collect(uint32_t *first_bad, uint32_t ntiles, uint32_t rows, uint32_t S, uint32_t *relist, uint32_t *n_relist)
+{
+    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    const uint32_t t = first_bad[row];
+    if (t < ntiles) { relist[atomicAdd(n_relist, 1u)] = (row % S) * ntiles + t; first_bad[row] = 0xFFFFFFFFu; }
+}
+
+/* every hand-off certified: the last tile's tail becomes the carry of the next push */
+__global__ void k1_commit(const float *tail, float *carry, uint32_t ntiles, uint32_t rows)
+{
+    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row < rows) carry[row] = tail[(uint64_t)(ntiles - 1) * rows + row];
+}
+
+#endif /* WM_K1_DEMOD_H */

@@ -1,0 +1,39 @@
+/* wm_k2_common.h -- what the two framer kernels share: launch arguments and the lane numbering.
+ * Device code, included by wm_kernels.hip (one translation unit, see the overview there). */
+#ifndef WM_K2_COMMON_H
+#define WM_K2_COMMON_H
+
+/* =============================================================================================
+ * K2: sequential lanes over time segments
+ * ===========================================================================================*/
+struct K2Args {
+    WmPush g;
+    const float *dphi;
+    const uint8_t *rssi;
+    uint32_t *bits;            /* [2][S][Mcap/32]                                          */
+    uint32_t *chips;           /* base of this algo's regions: [2][S][nseg_cap][cap]       */
+    uint32_t *counts;          /* [2][S][nseg_cap]                                          */
+    void *st_start;            /* state each segment's main loop started from               */
+    void *st_final;            /* state after the segment's last sample                     */
+    void *st_carry;            /* [2][S] exact state carried from the previous push         */
+    const uint32_t *list;      /* re-run list of lane ids, or nullptr                       */
+    uint32_t n_lanes;
+    uint32_t algo;             /* WMBUS_ALGO_* of this launch                              */
+    uint32_t *err;
+    uint32_t *sync_seen;       /* [2][S][nseg_cap]: set when a pass emitted an access-code chip into the region */
+    /* checkpoints of the speculative pass, every WM_CK_SAMPLES inside a segment: lane state + chips so
+     * far (16 words each).  A re-run stops at the first checkpoint it reproduces: from there on the
+     * speculative pass had already been on the exact trajectory. */
+    uint32_t *ckpt; uint32_t nck;
+};
+
+__device__ __forceinline__ void lane_decode(const WmPush &g, uint32_t algo, uint32_t lane, uint32_t &ch, uint32_t &stream, uint32_t &seg)
+{
+    /* lane = (ch * nseg + seg) * S + stream : neighbouring lanes = neighbouring streams */
+    stream = lane % g.S;
+    const uint32_t r = lane / g.S;
+    seg = r % g.nseg[algo];
+    ch = r / g.nseg[algo];
+}
+
+#endif /* WM_K2_COMMON_H */

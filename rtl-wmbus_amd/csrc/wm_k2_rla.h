@@ -1,0 +1,192 @@
+/* wm_k2_rla.h -- K2 run-length framer lanes.  Uses no wave-level or float intrinsics beyond __ffs and __frcp_rn, so
+ * tests/emu compiles this file for the host and runs it lane by lane against the oracle.
+ * Device code, included by wm_kernels.hip (one translation unit, see the overview there). */
+#ifndef WM_K2_RLA_H
+#define WM_K2_RLA_H
+
+/* Exact truncating signed division for |a| < 2^24, 0 < b < 2^12 via one float reciprocal and a
+ * +-1 fix-up (the hardware integer divide is ~40 instructions and sits on the serial path). */
+__device__ __forceinline__ int wm_sdiv(int a, int b)
+{
+    const unsigned ua = (unsigned)(a < 0 ? -a : a);
+    if (ua >= (1u << 24) || (unsigned)b >= (1u << 12)) return a / b;
+    unsigned q = (unsigned)((float)ua * __frcp_rn((float)b));
+    const int r = (int)ua - (int)(q * (unsigned)b);
+    if (r < 0) q--; else if (r >= b) q++;
+    return a < 0 ? -(int)q : (int)q;
+}
+
+#define WM_RLA_CROW 17           /* words per lane in the run-length kernel's chip staging (16 + 1: conflict-free) */
+/* Deglitch filter for a whole 32-sample block, bit-parallel.  W holds raw slicer bits in time
+ * order: bit 5+k = sample k of the block, bits 0..4 = the five samples before it.
+ *   T1/C1 (rtl_wmbus.c:126-144,733): level = popcount(last 6 raw bits) >= 3, by a bit-sliced adder;
+ *   S1    (rtl_wmbus.c:149-154,644): LUT 0101011101111111 = newest | majority(previous three).
+ * Returns bit k = deglitched level at sample k. */
+__device__ __forceinline__ uint32_t deglitch_block(uint64_t W, bool s1)
+{
+    const uint64_t a0 = W, a1 = W << 1, a2 = W << 2, a3 = W << 3;
+    uint64_t D;
+    if (s1) D = a0 | (a1 & a2) | (a1 & a3) | (a2 & a3);
+    else {
+        const uint64_t a4 = W << 4, a5 = W << 5;
+        const uint64_t x1 = a0 ^ a1, s_1 = x1 ^ a2, c_1 = (a0 & a1) | (a2 & x1);
+        const uint64_t x2 = a3 ^ a4, s_2 = x2 ^ a5, c_2 = (a3 & a4) | (a5 & x2);
+        D = (c_1 & c_2) | ((c_1 ^ c_2) & (s_1 | s_2));          /* s1+s2+2(c1+c2) >= 3 */
+    }
+    return (uint32_t)(D >> 5);
+}
+
+/* Run-length framer lane (rtl_wmbus.c:640-702 S1, :729-803 T1/C1), edge-driven: the per-sample
+ * work (shift, deglitch, compare, count) is done for 32 samples at once with bit operations and
+ * the lane only iterates over the EDGES of the deglitched signal.  A framer reset clears the raw
+ * history (rtl_wmbus.c:632,723), so after one the remaining levels of the block are recomputed
+ * from the masked history.  WmRlaState.raw keeps the last five raw bits in time order. */
+struct RlaLds { uint32_t chip[64 * WM_RLA_WPB * WM_RLA_CROW]; };     /* lane-private staging; the block's waves are independent */
+
+__device__ __forceinline__ void rla_lanes(const K2Args &a, const uint32_t block_id, RlaLds &lds)
+{
+    uint32_t *s_chip = lds.chip;
+    uint32_t lane = block_id * (64 * WM_RLA_WPB) + threadIdx.x;
+    if (lane >= a.n_lanes) return;
+    const bool rerun = a.list != nullptr;
+    if (rerun) lane = a.list[lane];
+    const WmPush &g = a.g;
+    uint32_t ch, stream, seg;
+    lane_decode(g, 0, lane, ch, stream, seg);
+    if (!(g.flags & (ch ? WM_F_S1 : WM_F_T1C1))) return;
+
+    const uint64_t row = (uint64_t)ch * g.S + stream;
+    const uint64_t sidx = row * g.nseg_cap[0] + seg;
+    const uint32_t mb = seg * g.seg_len[0], me = min(g.M, mb + g.seg_len[0]);
+    const uint32_t cap_rl = g.cap[0];
+    WmRlaState *stS = (WmRlaState *)a.st_start, *stF = (WmRlaState *)a.st_final, *stC = (WmRlaState *)a.st_carry;
+    const WmRlaState reset = {0, 8 * 256, 0, 2u, 0u, 0u, 24, 24};   /* :628-637 / :717-726, reset pending */
+
+    WmRlaState s;
+    uint32_t m;
+    if (rerun) { s = seg ? stF[sidx - 1] : stC[row]; m = mb; }
+    else if (mb <= g.lookback) { s = stC[row]; m = 0; }
+    else { s = reset; m = mb - g.lookback; }
+
+    const uint32_t *bw = a.bits + row * (g.Mcap / 32);
+    uint32_t *out = a.chips + sidx * cap_rl;
+    const bool s1 = ch != 0;
+    const uint32_t syncw = s1 ? WM_SYNC_S1 : WM_SYNC_T1C1, syncm = s1 ? WM_SYNC_S1_MASK : WM_SYNC_T1C1_MASK;
+    const uint32_t hist_mask = s1 ? 0x1Cu : 0x1Fu;       /* S1 looks back 3 samples, T1/C1 5      */
+
+    /* Chips are staged in LDS (16 words per lane) and leave in whole, 32-byte aligned groups of 8:
+     * every lane appends to its own region of HBM, so with half a million lanes in flight the
+     * partially written lines do not stay in L2; 4-byte stores (or unaligned 16-byte ones) turn
+     * into read-modify-write traffic at the memory side and cost 3 of the kernel's 8.4 ms. */
+    uint32_t *my_chip = s_chip + threadIdx.x * WM_RLA_CROW;
+    uint32_t pend = 0, n_fl = 0, saw_sync = 0;               /* staged chips; chips already in HBM (multiple of 8) */
+    auto flush8 = [&]() {                                    /* the oldest 8 staged words -> HBM */
+        uint32_t w[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) w[i] = my_chip[i];
+        if (n_fl + 8u <= cap_rl) {
+            *(uint4 *)(out + n_fl) = make_uint4(w[0], w[1], w[2], w[3]);
+            *(uint4 *)(out + n_fl + 4) = make_uint4(w[4], w[5], w[6], w[7]);
+        }
+        for (uint32_t i = 8; i < pend; i++) my_chip[i - 8] = my_chip[i];
+        n_fl += 8u; pend = pend > 8u ? pend - 8u : 0u;
+    };
+
+    /* slicer words arrive 8 at a time (one aligned 32-byte sector per lane and 256 samples; single
+     * words cost a sector of HBM traffic each); the next group is in flight while this one is used */
+    uint32_t grp = m >> 8;                                   /* group (256 samples) the lane is in */
+    uint4 wq0 = *(const uint4 *)(bw + 8u * grp), wq1 = *(const uint4 *)(bw + 8u * grp + 4), nq0 = {}, nq1 = {};
+    auto fetch_group = [&](uint32_t gq) {                    /* rows hold whole groups (Mcap is a multiple of 256) */
+        if (gq * 256u < g.Mcap) { nq0 = *(const uint4 *)(bw + 8u * gq); nq1 = *(const uint4 *)(bw + 8u * gq + 4); }
+    };
+    fetch_group(grp + 1u);
+    auto block = [&](const bool emit) {
+        const uint32_t sub = (m >> 5) & 7u;
+        const uint32_t wsel[8] = {wq0.x, wq0.y, wq0.z, wq0.w, wq1.x, wq1.y, wq1.z, wq1.w};
+        uint32_t word = wsel[0];
+#pragma unroll
+        for (int i = 1; i < 8; i++) word = sub == (uint32_t)i ? wsel[i] : word;
+        const uint32_t kend = min(32u, me - m);
+        const uint32_t valid = kend == 32u ? 0xFFFFFFFFu : ((1u << kend) - 1u);
+        uint64_t W = ((uint64_t)(word & valid) << 5) | (s.raw & hist_mask);
+        uint32_t D = deglitch_block(W, s1);
+        uint32_t k0 = 0;
+        while (k0 < kend) {
+            const uint32_t level = s.state & 1u;
+            const uint32_t x = (level ? ~D : D) & valid & (0xFFFFFFFFu << k0);
+            if (!x) { s.run += (int)(kend - k0); break; }
+            const uint32_t k = (uint32_t)__ffs((int)x) - 1u;          /* first sample whose level differs */
+            s.run += (int)(k - k0);
+            int unit = 0, half = 0;
+            const int run0 = s.run;
+            bool rst;
+            if (!s1) {
+                rst = s.run < 5;                                                             /* :742 */
+                if (!rst) { s.run *= 256; unit = s.bitlen; half = unit / 2; rst = s.run <= half; }   /* :752-756 */
+            } else {
+                unit = (s.spb0 + s.spb1) / 2;
+                rst = unit <= 12 || unit >= 36;                                              /* :659 */
+                if (!rst) { half = unit / 2; rst = run0 <= half; }                           /* :671 */
+            }
+            if (rst) {
+                s = reset;
+                W &= ~((2ull << (5u + k)) - 1ull);       /* raw history cleared, incl. sample k */
+                D = deglitch_block(W, s1);
+            } else {
+                int n = 0;
+                while (s.run > half && n < (int)WM_RLA_RUN_LIMIT) {                          /* :765-779 / :680-694 */
+                    s.run -= unit;
+                    s.sr = ((s.sr << 1) | level) & syncm;
+                    if (emit) {
+                        const uint32_t val = level | (s.sr == syncw ? 2u : 0u) | ((s.state & 2u) ? 4u : 0u);
+                        saw_sync |= val & 2u;
+                        my_chip[pend] = WM_CHIP_WORD(m + k - mb, val);
+                        if (++pend == 16u) flush8();         /* a long run can emit many chips at one edge */
+                    }
+                    s.state &= ~2u;                        /* reset marker travels with the first chip */
+                    n++;
+                }
+                if (s.run > half) {
+                    /* A run of more than WM_RLA_RUN_LIMIT chips (exact silence, then an edge): a packet
+                     * decoder consumes at most 16*290 chips after an access code, and identical chips
+                     * cannot complete one, so the rest of the run need not be materialised -- only
+                     * counted, as the reference's loop would. */
+                    const int k = (s.run - half + unit - 1) / unit;
+                    s.run -= k * unit; n += k;
+                    s.sr = level ? syncm : 0u;
+                }
+                if (!s1) {
+                    s.cum += s.run;
+                    s.bitlen += wm_sdiv(s.run + s.cum / 16, 32 * n);                         /* :792-796 */
+                } else {
+                    const int v = wm_sdiv(run0, n);                                          /* :698 */
+                    if (level) s.spb1 = v; else s.spb0 = v;
+                }
+            }
+            s.state = (s.state & 2u) | (level ^ 1u);
+            s.run = 1;
+            k0 = k + 1u;
+        }
+        s.raw = (uint32_t)(W >> kend) & hist_mask;        /* the five newest raw bits, time order */
+        if (sub == 7u) { wq0 = nq0; wq1 = nq1; grp++; fetch_group(grp + 1u); }
+        if (emit && pend >= 8u) flush8();
+        m += 32;
+    };
+    while (m < mb) block(false);                         /* speculative look-back: no stores at all */
+    stS[sidx] = s;
+    while (m < me) block(true);
+    const uint32_t n_out = n_fl + pend;
+    while (pend) flush8();                               /* last group: the slots beyond n_out are never read */
+    stF[sidx] = s;
+    a.counts[sidx] = n_out;
+    if (saw_sync) a.sync_seen[sidx] = 1u;
+    if (n_out > cap_rl) atomicOr(a.err, WM_ERR_CHIP_OVERFLOW);
+}
+
+__global__ __launch_bounds__(64 * WM_RLA_WPB) void k2_rla(K2Args a)
+{
+    __shared__ RlaLds lds;
+    rla_lanes(a, blockIdx.x, lds);
+}
+
+#endif /* WM_K2_RLA_H */
