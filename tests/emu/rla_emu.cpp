@@ -1,0 +1,87 @@
+/* rla_emu.cpp -- TEST INFRASTRUCTURE (never part of the product): the run-length framer's device
+ * code (rtl-wmbus_amd/csrc/wm_k2_rla.h, the very source hipcc compiles for gfx950) built for the
+ * host behind a small shim and executed lane by lane, with the speculative-start / verify / re-run
+ * loop of wm_api.hip's run_segments around it.  Lanes of this kernel never talk to each other (no
+ * barrier, no shuffle), so running them one after the other is the same computation.  Purpose: the
+ * framer logic can be checked against the oracle -- and changed -- on a box without a GPU; the GPU
+ * tests remain the proof for the compiled kernel. */
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+/* ---- the shim: what the device header needs from the HIP language ---------------------------- */
+#define __device__
+#define __global__
+#define __forceinline__ inline
+#define __launch_bounds__(x)
+#define __shared__ static
+struct uint4 { uint32_t x, y, z, w; };
+static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
+struct Idx3 { uint32_t x, y, z; };
+static Idx3 threadIdx, blockIdx;
+static inline int __ffs(int v) { return __builtin_ffs(v); }
+static inline float __frcp_rn(float x) { return 1.0f / x; }          /* correctly rounded on both sides */
+static inline uint32_t atomicOr(uint32_t *p, uint32_t v) { const uint32_t o = *p; *p |= v; return o; }
+using std::min;
+
+#include "wm_dev.h"
+#include "wm_k2_common.h"
+#include "wm_k2_rla.h"
+
+extern "C" {
+
+/* One push of `M` decimated samples for S captures.  bits: [2][S][Mcap/32] slicer words; carry:
+ * [2][S] WmRlaState in/out (zero-initialised = the reset state is NOT implied: pass what
+ * wmbus_open would, see rla_reset_state).  chips: [2][S][nseg][cap], counts: [2][S][nseg].
+ * Returns the number of re-run lanes (all rounds), or -1 if verification did not converge. */
+long wm_emu_rla(const uint32_t *bits, uint32_t S, uint32_t M, uint32_t Mcap, uint32_t flags, uint32_t seg_len,
+                uint32_t lookback, uint32_t cap, void *carry, uint32_t *chips, uint32_t *counts, uint32_t *err_out)
+{
+    WmPush g{};
+    g.M = M; g.Mcap = Mcap; g.S = S; g.flags = flags; g.d = 2;
+    g.seg_len[0] = seg_len; g.nseg[0] = (M + seg_len - 1) / seg_len; g.nseg_cap[0] = g.nseg[0]; g.cap[0] = cap;
+    g.lookback = lookback;
+    const uint32_t rows = 2 * S, nseg = g.nseg[0], lanes = rows * nseg;
+    std::vector<WmRlaState> st_start((size_t)rows * nseg), st_final((size_t)rows * nseg);
+    std::vector<uint32_t> seen((size_t)rows * nseg, 0), list;
+    uint32_t err = 0;
+    K2Args a{};
+    a.g = g; a.bits = const_cast<uint32_t *>(bits); a.chips = chips; a.counts = counts;
+    a.st_start = st_start.data(); a.st_final = st_final.data(); a.st_carry = carry;
+    a.algo = 0; a.err = &err; a.sync_seen = seen.data();
+    static RlaLds lds;
+    const uint32_t B = 64 * WM_RLA_WPB;
+    auto launch = [&](const uint32_t *lst, uint32_t n) {
+        a.list = lst; a.n_lanes = n;
+        for (uint32_t b = 0; b < (n + B - 1) / B; b++)
+            for (uint32_t t = 0; t < B; t++) { threadIdx.x = t; rla_lanes(a, b, lds); }
+    };
+    launch(nullptr, lanes);
+    long reruns = 0;
+    for (uint32_t round = 0;; round++) {
+        list.clear();
+        for (uint32_t lane = 0; lane < lanes; lane++) {                  /* k2_verify */
+            uint32_t ch, stream, seg;
+            lane_decode(g, 0, lane, ch, stream, seg);
+            if (!(g.flags & (ch ? WM_F_S1 : WM_F_T1C1)) || seg == 0) continue;
+            const size_t sidx = ((size_t)ch * S + stream) * nseg + seg;
+            if (std::memcmp(&st_start[sidx], &st_final[sidx - 1], sizeof(WmRlaState))) list.push_back(lane);
+        }
+        if (list.empty()) break;
+        if (round > nseg + 1) return -1;
+        reruns += (long)list.size();
+        launch(list.data(), (uint32_t)list.size());
+    }
+    WmRlaState *c = (WmRlaState *)carry;                                 /* k_carry */
+    for (uint32_t r = 0; r < rows; r++) c[r] = st_final[(size_t)r * nseg + nseg - 1];
+    if (err_out) *err_out = err;
+    return reruns;
+}
+
+/* the state a fresh context starts from (wm_api.hip: wmbus_open / rtl_wmbus.c:628-637,717-726) */
+void wm_emu_rla_reset_state(void *st) { const WmRlaState r = {0, 8 * 256, 0, 0u, 0u, 0u, 24, 24}; *(WmRlaState *)st = r; }
+unsigned wm_emu_rla_state_bytes(void) { return sizeof(WmRlaState); }
+unsigned wm_emu_chip_pos_shift(void) { return 3; }
+
+}

@@ -1,0 +1,99 @@
+"""The run-length framer's DEVICE SOURCE (rtl-wmbus_amd/csrc/wm_k2_rla.h) compiled for the host and
+run lane by lane (tests/emu/rla_emu.cpp) against the oracle's run-length chips: speculative starts,
+hand-off verification and re-runs included.  Needs no GPU; the GPU suite checks the compiled kernel."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from cases import flags_to_oracle_opts
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SO = os.path.join(HERE, "emu", "librla_emu.so")
+SRC = os.path.join(HERE, "emu", "rla_emu.cpp")
+CSRC = os.path.join(ROOT, "rtl-wmbus_amd", "csrc")
+F_T1C1, F_S1 = 8, 16                                     # WM_F_* of wm_dev.h
+
+
+@pytest.fixture(scope="module")
+def emu():
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("wm_k2_rla.h", "wm_k2_common.h", "wm_dev.h")]
+    if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I" + CSRC, "-Wno-unknown-pragmas", "-o", SO, SRC], check=True)
+    L = ctypes.CDLL(SO)
+    L.wm_emu_rla.restype = ctypes.c_long
+    L.wm_emu_rla.argtypes = [ctypes.c_void_p] + [ctypes.c_uint] * 7 + [ctypes.c_void_p] * 4
+    L.wm_emu_rla_state_bytes.restype = ctypes.c_uint
+    L.wm_emu_rla_reset_state.argtypes = [ctypes.c_void_p]
+    return L
+
+
+def run_emulated(emu, bit_rows, pushes, seg_len, lookback, flags=F_T1C1 | F_S1):
+    """bit_rows: [2][M] uint8 slicer bits of one capture; pushes: decimated samples per push."""
+    sb = emu.wm_emu_rla_state_bytes()
+    carry = np.zeros(2 * sb, np.uint8)
+    for r in range(2):
+        emu.wm_emu_rla_reset_state(carry[r * sb:].ctypes.data)
+    out, m0, reruns = [[], []], 0, 0
+    cap = seg_len + 8 + 8192
+    for M in pushes:
+        Mcap = (M + 255) // 256 * 256
+        words = np.zeros((2, Mcap // 32), np.uint32)
+        for ch in range(2):
+            b = np.zeros(Mcap, np.uint8)
+            b[:M] = bit_rows[ch][m0:m0 + M]
+            words[ch] = np.packbits(b.reshape(-1, 32), axis=1, bitorder="little").view(np.uint32).ravel()
+        nseg = (M + seg_len - 1) // seg_len
+        chips = np.zeros((2, nseg, cap), np.uint32)
+        counts = np.zeros((2, nseg), np.uint32)
+        err = ctypes.c_uint(0)
+        r = emu.wm_emu_rla(words.ctypes.data, 1, M, Mcap, flags, seg_len, lookback, cap, carry.ctypes.data,
+                           chips.ctypes.data, counts.ctypes.data, ctypes.byref(err))
+        assert r >= 0 and err.value == 0
+        reruns += r
+        for ch in range(2):
+            for s in range(nseg):
+                w = chips[ch, s, :counts[ch, s]]
+                out[ch].append(np.stack([m0 + s * seg_len + (w >> 3), w & 7], axis=1))
+        m0 += M
+    return [np.concatenate(o) if o else np.zeros((0, 2), np.uint32) for o in out], reruns
+
+
+def oracle_rla_chips(ref, ch):
+    oc = ref["chips"][(ref["chips"]["chain"] == ch) & (ref["chips"]["algo"] == 0)]
+    return np.stack([oc["sample"].astype(np.uint32), oc["value"].astype(np.uint32)], axis=1)
+
+
+@pytest.mark.parametrize("seg_len,lookback", [(8192, 1024), (1024, 64), (2048, 32)])
+def test_device_source_on_host_matches_oracle_bundled_capture(emu, oracle, samples, seg_len, lookback):
+    cu8 = samples["samples2"]
+    ref = oracle.run(cu8, flags_to_oracle_opts(oracle, ["-v"]), taps=True, chips=True)
+    got, reruns = run_emulated(emu, ref["bit"], [ref["m"]], seg_len, lookback)
+    for ch in (0, 1):
+        assert np.array_equal(got[ch], oracle_rla_chips(ref, ch)), ch
+    if seg_len < 8192:
+        assert reruns > 0                                    # the re-run path really ran
+
+
+def test_device_source_on_host_matches_oracle_across_pushes_and_synthetic(emu, oracle, wm):
+    rng = np.random.default_rng(5)
+    for k in range(6):
+        cu8 = wm.synth_capture(seed=900 + k, n_samples=1 << 18, kinds=15, frames_per_s=120.0, amplitude=float(rng.choice([8.0, 25.0, 60.0])))[0]
+        if k % 2:                                            # a stretch of exact silence (long runs, resets)
+            a = int(rng.integers(0, cu8.size // 2)) & ~1
+            cu8[a:a + int(rng.integers(4096, cu8.size // 3))] = 128
+        ref = oracle.run(cu8, flags_to_oracle_opts(oracle, ["-v"]), taps=True, chips=True)
+        M = ref["m"]
+        cuts = sorted(set(int(x) // 2048 * 2048 for x in rng.integers(2048, M, 3)))        # pushes are multiples of 4096 B = 2048 IQ = 1024 decimated
+        pushes = [b - a for a, b in zip([0] + cuts, cuts + [M]) if b > a]
+        got, _ = run_emulated(emu, ref["bit"], pushes, int(rng.choice([1024, 4096, 8192])), int(rng.choice([32, 256, 1024])))
+        for ch in (0, 1):
+            want = oracle_rla_chips(ref, ch)
+            # the kernel materialises at most 8192 chips per edge (tests/test_gpu_fuzz.py: truncate_runs)
+            new_edge = np.concatenate([[True], want[1:, 0] != want[:-1, 0]]) if len(want) else np.zeros(0, bool)
+            start = np.maximum.accumulate(np.where(new_edge, np.arange(len(want)), 0)) if len(want) else np.zeros(0, int)
+            want = want[np.arange(len(want)) - start < 8192]
+            assert np.array_equal(got[ch], want), (k, ch)
