@@ -36,6 +36,21 @@ __device__ __forceinline__ uint32_t deglitch_block(uint64_t W, bool s1)
     return (uint32_t)(D >> 5);
 }
 
+/* The same filter on a short word (history in bits 0..4, at most 27 samples): 32-bit operations. */
+__device__ __forceinline__ uint32_t deglitch_word(uint32_t W, bool s1)
+{
+    const uint32_t a0 = W, a1 = W << 1, a2 = W << 2, a3 = W << 3;
+    uint32_t D;
+    if (s1) D = a0 | (a1 & a2) | (a1 & a3) | (a2 & a3);
+    else {
+        const uint32_t a4 = W << 4, a5 = W << 5;
+        const uint32_t x1 = a0 ^ a1, s_1 = x1 ^ a2, c_1 = (a0 & a1) | (a2 & x1);
+        const uint32_t x2 = a3 ^ a4, s_2 = x2 ^ a5, c_2 = (a3 & a4) | (a5 & x2);
+        D = (c_1 & c_2) | ((c_1 ^ c_2) & (s_1 | s_2));
+    }
+    return D >> 5;
+}
+
 /* Run-length framer lane (rtl_wmbus.c:640-702 S1, :729-803 T1/C1), edge-driven: the per-sample
  * work (shift, deglitch, compare, count) is done for 32 samples at once with bit operations and
  * the lane only iterates over the EDGES of the deglitched signal.  A framer reset clears the raw
@@ -117,47 +132,51 @@ __device__ __forceinline__ void rla_lanes(const K2Args &a, const uint32_t block_
             if (!x) { s.run += (int)(kend - k0); break; }
             const uint32_t k = (uint32_t)__ffs((int)x) - 1u;          /* first sample whose level differs */
             s.run += (int)(k - k0);
-            int unit = 0, half = 0;
+            /* Everything below is written for a wave whose 64 lanes take DIFFERENT paths at almost every
+             * edge (a path one lane in fifty takes is taken by the wave nearly every time): no
+             * data-dependent loop for the common cases, and the rare ones kept short. */
             const int run0 = s.run;
+            int unit, half, runq;                        /* runq: the run in the units the chip clock counts in */
             bool rst;
-            if (!s1) {
-                rst = s.run < 5;                                                             /* :742 */
-                if (!rst) { s.run *= 256; unit = s.bitlen; half = unit / 2; rst = s.run <= half; }   /* :752-756 */
-            } else {
-                unit = (s.spb0 + s.spb1) / 2;
-                rst = unit <= 12 || unit >= 36;                                              /* :659 */
-                if (!rst) { half = unit / 2; rst = run0 <= half; }                           /* :671 */
-            }
+            if (!s1) { unit = s.bitlen; half = unit / 2; runq = run0 * 256; rst = run0 < 5 || runq <= half; }   /* :742, :752-756 */
+            else { unit = (s.spb0 + s.spb1) / 2; half = unit / 2; runq = run0; rst = unit <= 12 || unit >= 36 || run0 <= half; }   /* :659, :671 */
             if (rst) {
                 s = reset;
                 W &= ~((2ull << (5u + k)) - 1ull);       /* raw history cleared, incl. sample k */
-                D = deglitch_block(W, s1);
+                /* only the next five levels still look at cleared history: patch those instead of
+                 * deglitching the whole block again */
+                const uint32_t v5 = (uint32_t)(W >> (6u + k)) & 0x1Fu;                  /* raw samples k+1 .. k+5 */
+                const uint64_t pm = 0x1Full << (k + 1u);
+                D = (uint32_t)(((uint64_t)D & ~pm) | ((uint64_t)(deglitch_word(v5 << 5, s1) & 0x1Fu) << (k + 1u)));
             } else {
-                int n = 0;
-                while (s.run > half && n < (int)WM_RLA_RUN_LIMIT) {                          /* :765-779 / :680-694 */
-                    s.run -= unit;
-                    s.sr = ((s.sr << 1) | level) & syncm;
-                    if (emit) {
-                        const uint32_t val = level | (s.sr == syncw ? 2u : 0u) | ((s.state & 2u) ? 4u : 0u);
+                /* chips of this run: the reference counts the run down chip by chip (:765-779 / :680-694),
+                 * i.e. n = ceil((run - half) / unit) >= 1 */
+                const int n = wm_sdiv(runq - half + unit - 1, unit);
+                const uint32_t n_emit = (uint32_t)min(n, (int)WM_RLA_RUN_LIMIT);
+                /* A run of more than WM_RLA_RUN_LIMIT chips (exact silence, then an edge): a packet
+                 * decoder consumes at most 16*290 chips after an access code, and identical chips
+                 * cannot complete one, so the rest of the run is not materialised -- only counted, as
+                 * the reference's loop would. */
+                if (emit) {
+                    uint32_t mark = (s.state & 2u) ? 4u : 0u;                            /* reset marker travels with the first chip */
+                    for (uint32_t i = 0; i < n_emit; i++) {
+                        s.sr = ((s.sr << 1) | level) & syncm;
+                        const uint32_t val = level | (s.sr == syncw ? 2u : 0u) | mark;
+                        mark = 0u;
                         saw_sync |= val & 2u;
                         my_chip[pend] = WM_CHIP_WORD(m + k - mb, val);
                         if (++pend == 16u) flush8();         /* a long run can emit many chips at one edge */
                     }
-                    s.state &= ~2u;                        /* reset marker travels with the first chip */
-                    n++;
+                    if ((uint32_t)n > n_emit) s.sr = level ? syncm : 0u;
+                } else {                                     /* look-back: only the shift register matters */
+                    const uint32_t sh = n_emit < 24u ? n_emit : 24u;
+                    s.sr = ((s.sr << sh) | (level ? (1u << sh) - 1u : 0u)) & syncm;
                 }
-                if (s.run > half) {
-                    /* A run of more than WM_RLA_RUN_LIMIT chips (exact silence, then an edge): a packet
-                     * decoder consumes at most 16*290 chips after an access code, and identical chips
-                     * cannot complete one, so the rest of the run need not be materialised -- only
-                     * counted, as the reference's loop would. */
-                    const int k = (s.run - half + unit - 1) / unit;
-                    s.run -= k * unit; n += k;
-                    s.sr = level ? syncm : 0u;
-                }
+                s.state &= ~2u;
+                const int rest = runq - n * unit;            /* what the count-down leaves: (half - unit, half] */
                 if (!s1) {
-                    s.cum += s.run;
-                    s.bitlen += wm_sdiv(s.run + s.cum / 16, 32 * n);                         /* :792-796 */
+                    s.cum += rest;
+                    s.bitlen += wm_sdiv(rest + s.cum / 16, 32 * n);                          /* :792-796 */
                 } else {
                     const int v = wm_sdiv(run0, n);                                          /* :698 */
                     if (level) s.spb1 = v; else s.spb0 = v;

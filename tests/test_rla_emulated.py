@@ -79,12 +79,22 @@ def test_device_source_on_host_matches_oracle_bundled_capture(emu, oracle, sampl
 
 
 def test_device_source_on_host_matches_oracle_across_pushes_and_synthetic(emu, oracle, wm):
-    rng = np.random.default_rng(5)
-    for k in range(6):
-        cu8 = wm.synth_capture(seed=900 + k, n_samples=1 << 18, kinds=15, frames_per_s=120.0, amplitude=float(rng.choice([8.0, 25.0, 60.0])))[0]
+    rng = np.random.default_rng(5 + int(os.environ.get("WMBUS_EMU_SEED", "0")))
+    for k in range(int(os.environ.get("WMBUS_EMU_N", "8"))):          # more for a bug hunt
+        cu8 = wm.synth_capture(seed=int(rng.integers(1, 1 << 30)), n_samples=1 << 18, kinds=int(rng.choice([15, 15, 8, 7])), frames_per_s=120.0,
+                               amplitude=float(rng.choice([8.0, 25.0, 60.0])), noise_sigma=float(rng.choice([0.5, 3.0, 3.0, 10.0])))[0]
         if k % 2:                                            # a stretch of exact silence (long runs, resets)
             a = int(rng.integers(0, cu8.size // 2)) & ~1
-            cu8[a:a + int(rng.integers(4096, cu8.size // 3))] = 128
+            cu8[a:a + int(rng.integers(4096, cu8.size // 3))] = int(rng.choice([127, 128]))
+        if k % 7 == 6:                                       # silence longer than WM_RLA_RUN_LIMIT chips, then signal again
+            cu8[cu8.size // 16 & ~1: cu8.size * 15 // 16 & ~1] = 128
+        if k % 5 == 4:                                       # a slow square wave: chips far off the nominal rate
+            a = int(rng.integers(0, cu8.size // 2)) & ~1
+            per = int(rng.integers(3, 200))
+            n_sq = min(cu8.size - a, 60000) // 2
+            ph = (np.arange(n_sq) // per) % 2
+            cu8[a:a + 2 * n_sq:2] = 128 + 60 * np.cos(2 * np.pi * 0.03 * np.arange(n_sq) * (2 * ph - 1))
+            cu8[a + 1:a + 2 * n_sq:2] = 128 + 60 * np.sin(2 * np.pi * 0.03 * np.arange(n_sq) * (2 * ph - 1))
         ref = oracle.run(cu8, flags_to_oracle_opts(oracle, ["-v"]), taps=True, chips=True)
         M = ref["m"]
         cuts = sorted(set(int(x) // 2048 * 2048 for x in rng.integers(2048, M, 3)))        # pushes are multiples of 4096 B = 2048 IQ = 1024 decimated
