@@ -81,7 +81,7 @@ __device__ __forceinline__ void rla_lanes(const K2Args &a, const uint32_t block_
     uint32_t m;
     if (rerun) { s = seg ? stF[sidx - 1] : stC[row]; m = mb; }
     else if (mb <= g.lookback) { s = stC[row]; m = 0; }
-    else { s = reset; m = mb - g.lookback; }
+    else { s = reset; m = (mb - g.lookback) & ~63u; }     /* whole 64-sample steps (segments are multiples of 1024) */
 
     const uint32_t *bw = a.bits + row * (g.Mcap / 32);
     uint32_t *out = a.chips + sidx * cap_rl;
@@ -115,22 +115,28 @@ __device__ __forceinline__ void rla_lanes(const K2Args &a, const uint32_t block_
         if (gq * 256u < g.Mcap) { nq0 = *(const uint4 *)(bw + 8u * gq); nq1 = *(const uint4 *)(bw + 8u * gq + 4); }
     };
     fetch_group(grp + 1u);
+    /* One step = 64 samples (two slicer words).  The wave walks its 64 lanes' edges in lock step, so a
+     * step costs the wave the LARGEST edge count among its lanes; over 64 samples that maximum is
+     * relatively smaller than over 32 (T1/C1 in noise: 4.6 edges per 32 samples on average, 11 for the
+     * unluckiest of 64 lanes; 9.3 and 17.7 per 64). */
     auto block = [&](const bool emit) {
-        const uint32_t sub = (m >> 5) & 7u;
-        const uint32_t wsel[8] = {wq0.x, wq0.y, wq0.z, wq0.w, wq1.x, wq1.y, wq1.z, wq1.w};
-        uint32_t word = wsel[0];
+        const uint32_t sub = (m >> 6) & 3u;                  /* word pair within the group of 8 */
+        const uint32_t lo4[4] = {wq0.x, wq0.z, wq1.x, wq1.z}, hi4[4] = {wq0.y, wq0.w, wq1.y, wq1.w};
+        uint32_t w_lo = lo4[0], w_hi = hi4[0];
 #pragma unroll
-        for (int i = 1; i < 8; i++) word = sub == (uint32_t)i ? wsel[i] : word;
-        const uint32_t kend = min(32u, me - m);
-        const uint32_t valid = kend == 32u ? 0xFFFFFFFFu : ((1u << kend) - 1u);
-        uint64_t W = ((uint64_t)(word & valid) << 5) | (s.raw & hist_mask);
-        uint32_t D = deglitch_block(W, s1);
+        for (int i = 1; i < 4; i++) { w_lo = sub == (uint32_t)i ? lo4[i] : w_lo; w_hi = sub == (uint32_t)i ? hi4[i] : w_hi; }
+        const uint32_t kend = min(64u, me - m);
+        const uint64_t valid = kend == 64u ? ~0ull : ((1ull << kend) - 1ull);
+        uint64_t R = (((uint64_t)w_hi << 32) | w_lo) & valid;    /* raw slicer bits, bit j = sample j of the step */
+        uint32_t hist = s.raw & hist_mask;                   /* the five samples before it, bit 4 = newest */
+        uint64_t D = (uint64_t)deglitch_block(((uint64_t)(uint32_t)R << 5) | hist, s1) |
+                     ((uint64_t)deglitch_block(((R >> 32) << 5) | ((uint32_t)R >> 27), s1) << 32);
         uint32_t k0 = 0;
         while (k0 < kend) {
             const uint32_t level = s.state & 1u;
-            const uint32_t x = (level ? ~D : D) & valid & (0xFFFFFFFFu << k0);
+            const uint64_t x = (level ? ~D : D) & valid & (~0ull << k0);
             if (!x) { s.run += (int)(kend - k0); break; }
-            const uint32_t k = (uint32_t)__ffs((int)x) - 1u;          /* first sample whose level differs */
+            const uint32_t k = (uint32_t)__ffsll((long long)x) - 1u;  /* first sample whose level differs */
             s.run += (int)(k - k0);
             /* Everything below is written for a wave whose 64 lanes take DIFFERENT paths at almost every
              * edge (a path one lane in fifty takes is taken by the wave nearly every time): no
@@ -142,12 +148,12 @@ __device__ __forceinline__ void rla_lanes(const K2Args &a, const uint32_t block_
             else { unit = (s.spb0 + s.spb1) / 2; half = unit / 2; runq = run0; rst = unit <= 12 || unit >= 36 || run0 <= half; }   /* :659, :671 */
             if (rst) {
                 s = reset;
-                W &= ~((2ull << (5u + k)) - 1ull);       /* raw history cleared, incl. sample k */
+                R &= ~((2ull << k) - 1ull); hist = 0;    /* raw history cleared, incl. sample k (k = 63: everything) */
                 /* only the next five levels still look at cleared history: patch those instead of
-                 * deglitching the whole block again */
-                const uint32_t v5 = (uint32_t)(W >> (6u + k)) & 0x1Fu;                  /* raw samples k+1 .. k+5 */
-                const uint64_t pm = 0x1Full << (k + 1u);
-                D = (uint32_t)(((uint64_t)D & ~pm) | ((uint64_t)(deglitch_word(v5 << 5, s1) & 0x1Fu) << (k + 1u)));
+                 * deglitching the whole step again (shifts by k + 1 <= 64 in two parts) */
+                const uint32_t v5 = (uint32_t)((R >> k) >> 1) & 0x1Fu;                  /* raw samples k+1 .. k+5 */
+                const uint64_t pm = (0x1Full << k) << 1;
+                D = (D & ~pm) | (((uint64_t)(deglitch_word(v5 << 5, s1) & 0x1Fu) << k) << 1);
             } else {
                 /* chips of this run: the reference counts the run down chip by chip (:765-779 / :680-694),
                  * i.e. n = ceil((run - half) / unit) >= 1 */
@@ -186,10 +192,11 @@ __device__ __forceinline__ void rla_lanes(const K2Args &a, const uint32_t block_
             s.run = 1;
             k0 = k + 1u;
         }
-        s.raw = (uint32_t)(W >> kend) & hist_mask;        /* the five newest raw bits, time order */
-        if (sub == 7u) { wq0 = nq0; wq1 = nq1; grp++; fetch_group(grp + 1u); }
+        /* the five newest raw bits, time order (a ragged last step may be shorter than five samples) */
+        s.raw = (kend >= 5u ? (uint32_t)(R >> (kend - 5u)) : (((uint32_t)R << (5u - kend)) | (hist >> kend))) & 0x1Fu & hist_mask;
+        if (sub == 3u) { wq0 = nq0; wq1 = nq1; grp++; fetch_group(grp + 1u); }
         if (emit && pend >= 8u) flush8();
-        m += 32;
+        m += 64;
     };
     while (m < mb) block(false);                         /* speculative look-back: no stores at all */
     stS[sidx] = s;

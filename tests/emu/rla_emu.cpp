@@ -21,6 +21,7 @@ static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
 struct Idx3 { uint32_t x, y, z; };
 static Idx3 threadIdx, blockIdx;
 static inline int __ffs(int v) { return __builtin_ffs(v); }
+static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 static inline float __frcp_rn(float x) { return 1.0f / x; }          /* correctly rounded on both sides */
 static inline uint32_t atomicOr(uint32_t *p, uint32_t v) { const uint32_t o = *p; *p |= v; return o; }
 using std::min;

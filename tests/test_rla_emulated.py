@@ -97,7 +97,9 @@ def test_device_source_on_host_matches_oracle_across_pushes_and_synthetic(emu, o
             cu8[a + 1:a + 2 * n_sq:2] = 128 + 60 * np.sin(2 * np.pi * 0.03 * np.arange(n_sq) * (2 * ph - 1))
         ref = oracle.run(cu8, flags_to_oracle_opts(oracle, ["-v"]), taps=True, chips=True)
         M = ref["m"]
-        cuts = sorted(set(int(x) // 2048 * 2048 for x in rng.integers(2048, M, 3)))        # pushes are multiples of 4096 B = 2048 IQ = 1024 decimated
+        # pushes are multiples of 4096 B = 2048 IQ samples: whole kilo-samples at d = 2, ragged counts at d = 3, 5, ...
+        q = 2048 if k % 3 else 1
+        cuts = sorted(set(int(x) // q * q for x in rng.integers(2048, M, 3)))
         pushes = [b - a for a, b in zip([0] + cuts, cuts + [M]) if b > a]
         got, _ = run_emulated(emu, ref["bit"], pushes, int(rng.choice([1024, 4096, 8192])), int(rng.choice([32, 256, 1024])))
         for ch in (0, 1):
