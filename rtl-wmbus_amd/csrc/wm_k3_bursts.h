@@ -39,8 +39,10 @@ __device__ uint32_t burst_need(uint32_t chain, uint32_t hb, uint32_t nb)
         if (mode != 0x54Cu && mode != 0x543u) return 12u;
         if (nb < 24) return WM_MAXCHIPS_T1C1;
         if (((hb >> 8) & 15u) != 0xDu) return 16u;
-        const uint32_t L = hb & 255u;
-        return 24u + 8u * ((mode == 0x543u ? 1u + L : full_len_a(L)) - 1u);
+        const uint32_t L = hb & 255u, total = mode == 0x543u ? 1u + L : full_len_a(L);
+        /* the decoder looks at the length only after storing a byte: a frame B that claims L = 0 still
+         * takes one byte after its L-field (found by tests/test_burst_need.py) */
+        return 24u + 8u * (total > 2u ? total - 1u : 1u);
     }
     if (nb < 16) return WM_MAXCHIPS_S1;
     uint32_t L = 0;
