@@ -282,6 +282,22 @@ WM_HD float wm_discriminator_fast(float i, float q, float pi_, float pq_)
  * carry: bits(y) + WM_LEVEL_CARRY overflows 32 bits <=> level low. */
 #define WM_LEVEL_CARRY 0x7FFBEE52u      /* 0xFFFFFFFF - (0x80000000 + 266669) */
 WM_HD int wm_level_high(float y) { return (uint64_t)wm_f2u(y) + WM_LEVEL_CARRY <= 0xFFFFFFFFull; }
+/* acc = (acc << 1) | (level LOW), for a word that collects the clock levels of a block: the carry of
+ * the add goes straight into an add-with-carry on the device. */
+#if defined(__HIP_DEVICE_COMPILE__)
+WM_HD uint32_t wm_shift_in_level_low(uint32_t acc, uint32_t ybits)
+{
+    uint32_t tmp;
+    asm("v_add_co_u32 %1, vcc, %3, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+        : "+v"(acc), "=&v"(tmp) : "v"(ybits), "s"(WM_LEVEL_CARRY) : "vcc");
+    return acc;
+}
+#else
+WM_HD uint32_t wm_shift_in_level_low(uint32_t acc, uint32_t ybits)
+{
+    return (acc << 1) | (uint32_t)(((uint64_t)ybits + WM_LEVEL_CARRY) >> 32);
+}
+#endif
 
 /* cu8 sample -> boxcar input (rtl_wmbus.c:1312-1313 then the int parameter of mavgi,
  * moving_average_filter.h:47): (int)((float)u8 - 127.5f), truncation toward zero. */

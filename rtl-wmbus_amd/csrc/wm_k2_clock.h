@@ -120,11 +120,7 @@ __device__ __forceinline__ void clk_block32(WmClkState &s, const IirCoef &c, con
             if (n >= 0 && n < 32) {
                 h2[k] = h1[k]; h1[k] = h0[k];
                 if (k < 2) in[k + 1] = o[k];
-                else {
-                    uint32_t tmp;
-                    asm("v_add_co_u32 %1, vcc, %3, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
-                        : "+v"(low), "=&v"(tmp) : "v"(wm_f2u(o[2])), "s"(WM_LEVEL_CARRY) : "vcc");
-                }
+                else low = wm_shift_in_level_low(low, wm_f2u(o[2]));
             }
         }
         __builtin_amdgcn_sched_barrier(0);

@@ -32,6 +32,8 @@ using std::min;
 
 extern "C" {
 
+int wm_emu_descending = 1;
+
 /* One push of `M` decimated samples for S captures.  bits: [2][S][Mcap/32] slicer words; carry:
  * [2][S] WmRlaState in/out (zero-initialised = the reset state is NOT implied: pass what
  * wmbus_open would, see rla_reset_state).  chips: [2][S][nseg][cap], counts: [2][S][nseg].
@@ -55,8 +57,13 @@ long wm_emu_rla(const uint32_t *bits, uint32_t S, uint32_t M, uint32_t Mcap, uin
     const uint32_t B = 64 * WM_RLA_WPB;
     auto launch = [&](const uint32_t *lst, uint32_t n) {
         a.list = lst; a.n_lanes = n;
-        for (uint32_t b = 0; b < (n + B - 1) / B; b++)
-            for (uint32_t t = 0; t < B; t++) { threadIdx.x = t; rla_lanes(a, b, lds); }
+        /* descending lane order: a re-run lane reads its predecessor's end state before that predecessor's
+         * own re-run of the same launch replaces it, as it mostly happens on the GPU (cascading rounds) */
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t l = wm_emu_descending ? n - 1 - i : i;
+            threadIdx.x = l % B;
+            rla_lanes(a, l / B, lds);
+        }
     };
     launch(nullptr, lanes);
     long reruns = 0;

@@ -1,0 +1,107 @@
+"""The clock-recovery / time2 framer lanes' DEVICE SOURCE (rtl-wmbus_amd/csrc/wm_k2_clock.h) compiled for
+the host and run lane by lane (tests/emu/clock_emu.cpp) against the oracle: slicer bits and time2 chips,
+with speculative cold starts, hand-off verification, re-run rounds, checkpoints / early exit and the
+carry across pushes.  No GPU needed; the GPU suite checks the compiled kernel (and its cooperative loads)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from cases import flags_to_oracle_opts
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(os.path.dirname(HERE), "rtl-wmbus_amd", "csrc")
+SO = os.path.join(HERE, "emu", "libclock_emu.so")
+SRC = os.path.join(HERE, "emu", "clock_emu.cpp")
+F_DC, F_T1C1, F_S1, F_T2A = 4, 8, 16, 64                   # WM_F_* of wm_dev.h
+
+
+@pytest.fixture(scope="module")
+def emu():
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("wm_k2_clock.h", "wm_k2_common.h", "wm_dev.h", "wm_exact.h")]
+    if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-I" + CSRC, "-Wno-unknown-pragmas",
+                        "-o", SO, SRC], check=True)
+    L = ctypes.CDLL(SO)
+    L.wm_emu_clock.restype = ctypes.c_long
+    L.wm_emu_clock.argtypes = [ctypes.c_void_p] + [ctypes.c_uint] * 8 + [ctypes.c_void_p] * 6
+    L.wm_emu_clock_state_bytes.restype = ctypes.c_uint
+    return L
+
+
+def run_emulated(emu, soft_rows, pushes, seg_len, warm, dc=False, descending=True):
+    """soft_rows: [2][M] float32 FIR outputs of one capture; pushes: decimated samples per push."""
+    ctypes.c_int.in_dll(emu, "wm_emu_descending").value = int(descending)   # see clock_emu.cpp: launch semantics
+    sb = emu.wm_emu_clock_state_bytes()
+    carry = np.zeros(2 * sb, np.uint8)                     # a fresh context starts from the all-zero state
+    chips_out, bits_out, m0, reruns, max_rounds = [[], []], [[], []], 0, 0, 0
+    cap = seg_len // 4 + 8
+    flags = F_T1C1 | F_S1 | F_T2A | (F_DC if dc else 0)
+    for M in pushes:
+        Mcap = (M + 255) // 256 * 256
+        x = np.zeros((2, Mcap), np.float32)
+        for ch in range(2):
+            x[ch, :M] = soft_rows[ch][m0:m0 + M]
+        nseg = (M + seg_len - 1) // seg_len
+        bits = np.zeros((2, Mcap // 32), np.uint32)
+        chips = np.zeros((2, nseg, cap), np.uint32)
+        counts = np.zeros((2, nseg), np.uint32)
+        err, rounds = ctypes.c_uint(0), ctypes.c_uint(0)
+        r = emu.wm_emu_clock(x.ctypes.data, 1, M, Mcap, flags, seg_len, warm[0], warm[1], cap, carry.ctypes.data, bits.ctypes.data,
+                             chips.ctypes.data, counts.ctypes.data, ctypes.byref(err), ctypes.byref(rounds))
+        assert r >= 0 and err.value == 0
+        reruns += r
+        max_rounds = max(max_rounds, rounds.value)
+        for ch in range(2):
+            bits_out[ch].append(np.unpackbits(bits[ch].view(np.uint8), bitorder="little")[:M])
+            for s in range(nseg):
+                w = chips[ch, s, :counts[ch, s]]
+                chips_out[ch].append(np.stack([m0 + s * seg_len + (w >> 3), w & 7], axis=1))
+        m0 += M
+    return ([np.concatenate(o) if o else np.zeros((0, 2), np.uint32) for o in chips_out], [np.concatenate(b) for b in bits_out],
+            reruns, max_rounds)
+
+
+def oracle_t2a_chips(ref, ch):
+    oc = ref["chips"][(ref["chips"]["chain"] == ch) & (ref["chips"]["algo"] == 1)]
+    return np.stack([oc["sample"].astype(np.uint32), oc["value"].astype(np.uint32)], axis=1)
+
+
+@pytest.mark.parametrize("seg_len,warm,flags", [(32768, (12288, 24576), ["-v"]), (4096, (512, 512), ["-v"]), (8192, (1024, 2048), ["-v", "-o"]),
+                                                 (2048, (128, 256), ["-v"])])
+def test_device_source_on_host_matches_oracle_bundled_capture(emu, oracle, samples, seg_len, warm, flags):
+    cu8 = samples["samples2"]
+    ref = oracle.run(cu8, flags_to_oracle_opts(oracle, flags), taps=True, chips=True)
+    chips, bits, reruns, rounds = run_emulated(emu, ref["dphi_fir"], [ref["m"]], seg_len, warm, dc="-o" in flags)
+    for ch in (0, 1):
+        assert np.array_equal(bits[ch], ref["bit"][ch]), ("bits", ch)
+        assert np.array_equal(chips[ch], oracle_t2a_chips(ref, ch)), ("chips", ch)
+    if seg_len <= 4096:
+        assert reruns > 0
+
+
+def test_device_source_on_host_matches_oracle_randomised(emu, oracle, wm):
+    rng = np.random.default_rng(9 + int(os.environ.get("WMBUS_EMU_SEED", "0")))
+    multi = 0
+    for k in range(int(os.environ.get("WMBUS_EMU_N", "8"))):               # more for a bug hunt
+        cu8 = wm.synth_capture(seed=int(rng.integers(1, 1 << 30)), n_samples=1 << 18, kinds=int(rng.choice([15, 15, 8, 7])), frames_per_s=120.0,
+                               amplitude=float(rng.choice([8.0, 25.0, 60.0])), noise_sigma=float(rng.choice([0.5, 3.0, 3.0, 10.0])))[0]
+        if k % 3 == 1:
+            a = int(rng.integers(0, cu8.size // 2)) & ~1
+            cu8[a:a + int(rng.integers(4096, cu8.size // 3))] = int(rng.choice([127, 128]))
+        dc = bool(k % 4 == 3)
+        ref = oracle.run(cu8, flags_to_oracle_opts(oracle, ["-v"] + (["-o"] if dc else [])), taps=True, chips=True)
+        M = ref["m"]
+        q = 1024 if k % 3 else 1
+        cuts = sorted(set(int(x) // q * q for x in rng.integers(1024, M, 3)))
+        pushes = [b - a for a, b in zip([0] + cuts, cuts + [M]) if b > a]
+        seg_len = int(rng.choice([2048, 4096, 8192, 32768]))
+        warm = (int(rng.choice([64, 128, 512, 4096, 12288])), int(rng.choice([64, 128, 512, 8192, 24576])))
+        chips, bits, reruns, rounds = run_emulated(emu, ref["dphi_fir"], pushes, seg_len, warm, dc=dc, descending=bool(k % 5))
+        multi += rounds > 1
+        for ch in (0, 1):
+            assert np.array_equal(bits[ch], ref["bit"][ch]), (k, "bits", ch)
+            assert np.array_equal(chips[ch], oracle_t2a_chips(ref, ch)), (k, "chips", ch, seg_len, warm)
+    assert multi > 0                                           # cascading re-run rounds (where the checkpoint bug lived) occurred

@@ -31,8 +31,9 @@ def emu():
     return L
 
 
-def run_emulated(emu, bit_rows, pushes, seg_len, lookback, flags=F_T1C1 | F_S1):
+def run_emulated(emu, bit_rows, pushes, seg_len, lookback, flags=F_T1C1 | F_S1, descending=True):
     """bit_rows: [2][M] uint8 slicer bits of one capture; pushes: decimated samples per push."""
+    ctypes.c_int.in_dll(emu, "wm_emu_descending").value = int(descending)   # see rla_emu.cpp: launch semantics
     sb = emu.wm_emu_rla_state_bytes()
     carry = np.zeros(2 * sb, np.uint8)
     for r in range(2):
@@ -101,7 +102,7 @@ def test_device_source_on_host_matches_oracle_across_pushes_and_synthetic(emu, o
         q = 2048 if k % 3 else 1
         cuts = sorted(set(int(x) // q * q for x in rng.integers(2048, M, 3)))
         pushes = [b - a for a, b in zip([0] + cuts, cuts + [M]) if b > a]
-        got, _ = run_emulated(emu, ref["bit"], pushes, int(rng.choice([1024, 4096, 8192])), int(rng.choice([32, 256, 1024])))
+        got, _ = run_emulated(emu, ref["bit"], pushes, int(rng.choice([1024, 4096, 8192])), int(rng.choice([32, 256, 1024])), descending=bool(k % 5))
         for ch in (0, 1):
             want = oracle_rla_chips(ref, ch)
             # the kernel materialises at most 8192 chips per edge (tests/test_gpu_fuzz.py: truncate_runs)
