@@ -99,6 +99,9 @@ def test_device_source_on_host_matches_oracle_randomised(emu, oracle, wm):
         pushes = [b - a for a, b in zip([0] + cuts, cuts + [M]) if b > a]
         seg_len = int(rng.choice([2048, 4096, 8192, 32768]))
         warm = (int(rng.choice([64, 128, 512, 4096, 12288])), int(rng.choice([64, 128, 512, 8192, 24576])))
+        if os.environ.get("WMBUS_EMU_STRESS"):               # bug hunts: many checkpoints per segment, hopeless warm-ups
+            seg_len = int(rng.choice([4096, 8192, 16384]))
+            warm = (int(rng.choice([32, 64, 256])), int(rng.choice([32, 64, 256])))
         chips, bits, reruns, rounds = run_emulated(emu, ref["dphi_fir"], pushes, seg_len, warm, dc=dc, descending=bool(k % 5))
         multi += rounds > 1
         for ch in (0, 1):
