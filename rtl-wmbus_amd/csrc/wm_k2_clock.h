@@ -149,6 +149,26 @@ __device__ __forceinline__ void clk_block32(WmClkState &s, const IirCoef &c, con
  * WM_CLK_XROW).  Lane-private 16-byte loads of the same data touch 64 lines per instruction and
  * re-fetch each line from L2 several times.  Re-run launches and odd stream counts take the
  * lane-private path. */
+/* The same block, one sample after the other (clk_step): a 36-deep dependent chain per sample instead
+ * of three interleaved ones, but a fraction of the registers.  Candidate for the few re-run lanes of the
+ * fused launch (k2_clock_rla), whose register need is also what its thousand run-length waves are
+ * charged; selected with WM_FUSED_LEAN_CLOCK (off: not measured yet).  Host-emulated against the oracle. */
+template <bool DC>
+__device__ __forceinline__ void clk_block32_lean(WmClkState &s, const IirCoef &c, const float *xrow, uint32_t &bitw, uint32_t &smask)
+{
+    uint32_t bw = 0, sm = 0, hist = s.clk;
+#pragma unroll 1
+    for (uint32_t k = 0; k < 32u; k++) {
+        float soft;
+        const uint32_t high = clk_step(s, c, DC, xrow[k], soft);
+        hist = ((hist << 1) | high) & 0xFu;
+        bw |= (uint32_t)(soft >= 0.0f) << k;
+        sm |= (uint32_t)(hist == 7u) << k;
+    }
+    s.clk = hist & 7u;
+    bitw = bw; smask = sm;
+}
+
 template <int W> struct ClkLds {         /* per block: W independent waves */
     float x[W][64 * WM_CLK_XROW];
     uint32_t chip[W][64 * WM_CLK_CROW];
@@ -160,7 +180,7 @@ template <int W> struct ClkLds {         /* per block: W independent waves */
  * long-running wave on ONE SIMD slows every 4-wave K1 block of that CU down to the pace of the K1
  * wave that shares the SIMD with it (measured: two clock launches in flight, one wave per CU, cost
  * K1 60 %). */
-template <bool DC, int W>
+template <bool DC, int W, bool LEAN = false>
 __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t block, ClkLds<W> &lds)
 {
     const uint32_t ln = threadIdx.x & 63u, wv = threadIdx.x >> 6;
@@ -253,7 +273,7 @@ __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t bloc
         put_x(gx);
         fetch_x(gx, min(m + 64u, m_last));
         uint32_t bitw, smask;
-        clk_block32<DC>(s, c, xrow, bitw, smask);
+        if (LEAN) clk_block32_lean<DC>(s, c, xrow, bitw, smask); else clk_block32<DC>(s, c, xrow, bitw, smask);
         /* shift-register upkeep, loop-free: at most 8 chips per block, oldest first */
 #pragma unroll
         for (int i = 0; i < 8; i++) {
@@ -299,7 +319,7 @@ __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t bloc
         put_x(gx);
         fetch_x(gx, min(m + 64u, m_last));
         uint32_t bitw, smask;
-        clk_block32<DC>(s, c, xrow, bitw, smask);
+        if (LEAN) clk_block32_lean<DC>(s, c, xrow, bitw, smask); else clk_block32<DC>(s, c, xrow, bitw, smask);
         uint32_t cnt = 0;
 #pragma unroll
         for (int i = 0; i < 8; i++) {

@@ -45,10 +45,17 @@
  * LDS cannot be placed while K1 refills the CU with its small blocks (and, once placed, costs K1
  * three of its eight blocks): the few clock blocks of this launch therefore run ONE wave each, in
  * the footprint of a run-length block (17 KB instead of 63 KB). */
-__global__ __launch_bounds__(64 * WM_RLA_WPB) void k2_clock_rla(K2Args clk, K2Args rla, uint32_t clk_blocks)
+/* Build-time experiments for this kernel's register footprint, both off: */
+#ifndef WM_FUSED_WAVES_PER_SIMD
+#define WM_FUSED_WAVES_PER_SIMD 1      /* 4: at most 128 VGPRs (the clock lanes spill a little) */
+#endif
+#ifndef WM_FUSED_LEAN_CLOCK
+#define WM_FUSED_LEAN_CLOCK 0          /* 1: the clock re-run lanes take the per-sample path */
+#endif
+__global__ __launch_bounds__(64 * WM_RLA_WPB, WM_FUSED_WAVES_PER_SIMD) void k2_clock_rla(K2Args clk, K2Args rla, uint32_t clk_blocks)
 {
     __shared__ __attribute__((aligned(16))) union { ClkLds<1> c; RlaLds r; } lds;
-    if (blockIdx.x < clk_blocks) clock_lanes<false, 1>(clk, blockIdx.x, lds.c);
+    if (blockIdx.x < clk_blocks) clock_lanes<false, 1, WM_FUSED_LEAN_CLOCK != 0>(clk, blockIdx.x, lds.c);
     else rla_lanes(rla, blockIdx.x - clk_blocks, lds.r);
 }
 

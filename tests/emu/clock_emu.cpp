@@ -43,6 +43,7 @@ using std::min;
 extern "C" {
 
 int wm_emu_descending = 1;
+int wm_emu_lean_reruns = 0;
 
 /* One push of M decimated samples for S captures.  dphi: [2][S][Mcap] soft symbols; carry: [2][S]
  * WmClkState in/out; bits: [2][S][Mcap/32] out; chips: [2][S][nseg][cap]; counts: [2][S][nseg].
@@ -75,7 +76,10 @@ long wm_emu_clock(const float *dphi, uint32_t S, uint32_t M, uint32_t Mcap, uint
         for (uint32_t i = 0; i < n; i++) {
             const uint32_t l = wm_emu_descending ? n - 1 - i : i;
             threadIdx.x = l & 63u;
-            if (dc) clock_lanes<true, 1>(a, l >> 6, lds); else clock_lanes<false, 1>(a, l >> 6, lds);
+            /* re-run launches may use the lean per-sample block (candidate for the fused launch) */
+            const bool lean = wm_emu_lean_reruns && lst != nullptr;
+            if (dc) { if (lean) clock_lanes<true, 1, true>(a, l >> 6, lds); else clock_lanes<true, 1>(a, l >> 6, lds); }
+            else { if (lean) clock_lanes<false, 1, true>(a, l >> 6, lds); else clock_lanes<false, 1>(a, l >> 6, lds); }
         }
     };
     launch(nullptr, lanes);
