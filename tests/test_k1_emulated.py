@@ -1,0 +1,109 @@
+"""The demodulation kernel's DEVICE SOURCE (rtl-wmbus_amd/csrc/wm_k1_demod.h) compiled for the host with
+clang++ and run block by block on a coroutine block emulator (tests/emu/block_emu.h, k1_emu.cpp): every
+thread of a block is a coroutine, __syncthreads and the wave ballot are scheduling points.  Soft symbols
+bit for bit and RSSI bytes against the oracle, for every compiled decimation, with and without the
++-325 kHz shift, the -a discriminator, several pushes, and the RSSI-filter repair path.  No GPU needed."""
+import ctypes
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from cases import flags_to_oracle_opts
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(os.path.dirname(HERE), "rtl-wmbus_amd", "csrc")
+SO = os.path.join(HERE, "emu", "libk1_emu.so")
+SRC = os.path.join(HERE, "emu", "k1_emu.cpp")
+CLANG = shutil.which("clang++") or "/opt/rocm/lib/llvm/bin/clang++"      # needs clang (ext_vector_type)
+HIST, SLACK = 4096, 256
+F_SHIFT, F_ACCURATE, F_T1C1, F_S1 = 1, 2, 8, 16                        # WM_F_* of wm_dev.h
+FS = {2: 1600, 3: 2400, 4: 3200, 5: 4000, 6: 4800}
+
+
+@pytest.fixture(scope="module")
+def emu():
+    if not os.path.exists(CLANG):
+        pytest.skip("no clang++ for the host build of the device source")
+    deps = [SRC, os.path.join(HERE, "emu", "block_emu.h")] + [os.path.join(CSRC, f) for f in ("wm_k1_demod.h", "wm_dev.h", "wm_exact.h")]
+    if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
+        subprocess.run([CLANG, "-O1", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-I" + CSRC, "-I" + os.path.join(HERE, "emu"),
+                        "-Wno-unknown-pragmas", "-Wno-pass-failed", "-o", SO, SRC], check=True)
+    L = ctypes.CDLL(SO)
+    L.wm_emu_k1.restype = ctypes.c_long
+    L.wm_emu_k1.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint64, ctypes.c_uint,
+                            ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    return L
+
+
+def run_emulated(emu, cu8, d, flags, push_bytes, polyphase=0):
+    """One capture through K1 push by push.  Returns (dphi [2][M] float32, rssi [2][M] uint8, repaired tiles)."""
+    total = cu8.size // 4096 * 4096
+    max_push = max(push_bytes)
+    stride = (HIST + max_push + SLACK + 255) // 256 * 256
+    row = np.full(stride, 128, np.uint8)                   # wmbus_open fills the window with 128 (= zero input)
+    carry = np.zeros(2, np.float32)
+    out_d, out_r, n0, off, repaired = [[], []], [[], []], 0, 0, 0
+    k = 0
+    while off < total:
+        nb = min(push_bytes[k % len(push_bytes)], total - off)
+        k += 1
+        row[HIST:HIST + nb] = cu8[off:off + nb]
+        n_new = nb // 2
+        M = (n0 + n_new) // d - n0 // d
+        ntiles = (M + 975) // 976
+        Mcap = max(256, (ntiles * 976 + 255) // 256 * 256)
+        dphi = np.zeros((2, Mcap), np.float32)
+        rssi = np.zeros((2, Mcap), np.uint8)
+        err = ctypes.c_uint(0)
+        r = emu.wm_emu_k1(row.ctypes.data, stride, 1, d, flags, n0, n_new, Mcap, dphi.ctypes.data, rssi.ctypes.data, carry.ctypes.data, ctypes.byref(err), polyphase)
+        assert r >= 0 and err.value == 0
+        repaired += r
+        for ch in range(2):
+            out_d[ch].append(dphi[ch, :M].copy()); out_r[ch].append(rssi[ch, :M].copy())
+        row[:HIST] = row[nb:nb + HIST].copy()              # k_roll_history
+        n0 += n_new; off += nb
+    return [np.concatenate(x) for x in out_d], [np.concatenate(x) for x in out_r], repaired
+
+
+def check(emu, oracle, cu8, flags_cli, d, pushes, polyphase=0):
+    oo = flags_to_oracle_opts(oracle, flags_cli)
+    oo.prefilter = polyphase
+    ref = oracle.run(cu8, oo, taps=True)
+    flags = F_T1C1 | F_S1 | (F_SHIFT if "-s" in flags_cli else 0) | (0 if "-a" in flags_cli else F_ACCURATE)   # -a = the fast discriminator
+    dphi, rssi, repaired = run_emulated(emu, cu8, d, flags, pushes, polyphase)
+    for ch in (0, 1):
+        assert len(dphi[ch]) == ref["m"]
+        assert np.array_equal(dphi[ch].view(np.uint32), ref["dphi_fir"][ch].view(np.uint32)), ("dphi", ch, flags_cli)
+        assert np.array_equal(rssi[ch], ref["rssi"][ch].astype(np.uint32).astype(np.uint8)), ("rssi", ch, flags_cli)
+    return repaired
+
+
+@pytest.mark.parametrize("flags_cli", [["-v"], ["-v", "-a"], ["-v", "-s"]])
+def test_device_source_on_host_matches_oracle_bundled_capture(emu, oracle, samples, flags_cli):
+    cu8 = samples["samples2"][: 1 << 19]                   # a quarter of the capture: the emulation runs ~0.3 M samples/s
+    check(emu, oracle, cu8, flags_cli, 2, [cu8.size])
+
+
+@pytest.mark.parametrize("d,extra", [(3, []), (4, ["-s"]), (5, ["-s"]), (6, []), (2, [])])
+def test_device_source_on_host_matches_oracle_decimations_and_pushes(emu, oracle, wm, d, extra):
+    kw = dict(t1c1_center_khz=325.0, s1_center_khz=-325.0) if "-s" in extra else {}
+    cu8 = wm.synth_capture(seed=400 + d, n_samples=3 << 16, fs_khz=FS[d], kinds=15, frames_per_s=150.0, amplitude=40.0, **kw)[0]
+    flags_cli = ["-v"] + (["-d", str(d)] if d != 2 else []) + extra
+    check(emu, oracle, cu8, flags_cli, d, [4096 * 7, 4096 * 20, 4096, 4096 * 64])
+
+
+def test_rssi_filter_repair_path_on_host(emu, oracle, wm):
+    """Signal, then exact silence: the EMA decays through ~90 samples of subnormals while a warm-up from
+    zero is already at zero -- hand-offs fail certification and are repaired sequentially."""
+    cu8 = wm.synth_capture(seed=77, n_samples=1 << 17, kinds=15, frames_per_s=400.0, amplitude=60.0)[0]
+    cu8[cu8.size // 2:] = 128
+    repaired = check(emu, oracle, cu8, ["-v"], 2, [cu8.size])
+    assert repaired > 0
+
+
+def test_polyphase_prefilter_kernel_on_host(emu, oracle, samples):
+    cu8 = samples["samples2"][: 1 << 19]
+    check(emu, oracle, cu8, ["-v"], 2, [4096 * 33, 4096 * 5], polyphase=1)
