@@ -18,7 +18,8 @@ static EmuIdx3 threadIdx, blockIdx, blockDim, gridDim;
 
 namespace block_emu {
 enum State { RUNNABLE, WAIT_BLOCK, WAIT_WAVE, DONE };
-struct Co { ucontext_t ctx; State st; std::vector<char> stack; int pred; unsigned long long ballot; };
+struct Co { ucontext_t ctx; State st; std::vector<char> stack; int pred; unsigned long long ballot, val; };
+static unsigned long long snap[16][64];     /* values the lanes of a wave posted at their last wave operation */
 static std::vector<Co> cos;
 static ucontext_t sched_ctx;
 static int cur = -1;
@@ -65,7 +66,7 @@ static void run_block(uint32_t nthreads, const std::function<void()> &fn, size_t
             }
             if (lv && ww == lv) {
                 for (uint32_t l = 0; l < 64 && w * 64 + l < nthreads; l++)
-                    if (cos[w * 64 + l].st == WAIT_WAVE) { cos[w * 64 + l].ballot = mask; cos[w * 64 + l].st = RUNNABLE; }
+                    if (cos[w * 64 + l].st == WAIT_WAVE) { snap[w][l] = cos[w * 64 + l].val; cos[w * 64 + l].ballot = mask; cos[w * 64 + l].st = RUNNABLE; }
                 released = true;
             }
         }
@@ -86,4 +87,14 @@ static inline unsigned long long __ballot(int pred)
     block_emu::yield(block_emu::WAIT_WAVE);
     return block_emu::cos[block_emu::cur].ballot;
 }
+/* wave shuffles of 32-bit values: every lane posts its value, the wave meets, everyone reads the snapshot */
+static inline uint32_t emu_wave_exchange(uint32_t v, int src_lane)
+{
+    block_emu::cos[block_emu::cur].val = v; block_emu::cos[block_emu::cur].pred = 0;
+    block_emu::yield(block_emu::WAIT_WAVE);
+    return (uint32_t)block_emu::snap[block_emu::cur / 64][src_lane & 63];
+}
+static inline uint32_t __shfl(uint32_t v, int src) { return emu_wave_exchange(v, src); }
+static inline int __shfl(int v, int src) { return (int)emu_wave_exchange((uint32_t)v, src); }
+static inline uint32_t __shfl_xor(uint32_t v, int m) { return emu_wave_exchange(v, (block_emu::cur & 63) ^ m); }
 #endif

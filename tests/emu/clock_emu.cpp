@@ -43,6 +43,7 @@ using std::min;
 extern "C" {
 
 int wm_emu_descending = 1;
+uint32_t *wm_emu_seen_out = nullptr;      /* optional: receives the per-region "access-code chip seen" flags */
 int wm_emu_lean_reruns = 0;
 
 /* One push of M decimated samples for S captures.  dphi: [2][S][Mcap] soft symbols; carry: [2][S]
@@ -101,6 +102,7 @@ long wm_emu_clock(const float *dphi, uint32_t S, uint32_t M, uint32_t Mcap, uint
     }
     WmClkState *c = (WmClkState *)carry;                                 /* k_carry */
     for (uint32_t r = 0; r < rows; r++) c[r] = st_final[(size_t)r * nseg + nseg - 1];
+    if (wm_emu_seen_out) std::memcpy(wm_emu_seen_out, seen.data(), seen.size() * sizeof(uint32_t));
     if (err_out) *err_out = err;
     if (rounds_out) *rounds_out = round;
     return reruns;

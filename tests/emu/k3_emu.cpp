@@ -1,0 +1,66 @@
+/* k3_emu.cpp -- TEST INFRASTRUCTURE: k3_scan and k3_bursts (device source wm_k3_bursts.h) on the coroutine
+ * block emulator: access-code hits of settled chip regions, then the bursts the host decoders get. */
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "block_emu.h"
+
+#define __host__
+#define __device__
+#define __global__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__
+struct uint2 { uint32_t x, y; };
+struct uint4 { uint32_t x, y, z, w; };
+static inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
+using std::max;
+using std::min;
+static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+static inline uint32_t atomicAdd(uint32_t *p, uint32_t v) { const uint32_t o = *p; *p += v; return o; }
+static inline uint32_t atomicOr(uint32_t *p, uint32_t v) { const uint32_t o = *p; *p |= v; return o; }
+
+#include "wm_dev.h"
+#include "wm_k2_common.h"
+#include "wm_k3_bursts.h"
+
+extern "C" {
+
+unsigned wm_emu_hdr_bytes(void) { return sizeof(WmBurstHdr); }
+
+/* geo: M, Mcap, flags, m0, seg_len[2], nseg[2], cap[2] (S = 1).  Returns the number of bursts, or -1 on overflow. */
+long wm_emu_k3(const uint64_t *geo, const uint32_t *chips0, const uint32_t *chips1, const uint32_t *counts0, const uint32_t *counts1,
+               const uint32_t *seen0, const uint32_t *seen1, const uint8_t *rssi, const uint32_t *pending, void *hdr_out, uint32_t hdr_cap,
+               uint32_t *words_out, uint32_t words_cap, uint32_t *n_words_out, uint32_t max_blocks)
+{
+    WmPush g{};
+    g.S = 1; g.d = 2; g.M = (uint32_t)geo[0]; g.Mcap = (uint32_t)geo[1]; g.flags = (uint32_t)geo[2]; g.m0 = geo[3];
+    for (int a = 0; a < 2; a++) {
+        g.seg_len[a] = (uint32_t)geo[4 + a]; g.nseg[a] = (uint32_t)geo[6 + a]; g.nseg_cap[a] = g.nseg[a]; g.cap[a] = (uint32_t)geo[8 + a];
+    }
+    std::vector<uint2> hits(hdr_cap);
+    uint32_t n_hits = 0, err = 0, n_hdr = 0, n_words = 0;
+    const uint32_t lanes = 2u * (g.nseg[0] + g.nseg[1]) * g.S;
+    gridDim = {(lanes + 255u) / 256u, 1, 1};
+    for (uint32_t b = 0; b < gridDim.x; b++) {
+        blockIdx = {b, 0, 0};
+        block_emu::run_block(256, [&] { k3_scan(g, chips0, chips1, counts0, counts1, seen0, seen1, hits.data(), &n_hits, hdr_cap, &err); });
+    }
+    K3Args k3{};
+    k3.g = g; k3.rssi = rssi; k3.chips[0] = chips0; k3.chips[1] = chips1; k3.counts[0] = counts0; k3.counts[1] = counts1;
+    k3.hits = hits.data(); k3.n_hits = &n_hits; k3.hits_cap = hdr_cap; k3.pending = pending;
+    k3.hdr = (WmBurstHdr *)hdr_out; k3.hdr_cap = hdr_cap; k3.words = words_out; k3.words_cap = words_cap;
+    k3.n_hdr = &n_hdr; k3.n_words = &n_words; k3.err = &err;
+    const uint32_t n_items = 4 * g.S + std::min(n_hits, hdr_cap);
+    gridDim = {std::max(1u, std::min((n_items + 3u) / 4u, max_blocks)), 1, 1};
+    for (uint32_t b = 0; b < gridDim.x; b++) {
+        blockIdx = {b, 0, 0};
+        block_emu::run_block(256, [&] { k3_bursts(k3, n_items); });
+    }
+    if (n_words_out) *n_words_out = n_words;
+    return err ? -1 : (long)n_hdr;
+}
+
+}

@@ -33,6 +33,7 @@ using std::min;
 extern "C" {
 
 int wm_emu_descending = 1;
+uint32_t *wm_emu_seen_out = nullptr;      /* optional: receives the per-region "access-code chip seen" flags */
 
 /* One push of `M` decimated samples for S captures.  bits: [2][S][Mcap/32] slicer words; carry:
  * [2][S] WmRlaState in/out (zero-initialised = the reset state is NOT implied: pass what
@@ -83,6 +84,7 @@ long wm_emu_rla(const uint32_t *bits, uint32_t S, uint32_t M, uint32_t Mcap, uin
     }
     WmRlaState *c = (WmRlaState *)carry;                                 /* k_carry */
     for (uint32_t r = 0; r < rows; r++) c[r] = st_final[(size_t)r * nseg + nseg - 1];
+    if (wm_emu_seen_out) std::memcpy(wm_emu_seen_out, seen.data(), seen.size() * sizeof(uint32_t));
     if (err_out) *err_out = err;
     return reruns;
 }

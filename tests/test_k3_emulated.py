@@ -1,0 +1,144 @@
+"""k3_scan + k3_bursts (device source rtl-wmbus_amd/csrc/wm_k3_bursts.h) on the coroutine block emulator,
+fed by the host-emulated framer kernels: the bursts the GPU would ship to the host packet decoders must be
+exactly the oracle's chips after every access-code chip -- position, value and RSSI of each chip, burst
+length from the L-field -- plus the continuation slots of decoders that were left busy.  No GPU needed."""
+import ctypes
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from cases import flags_to_oracle_opts
+import test_clock_emulated as CE
+import test_rla_emulated as RE
+import test_burst_need as BN
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(os.path.dirname(HERE), "rtl-wmbus_amd", "csrc")
+SO = os.path.join(HERE, "emu", "libk3_emu.so")
+SRC = os.path.join(HERE, "emu", "k3_emu.cpp")
+CLANG = shutil.which("clang++") or "/opt/rocm/lib/llvm/bin/clang++"
+HDR = np.dtype([("stream", "<u4"), ("chain", "u1"), ("algo", "u1"), ("flags", "<u2"), ("chip0", "<u4"), ("n_chips", "<u4"),
+                ("pos0", "<u8"), ("word_off", "<u4"), ("avail", "<u4")])
+F_T1C1, F_S1, F_RLA, F_T2A = 8, 16, 32, 64
+
+emu_clock = CE.emu
+emu_rla = RE.emu
+emu_need = BN.emu
+
+
+@pytest.fixture(scope="module")
+def emu_k3():
+    if not os.path.exists(CLANG):
+        pytest.skip("no clang++")
+    deps = [SRC, os.path.join(HERE, "emu", "block_emu.h")] + [os.path.join(CSRC, f) for f in ("wm_k3_bursts.h", "wm_k2_common.h", "wm_dev.h")]
+    if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
+        subprocess.run([CLANG, "-O1", "-std=c++17", "-shared", "-fPIC", "-I" + CSRC, "-I" + os.path.join(HERE, "emu"), "-Wno-unknown-pragmas",
+                        "-o", SO, SRC], check=True)
+    L = ctypes.CDLL(SO)
+    L.wm_emu_k3.restype = ctypes.c_long
+    L.wm_emu_k3.argtypes = [ctypes.c_void_p] * 10 + [ctypes.c_uint, ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p, ctypes.c_uint]
+    assert L.wm_emu_hdr_bytes() == HDR.itemsize
+    return L
+
+
+def framers_on_host(emu_clock, emu_rla, ref, seg1=32768, seg0=8192):
+    """One push through the emulated clock and run-length kernels; returns their raw region arrays."""
+    M = ref["m"]; Mcap = (M + 255) // 256 * 256
+    x = np.zeros((2, Mcap), np.float32)
+    for ch in range(2):
+        x[ch, :M] = ref["dphi_fir"][ch]
+    out = {}
+    # clock / time2
+    nseg1, cap1 = (M + seg1 - 1) // seg1, seg1 // 4 + 8
+    bits = np.zeros((2, Mcap // 32), np.uint32); chips1 = np.zeros((2, nseg1, cap1), np.uint32); counts1 = np.zeros((2, nseg1), np.uint32)
+    seen1 = np.zeros((2, nseg1), np.uint32); carry1 = np.zeros(2 * emu_clock.wm_emu_clock_state_bytes(), np.uint8); err = ctypes.c_uint(0)
+    ctypes.c_void_p.in_dll(emu_clock, "wm_emu_seen_out").value = seen1.ctypes.data
+    r = emu_clock.wm_emu_clock(x.ctypes.data, 1, M, Mcap, F_T1C1 | F_S1 | F_T2A, seg1, 4096, 8192, cap1, carry1.ctypes.data, bits.ctypes.data,
+                               chips1.ctypes.data, counts1.ctypes.data, ctypes.byref(err), None)
+    ctypes.c_void_p.in_dll(emu_clock, "wm_emu_seen_out").value = None
+    assert r >= 0 and err.value == 0
+    # run-length
+    nseg0, cap0 = (M + seg0 - 1) // seg0, seg0 + 8 + 8192
+    chips0 = np.zeros((2, nseg0, cap0), np.uint32); counts0 = np.zeros((2, nseg0), np.uint32); seen0 = np.zeros((2, nseg0), np.uint32)
+    sb = emu_rla.wm_emu_rla_state_bytes(); carry0 = np.zeros(2 * sb, np.uint8)
+    for rr in range(2):
+        emu_rla.wm_emu_rla_reset_state(carry0[rr * sb:].ctypes.data)
+    ctypes.c_void_p.in_dll(emu_rla, "wm_emu_seen_out").value = seen0.ctypes.data
+    r = emu_rla.wm_emu_rla(bits.ctypes.data, 1, M, Mcap, F_T1C1 | F_S1, seg0, 1024, cap0, carry0.ctypes.data, chips0.ctypes.data, counts0.ctypes.data,
+                           ctypes.byref(err))
+    ctypes.c_void_p.in_dll(emu_rla, "wm_emu_seen_out").value = None
+    assert r >= 0 and err.value == 0
+    geo = np.array([M, Mcap, F_T1C1 | F_S1 | F_RLA | F_T2A, 0, seg0, seg1, nseg0, nseg1, cap0, cap1], np.uint64)
+    return dict(geo=geo, chips=(chips0, chips1), counts=(counts0, counts1), seen=(seen0, seen1), Mcap=Mcap)
+
+
+def bursts_on_host(emu_k3, fr, rssi_rows, pending=None, max_blocks=256):
+    pend = np.zeros(4, np.uint32) if pending is None else np.asarray(pending, np.uint32)
+    hdr = np.zeros(1 << 16, HDR); words = np.zeros(1 << 24, np.uint32); nw = ctypes.c_uint(0)
+    n = emu_k3.wm_emu_k3(fr["geo"].ctypes.data, fr["chips"][0].ctypes.data, fr["chips"][1].ctypes.data, fr["counts"][0].ctypes.data,
+                         fr["counts"][1].ctypes.data, fr["seen"][0].ctypes.data, fr["seen"][1].ctypes.data, rssi_rows.ctypes.data,
+                         pend.ctypes.data, hdr.ctypes.data, hdr.size, words.ctypes.data, words.size, ctypes.byref(nw), max_blocks)
+    assert n >= 0
+    return hdr[:n], words[:nw.value]
+
+
+def expected_bursts(emu_need, ref, ch, al):
+    oc = ref["chips"][(ref["chips"]["chain"] == ch) & (ref["chips"]["algo"] == al)]
+    pos, val, rssi = oc["sample"].astype(np.int64), oc["value"].astype(np.uint32), oc["rssi"].astype(np.uint32)
+    out = {}
+    for i in np.nonzero(val & 2)[0]:
+        avail = len(val) - i
+        nb = min(24, avail - 1)
+        hb = 0
+        for b in val[i + 1:i + 1 + nb] & 1:
+            hb = (hb << 1) | int(b)
+        hb <<= 24 - nb
+        n = min(emu_need.wm_emu_burst_need(ch, hb, nb) + 1, avail)
+        w = ((pos[i:i + n] - pos[i]).astype(np.uint32) << 11) | (rssi[i:i + n] << 3) | (val[i:i + n] & 7)
+        out[int(i)] = (n, int(pos[i]), avail, w)
+    return out
+
+
+@pytest.mark.parametrize("seed,amp", [(1, 60.0), (2, 25.0)])
+def test_bursts_are_the_oracles_chips_after_every_access_code(emu_k3, emu_clock, emu_rla, emu_need, oracle, wm, seed, amp):
+    cu8 = wm.synth_capture(seed=5000 + seed, n_samples=1 << 19, kinds=15, frames_per_s=150.0, amplitude=amp)[0]
+    ref = oracle.run(cu8, flags_to_oracle_opts(oracle, ["-v"]), taps=True, chips=True)
+    fr = framers_on_host(emu_clock, emu_rla, ref)
+    rssi = np.zeros((2, fr["Mcap"]), np.uint8)
+    for ch in range(2):
+        rssi[ch, :ref["m"]] = ref["rssi"][ch].astype(np.uint32).astype(np.uint8)
+    hdr, words = bursts_on_host(emu_k3, fr, rssi)
+    assert not (hdr["flags"] & 1).any()                    # nothing pending: no continuation bursts
+    n_checked = 0
+    for ch in (0, 1):
+        for al in (0, 1):
+            want = expected_bursts(emu_need, ref, ch, al)
+            got = hdr[(hdr["chain"] == ch) & (hdr["algo"] == al)]
+            assert sorted(got["chip0"].tolist()) == sorted(want), (ch, al)
+            for h in got:
+                n, pos0, avail, w = want[int(h["chip0"])]
+                assert (h["n_chips"], h["pos0"], h["avail"]) == (n, pos0, avail), (ch, al, h)
+                assert np.array_equal(words[h["word_off"]:h["word_off"] + n], w), (ch, al, h)
+                n_checked += 1
+    assert n_checked > 20
+
+
+def test_continuation_slots_deliver_what_a_busy_decoder_is_owed(emu_k3, emu_clock, emu_rla, oracle, wm):
+    cu8 = wm.synth_capture(seed=5100, n_samples=1 << 18, kinds=15, frames_per_s=150.0, amplitude=60.0)[0]
+    ref = oracle.run(cu8, flags_to_oracle_opts(oracle, ["-v"]), taps=True, chips=True)
+    fr = framers_on_host(emu_clock, emu_rla, ref)
+    rssi = np.zeros((2, fr["Mcap"]), np.uint8)
+    pending = [0, 700, 33, 10 ** 7]                        # [algo][chain]: rla/T1C1 none, rla/S1 700, t2a/T1C1 33, t2a/S1 more than there is
+    hdr, words = bursts_on_host(emu_k3, fr, rssi, pending)
+    cont = hdr[(hdr["flags"] & 1) == 1]
+    assert len(cont) == 3
+    for h in cont:
+        al, ch = int(h["algo"]), int(h["chain"])
+        oc = ref["chips"][(ref["chips"]["chain"] == ch) & (ref["chips"]["algo"] == al)]
+        assert h["chip0"] == 0 and h["n_chips"] == min(pending[al * 2 + ch], len(oc)) and h["avail"] == len(oc)
+        w = words[h["word_off"]:h["word_off"] + h["n_chips"]]
+        assert np.array_equal(w & 7, oc["value"][:h["n_chips"]] & 7)
+        assert np.array_equal(h["pos0"] + (w >> 11), oc["sample"][:h["n_chips"]])
