@@ -107,3 +107,18 @@ def test_rssi_filter_repair_path_on_host(emu, oracle, wm):
 def test_polyphase_prefilter_kernel_on_host(emu, oracle, samples):
     cu8 = samples["samples2"][: 1 << 19]
     check(emu, oracle, cu8, ["-v"], 2, [4096 * 33, 4096 * 5], polyphase=1)
+
+
+def test_randomised_captures_on_host(emu, oracle, wm):
+    rng = np.random.default_rng(3 + int(os.environ.get("WMBUS_EMU_SEED", "0")))
+    for k in range(int(os.environ.get("WMBUS_EMU_N", "4"))):                 # more for a bug hunt
+        d = int(rng.choice([2, 2, 3, 4, 5, 6]))
+        shift = bool(rng.random() < 0.3)
+        kw = dict(t1c1_center_khz=325.0, s1_center_khz=-325.0) if shift else {}
+        cu8 = wm.synth_capture(seed=int(rng.integers(1, 1 << 30)), n_samples=int(rng.choice([1 << 16, 3 << 15])), fs_khz=FS[d], kinds=15,
+                               frames_per_s=200.0, amplitude=float(rng.choice([8.0, 60.0, 120.0])), noise_sigma=float(rng.choice([0.0, 3.0, 20.0])), **kw)[0]
+        if k % 2:
+            a = int(rng.integers(0, cu8.size // 2)) & ~1
+            cu8[a:a + int(rng.integers(4096, cu8.size // 2))] = int(rng.choice([0, 127, 128, 255]))
+        flags_cli = ["-v"] + (["-d", str(d)] if d != 2 else []) + (["-s"] if shift else []) + (["-a"] if rng.random() < 0.2 else [])
+        check(emu, oracle, cu8, flags_cli, d, [int(x) * 4096 for x in rng.integers(1, 30, 4)])
