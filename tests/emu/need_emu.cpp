@@ -34,6 +34,7 @@ extern "C" {
 extern "C" {
 
 unsigned wm_emu_burst_need(unsigned chain, unsigned hb, unsigned nb) { return burst_need(chain, hb, nb); }
+unsigned wm_emu_decoder_bytes(void) { return sizeof(wm_decoder); }
 
 /* Feed `n` chips (bit0 of each byte) to a decoder that has just seen the access code; returns how many
  * it consumed before it went back to idle (or finished a telegram), or n + 1 if it is still receiving. */

@@ -1,0 +1,165 @@
+"""The whole device pipeline on the host: K1 -> clock/time2 -> run-length -> k3_scan/k3_bursts, every kernel
+from its DEVICE SOURCE (tests/emu), push by push with all carried state, then the product's host packet
+decoders (wm_decoder.c) driven by a few lines of Python that mirror wmbus_collect (skip access codes that
+passed while a decoder was busy, continuation bursts for decoders left busy at a push boundary).  The
+datagram text must be the oracle's, byte for byte.  No GPU needed; the GPU suite checks the compiled code."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from cases import flags_to_oracle_opts
+import test_burst_need as BN
+import test_clock_emulated as CE
+import test_k1_emulated as K1
+import test_k3_emulated as K3
+import test_rla_emulated as RE
+
+emu_k1, emu_clock, emu_rla, emu_k3, emu_need = K1.emu, CE.emu, RE.emu, K3.emu_k3, BN.emu
+F_SHIFT, F_ACCURATE, F_DC, F_T1C1, F_S1, F_RLA, F_T2A = 1, 2, 4, 8, 16, 32, 64
+
+
+class HostPipeline:
+    def __init__(self, libs, d=2, flags=F_ACCURATE | F_T1C1 | F_S1 | F_RLA | F_T2A, seg1=32768, seg0=8192, warm=(12288, 24576), lookback=1024,
+                 max_push=1 << 20):
+        self.k1, self.clk, self.rla, self.k3, self.dec = libs
+        self.d, self.flags, self.seg1, self.seg0, self.warm, self.lookback = d, flags, seg1, seg0, warm, lookback
+        self.stride = (K1.HIST + max_push + K1.SLACK + 255) // 256 * 256
+        self.row = np.full(self.stride, 128, np.uint8)
+        self.ema = np.zeros(2, np.float32)
+        self.clk_carry = np.zeros(2 * self.clk.wm_emu_clock_state_bytes(), np.uint8)
+        sb = self.rla.wm_emu_rla_state_bytes()
+        self.rla_carry = np.zeros(2 * sb, np.uint8)
+        self.rla.wm_emu_rla_reset_state.argtypes = [ctypes.c_void_p]
+        for r in range(2):
+            self.rla.wm_emu_rla_reset_state(self.rla_carry[r * sb:].ctypes.data)
+        self.n0 = 0
+        db = self.dec.wm_emu_decoder_bytes()
+        self.decs = {}
+        self.dec.wm_decoder_init.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        self.dec.wm_decoder_chip.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint]
+        self.dec.wm_decoder_chips_owed.argtypes = [ctypes.c_void_p]; self.dec.wm_decoder_chips_owed.restype = ctypes.c_uint
+        self.dec.wm_decoder_format.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p]
+        self.dec.wm_decoder_format.restype = ctypes.c_size_t
+        for ch in range(2):
+            for al in range(2):
+                buf = ctypes.create_string_buffer(db)
+                self.dec.wm_decoder_init(buf, ch)
+                self.decs[(ch, al)] = [buf, 0]                  # decoder, chips owed
+
+    def push(self, data):
+        nb = data.size
+        self.row[K1.HIST:K1.HIST + nb] = data
+        n_new, d = nb // 2, self.d
+        m0 = self.n0 // d
+        M = (self.n0 + n_new) // d - m0
+        lines = []
+        if M > 0:
+            Mcap = max(256, ((M + 975) // 976 * 976 + 255) // 256 * 256)
+            dphi = np.zeros((2, Mcap), np.float32); rssi = np.zeros((2, Mcap), np.uint8); err = ctypes.c_uint(0)
+            assert self.k1.wm_emu_k1(self.row.ctypes.data, self.stride, 1, d, self.flags & 3 | F_T1C1 | F_S1, self.n0, n_new, Mcap, dphi.ctypes.data,
+                                     rssi.ctypes.data, self.ema.ctypes.data, ctypes.byref(err), 0) >= 0 and err.value == 0
+            dphi[:, M:] = 0                                     # rows beyond M are scratch for the framers
+            nseg1, cap1 = (M + self.seg1 - 1) // self.seg1, self.seg1 // 4 + 8
+            bits = np.zeros((2, Mcap // 32), np.uint32); chips1 = np.zeros((2, nseg1, cap1), np.uint32); counts1 = np.zeros((2, nseg1), np.uint32)
+            seen1 = np.zeros((2, nseg1), np.uint32)
+            ctypes.c_void_p.in_dll(self.clk, "wm_emu_seen_out").value = seen1.ctypes.data
+            r = self.clk.wm_emu_clock(dphi.ctypes.data, 1, M, Mcap, self.flags & (F_DC | F_T1C1 | F_S1 | F_T2A), self.seg1, self.warm[0], self.warm[1], cap1,
+                                      self.clk_carry.ctypes.data, bits.ctypes.data, chips1.ctypes.data, counts1.ctypes.data, ctypes.byref(err), None)
+            ctypes.c_void_p.in_dll(self.clk, "wm_emu_seen_out").value = None
+            assert r >= 0 and err.value == 0
+            nseg0, cap0 = (M + self.seg0 - 1) // self.seg0, self.seg0 + 8 + 8192
+            chips0 = np.zeros((2, nseg0, cap0), np.uint32); counts0 = np.zeros((2, nseg0), np.uint32); seen0 = np.zeros((2, nseg0), np.uint32)
+            ctypes.c_void_p.in_dll(self.rla, "wm_emu_seen_out").value = seen0.ctypes.data
+            r = self.rla.wm_emu_rla(bits.ctypes.data, 1, M, Mcap, self.flags & (F_T1C1 | F_S1), self.seg0, self.lookback, cap0, self.rla_carry.ctypes.data,
+                                    chips0.ctypes.data, counts0.ctypes.data, ctypes.byref(err))
+            ctypes.c_void_p.in_dll(self.rla, "wm_emu_seen_out").value = None
+            assert r >= 0 and err.value == 0
+            fr = dict(geo=np.array([M, Mcap, self.flags, m0, self.seg0, self.seg1, nseg0, nseg1, cap0, cap1], np.uint64), chips=(chips0, chips1),
+                      counts=(counts0, counts1), seen=(seen0, seen1))
+            pending = [self.decs[(ch, al)][1] for al in range(2) for ch in range(2)]          # [algo][chain]
+            hdr, words = K3.bursts_on_host(self.k3, fr, rssi, pending)
+            lines = self.collect(hdr, words)
+        self.row[:K1.HIST] = self.row[nb:nb + K1.HIST].copy()
+        self.n0 += n_new
+        return lines
+
+    def collect(self, hdr, words):
+        """wm_api.hip: wmbus_collect / decode_stream_range for one capture."""
+        out, seq = [], 0
+        order = sorted(range(len(hdr)), key=lambda i: (hdr[i]["chain"], hdr[i]["algo"], 0 if hdr[i]["flags"] & 1 else 1, hdr[i]["chip0"]))
+        line = ctypes.create_string_buffer(1024); ok = ctypes.c_int(0)
+        group, next_free = None, 0
+        for i in order:
+            h = hdr[i]
+            key = (int(h["chain"]), int(h["algo"]))
+            if key != group:
+                group, next_free = key, 0
+            dec = self.decs[key]
+            cont = bool(h["flags"] & 1)
+            if (dec[1] == 0) if cont else (h["chip0"] < next_free):
+                continue                                        # the access code passed while the decoder was busy
+            w = words[h["word_off"]:h["word_off"] + h["n_chips"]]
+            st, k = (1 if cont else 0), 0
+            while k < len(w):
+                val, rs = int(w[k]) & 7, (int(w[k]) >> 3) & 0xFF
+                if (val & 4) and st == 1:                       # the run-length framer reset itself
+                    dec[0][0:2] = bytes(2)                     # wm_decoder_abort: step = 0
+                    st = 0
+                    break
+                st = self.dec.wm_decoder_chip(dec[0], val & 3, rs)
+                if st == 2:
+                    n = self.dec.wm_decoder_format(dec[0], b"rla;" if key[1] == 0 else b"t2a;", b"TS", rs, line, 1024, ctypes.byref(ok))
+                    out.append((int(h["pos0"]) + (int(w[k]) >> 11), key[0], key[1], seq, line.raw[:n].decode()))
+                    seq += 1
+                    st = 0
+                if st == 0:
+                    k += 1
+                    break
+                k += 1
+            next_free = int(h["chip0"]) + k
+            cut = st == 1
+            assert not (cut and h["n_chips"] != h["avail"]), "burst too short"
+            dec[1] = max(1, self.dec.wm_decoder_chips_owed(dec[0])) if cut else 0
+        out.sort(key=lambda r: r[:4])
+        return [r[4] for r in out]
+
+
+def run_capture(libs, cu8, pushes, **kw):
+    p = HostPipeline(libs, **kw)
+    text, off, k = [], 0, 0
+    total = cu8.size // 4096 * 4096
+    while off < total:
+        nb = min(pushes[k % len(pushes)], total - off)
+        text += p.push(cu8[off:off + nb])
+        off += nb; k += 1
+    return "".join(text)
+
+
+@pytest.fixture(scope="module")
+def libs(emu_k1, emu_clock, emu_rla, emu_k3, emu_need):
+    return emu_k1, emu_clock, emu_rla, emu_k3, emu_need
+
+
+@pytest.mark.parametrize("pushes", [[1 << 20], [4096 * 37, 4096 * 11], [4096 * 3]])
+def test_bundled_capture_through_the_emulated_pipeline(libs, oracle, samples, pushes):
+    cu8 = samples["samples2"][: 1 << 20]
+    ref = oracle.run(cu8, flags_to_oracle_opts(oracle, ["-v"]))
+    assert len(ref["text"].splitlines()) >= 2
+    assert run_capture(libs, cu8, pushes) == ref["text"]
+
+
+def test_synthetic_captures_through_the_emulated_pipeline(libs, oracle, wm):
+    rng = np.random.default_rng(21 + int(os.environ.get("WMBUS_EMU_SEED", "0")))
+    n_lines = 0
+    for k in range(int(os.environ.get("WMBUS_EMU_N", "3"))):               # more for a bug hunt
+        cu8 = wm.synth_capture(seed=int(rng.integers(1, 1 << 30)), n_samples=1 << 18, kinds=15, frames_per_s=200.0,
+                               amplitude=float(rng.choice([25.0, 60.0])))[0]
+        ref = oracle.run(cu8, flags_to_oracle_opts(oracle, ["-v"]))
+        pushes = [int(x) * 4096 for x in rng.integers(1, 40, 3)]
+        got = run_capture(libs, cu8, pushes, seg1=int(rng.choice([4096, 32768])), seg0=int(rng.choice([1024, 8192])),
+                          warm=(int(rng.choice([512, 12288])), int(rng.choice([512, 24576]))))
+        assert got == ref["text"], (k, pushes)
+        n_lines += len(got.splitlines())
+    assert n_lines > 10
