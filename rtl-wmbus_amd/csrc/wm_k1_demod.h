@@ -174,7 +174,10 @@ __device__ __forceinline__ void k1_stage_b(const K1Args &a, const int tid, const
     constexpr int T = WM_K1_TILE2;
     const WmPush &g = a.g;
     __syncthreads();                                          /* magnitude rows complete */
-    const int wv = tid >> 6, e = tid & 63;
+    /* The four waves have different jobs here (EMA + the 11-tap FIR: ~520 instructions; the 46-tap FIR:
+     * ~870), and wave i of a workgroup lands on the same SIMD of its CU block after block: the jobs
+     * rotate with the tile so that every SIMD gets the average instead of two of them the maximum. */
+    const int e = tid & 63, wv = ((tid >> 6) + tile) & 3, rt = 64 * wv + e;      /* rt: thread id within the rotated roles */
     const int ch = wv & 1;                                    /* EMA chain of waves 0, 1 */
     const bool on = wv < 2 && (ch ? chS : chT) && 16 * e < T;
     const float al = 0.6789f, be = wm_sub(1.0f, 0.6789f);
@@ -228,7 +231,7 @@ __device__ __forceinline__ void k1_stage_b(const K1Args &a, const int tid, const
             }
             if (m0l < tn)
                 *(uint4 *)(a.rssi + row * g.Mcap + ts + m0l) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-            sFin[tid] = ema; sHead[tid] = head;
+            sFin[rt] = ema; sHead[rt] = head;
         }
         if (chT) { k1_fir_t(a, yDrT, 128 * wv + e, stream, ts, tn); k1_fir_t(a, yDrT, 128 * wv + 64 + e, stream, ts, tn); }
     } else if (chS) {
@@ -238,7 +241,7 @@ __device__ __forceinline__ void k1_stage_b(const K1Args &a, const int tid, const
     __syncthreads();
     /* certify: a lane's warm-up must have landed exactly on its predecessor's trajectory; a tile
      * with an uncertified lane publishes a head that cannot match (NaN) and is repaired */
-    const bool bad = on && e > 0 && m0l < tn && wm_f2u(head) != wm_f2u(sFin[tid - 1]);
+    const bool bad = on && e > 0 && m0l < tn && wm_f2u(head) != wm_f2u(sFin[rt - 1]);
     const unsigned long long badT = __ballot(bad);            /* waves 0 and 1 are the two chains */
     if (on) {
         if (e == 0) a.ema_head[ti] = badT ? wm_u2f(0x7FC00000u) : head;
