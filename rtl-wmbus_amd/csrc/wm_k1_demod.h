@@ -175,8 +175,8 @@ __device__ __forceinline__ void k1_stage_b(const K1Args &a, const int tid, const
     const WmPush &g = a.g;
     __syncthreads();                                          /* magnitude rows complete */
     /* The four waves have different jobs here (EMA + the 11-tap FIR: ~520 instructions; the 46-tap FIR:
-     * ~870), and wave i of a workgroup lands on the same SIMD of its CU block after block: the jobs
-     * rotate with the tile so that every SIMD gets the average instead of two of them the maximum. */
+     * ~870): the jobs rotate with the tile, so that no SIMD of a CU can end up with the heavy job block
+     * after block whatever order the hardware places a workgroup's waves in (two instructions). */
     const int e = tid & 63, wv = ((tid >> 6) + tile) & 3, rt = 64 * wv + e;      /* rt: thread id within the rotated roles */
     const int ch = wv & 1;                                    /* EMA chain of waves 0, 1 */
     const bool on = wv < 2 && (ch ? chS : chT) && 16 * e < T;
