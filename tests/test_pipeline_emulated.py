@@ -153,13 +153,18 @@ def test_bundled_capture_through_the_emulated_pipeline(libs, oracle, samples, pu
 def test_synthetic_captures_through_the_emulated_pipeline(libs, oracle, wm):
     rng = np.random.default_rng(21 + int(os.environ.get("WMBUS_EMU_SEED", "0")))
     n_lines = 0
-    for k in range(int(os.environ.get("WMBUS_EMU_N", "3"))):               # more for a bug hunt
-        cu8 = wm.synth_capture(seed=int(rng.integers(1, 1 << 30)), n_samples=1 << 18, kinds=15, frames_per_s=200.0,
-                               amplitude=float(rng.choice([25.0, 60.0])))[0]
-        ref = oracle.run(cu8, flags_to_oracle_opts(oracle, ["-v"]))
+    for k in range(int(os.environ.get("WMBUS_EMU_N", "4"))):               # more for a bug hunt
+        d = int(rng.choice([2, 2, 3, 4, 5]))
+        shift, dc, fast = bool(rng.random() < 0.3), bool(rng.random() < 0.3), bool(rng.random() < 0.2)
+        kw = dict(t1c1_center_khz=325.0, s1_center_khz=-325.0) if shift else {}
+        cu8 = wm.synth_capture(seed=int(rng.integers(1, 1 << 30)), n_samples=int(rng.choice([1 << 17, 1 << 18])), fs_khz=K1.FS[d], kinds=15,
+                               frames_per_s=200.0, amplitude=float(rng.choice([25.0, 60.0])), **kw)[0]
+        cli = ["-v"] + (["-d", str(d)] if d != 2 else []) + (["-s"] if shift else []) + (["-o"] if dc else []) + (["-a"] if fast else [])
+        ref = oracle.run(cu8, flags_to_oracle_opts(oracle, cli))
         pushes = [int(x) * 4096 for x in rng.integers(1, 40, 3)]
-        got = run_capture(libs, cu8, pushes, seg1=int(rng.choice([4096, 32768])), seg0=int(rng.choice([1024, 8192])),
+        flags = F_T1C1 | F_S1 | F_RLA | F_T2A | (F_SHIFT if shift else 0) | (F_DC if dc else 0) | (0 if fast else F_ACCURATE)
+        got = run_capture(libs, cu8, pushes, d=d, flags=flags, seg1=int(rng.choice([4096, 32768])), seg0=int(rng.choice([1024, 8192])),
                           warm=(int(rng.choice([512, 12288])), int(rng.choice([512, 24576]))))
-        assert got == ref["text"], (k, pushes)
+        assert got == ref["text"], (k, cli, pushes)
         n_lines += len(got.splitlines())
     assert n_lines > 10
