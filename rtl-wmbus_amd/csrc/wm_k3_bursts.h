@@ -82,16 +82,24 @@ __global__ __launch_bounds__(256) void k3_scan(WmPush g, const uint32_t *chips0,
         const int src = __ffsll((long long)todo) - 1;
         const uint32_t cnt = __shfl(my_cnt, src), sidx = __shfl(my_sidx, src), r_lane = __shfl(lane, src), r_algo = __shfl(algo, src);
         const uint32_t *w = (r_algo ? chips1 : chips0) + (uint64_t)sidx * g.cap[r_algo];
-        for (uint32_t k4 = 4u * ln; k4 < cnt; k4 += 256u) {             /* regions are 32-byte aligned, cap % 8 == 0 */
-            const uint4 v = *(const uint4 *)(w + k4);
-            const uint32_t q[4] = {v.x, v.y, v.z, v.w};
+        /* four 16-byte loads in flight per lane (a region of the clock framer is 8 k chips: 32 dependent
+         * trips of one load each were most of this kernel's time) */
+        for (uint32_t kb = 4u * ln; kb < cnt; kb += 1024u) {            /* regions are 32-byte aligned, cap % 8 == 0 */
+            uint4 v[4];
 #pragma unroll
-            for (uint32_t j = 0; j < 4; j++)
-                if (k4 + j < cnt && (q[j] & 2u)) {
-                    const uint32_t i = atomicAdd(n_hits, 1u);
-                    if (i < hits_cap) hits[i] = make_uint2(r_lane | (r_algo << 31), k4 + j);
-                    else atomicOr(err, WM_ERR_BURST_OVERFLOW);
-                }
+            for (uint32_t u = 0; u < 4; u++) v[u] = kb + 256u * u < cnt ? *(const uint4 *)(w + kb + 256u * u) : uint4{0u, 0u, 0u, 0u};
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                const uint32_t k4 = kb + 256u * u;
+                const uint32_t q[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++)
+                    if (k4 + j < cnt && (q[j] & 2u)) {
+                        const uint32_t i = atomicAdd(n_hits, 1u);
+                        if (i < hits_cap) hits[i] = make_uint2(r_lane | (r_algo << 31), k4 + j);
+                        else atomicOr(err, WM_ERR_BURST_OVERFLOW);
+                    }
+            }
         }
     }
 }
