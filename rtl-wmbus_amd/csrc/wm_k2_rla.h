@@ -52,7 +52,7 @@ __device__ __forceinline__ uint32_t deglitch_word(uint32_t W, bool s1)
 }
 
 /* Run-length framer lane (rtl_wmbus.c:640-702 S1, :729-803 T1/C1), edge-driven: the per-sample
- * work (shift, deglitch, compare, count) is done for 32 samples at once with bit operations and
+ * work (shift, deglitch, compare, count) is done for 64 samples at once with bit operations and
  * the lane only iterates over the EDGES of the deglitched signal.  A framer reset clears the raw
  * history (rtl_wmbus.c:632,723), so after one the remaining levels of the block are recomputed
  * from the masked history.  WmRlaState.raw keeps the last five raw bits in time order. */
@@ -117,8 +117,8 @@ __device__ __forceinline__ void rla_lanes(const K2Args &a, const uint32_t block_
     fetch_group(grp + 1u);
     /* One step = 64 samples (two slicer words).  The wave walks its 64 lanes' edges in lock step, so a
      * step costs the wave the LARGEST edge count among its lanes; over 64 samples that maximum is
-     * relatively smaller than over 32 (T1/C1 in noise: 4.6 edges per 32 samples on average, 11 for the
-     * unluckiest of 64 lanes; 9.3 and 17.7 per 64). */
+     * relatively smaller than over 32 (T1/C1 on the bench workload, measured on the host emulation with 64
+     * captures as the lanes: 8.4 edges per 64 samples on average, 18.9 for the unluckiest of 64 lanes). */
     auto block = [&](const bool emit) {
         const uint32_t sub = (m >> 6) & 3u;                  /* word pair within the group of 8 */
         const uint32_t lo4[4] = {wq0.x, wq0.z, wq1.x, wq1.z}, hi4[4] = {wq0.y, wq0.w, wq1.y, wq1.w};
