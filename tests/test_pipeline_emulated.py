@@ -161,7 +161,7 @@ def test_synthetic_captures_through_the_emulated_pipeline(libs, oracle, wm):
                                frames_per_s=200.0, amplitude=float(rng.choice([25.0, 60.0])), **kw)[0]
         cli = ["-v"] + (["-d", str(d)] if d != 2 else []) + (["-s"] if shift else []) + (["-o"] if dc else []) + (["-a"] if fast else [])
         ref = oracle.run(cu8, flags_to_oracle_opts(oracle, cli))
-        pushes = [int(x) * 4096 for x in rng.integers(1, 40, 3)]
+        pushes = [int(x) * 4096 for x in rng.integers(1, 4 if os.environ.get("WMBUS_EMU_TINY") else 40, 3)]      # TINY: pushes of 4 - 12 KB only
         flags = F_T1C1 | F_S1 | F_RLA | F_T2A | (F_SHIFT if shift else 0) | (F_DC if dc else 0) | (0 if fast else F_ACCURATE)
         got = run_capture(libs, cu8, pushes, d=d, flags=flags, seg1=int(rng.choice([4096, 32768])), seg0=int(rng.choice([1024, 8192])),
                           warm=(int(rng.choice([512, 12288])), int(rng.choice([512, 24576]))))
