@@ -53,8 +53,8 @@ BYTES_PER_SAMPLE = 2            # one u8 I + one u8 Q, read once
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--streams", type=int, default=1024, help="captures per GPU")
     ap.add_argument("--samples", type=int, default=1 << 22, help="IQ samples per capture per step")
     ap.add_argument("--seg-len", type=int, default=0)
