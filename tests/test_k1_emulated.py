@@ -20,7 +20,7 @@ SRC = os.path.join(HERE, "emu", "k1_emu.cpp")
 CLANG = shutil.which("clang++") or "/opt/rocm/lib/llvm/bin/clang++"      # needs clang (ext_vector_type)
 HIST, SLACK = 4096, 256
 F_SHIFT, F_ACCURATE, F_T1C1, F_S1 = 1, 2, 8, 16                        # WM_F_* of wm_dev.h
-FS = {2: 1600, 3: 2400, 4: 3200, 5: 4000, 6: 4800}
+FS = {1: 800, 2: 1600, 3: 2400, 4: 3200, 5: 4000, 6: 4800, 8: 6400}
 
 
 @pytest.fixture(scope="module")

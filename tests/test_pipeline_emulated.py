@@ -22,7 +22,8 @@ F_SHIFT, F_ACCURATE, F_DC, F_T1C1, F_S1, F_RLA, F_T2A = 1, 2, 4, 8, 16, 32, 64
 
 class HostPipeline:
     def __init__(self, libs, d=2, flags=F_ACCURATE | F_T1C1 | F_S1 | F_RLA | F_T2A, seg1=32768, seg0=8192, warm=(12288, 24576), lookback=1024,
-                 max_push=1 << 20):
+                 max_push=1 << 20, polyphase=0):
+        self.polyphase = polyphase
         self.k1, self.clk, self.rla, self.k3, self.dec = libs
         self.d, self.flags, self.seg1, self.seg0, self.warm, self.lookback = d, flags, seg1, seg0, warm, lookback
         self.stride = (K1.HIST + max_push + K1.SLACK + 255) // 256 * 256
@@ -59,7 +60,7 @@ class HostPipeline:
             Mcap = max(256, ((M + 975) // 976 * 976 + 255) // 256 * 256)
             dphi = np.zeros((2, Mcap), np.float32); rssi = np.zeros((2, Mcap), np.uint8); err = ctypes.c_uint(0)
             assert self.k1.wm_emu_k1(self.row.ctypes.data, self.stride, 1, d, self.flags & 3 | F_T1C1 | F_S1, self.n0, n_new, Mcap, dphi.ctypes.data,
-                                     rssi.ctypes.data, self.ema.ctypes.data, ctypes.byref(err), 0) >= 0 and err.value == 0
+                                     rssi.ctypes.data, self.ema.ctypes.data, ctypes.byref(err), self.polyphase) >= 0 and err.value == 0
             dphi[:, M:] = 0                                     # rows beyond M are scratch for the framers
             nseg1, cap1 = (M + self.seg1 - 1) // self.seg1, self.seg1 // 4 + 8
             bits = np.zeros((2, Mcap // 32), np.uint32); chips1 = np.zeros((2, nseg1, cap1), np.uint32); counts1 = np.zeros((2, nseg1), np.uint32)
@@ -72,7 +73,7 @@ class HostPipeline:
             nseg0, cap0 = (M + self.seg0 - 1) // self.seg0, self.seg0 + 8 + 8192
             chips0 = np.zeros((2, nseg0, cap0), np.uint32); counts0 = np.zeros((2, nseg0), np.uint32); seen0 = np.zeros((2, nseg0), np.uint32)
             ctypes.c_void_p.in_dll(self.rla, "wm_emu_seen_out").value = seen0.ctypes.data
-            r = self.rla.wm_emu_rla(bits.ctypes.data, 1, M, Mcap, self.flags & (F_T1C1 | F_S1), self.seg0, self.lookback, cap0, self.rla_carry.ctypes.data,
+            r = 0 if not self.flags & F_RLA else self.rla.wm_emu_rla(bits.ctypes.data, 1, M, Mcap, self.flags & (F_T1C1 | F_S1), self.seg0, self.lookback, cap0, self.rla_carry.ctypes.data,
                                     chips0.ctypes.data, counts0.ctypes.data, ctypes.byref(err))
             ctypes.c_void_p.in_dll(self.rla, "wm_emu_seen_out").value = None
             assert r >= 0 and err.value == 0
@@ -168,3 +169,38 @@ def test_synthetic_captures_through_the_emulated_pipeline(libs, oracle, wm):
         assert got == ref["text"], (k, cli, pushes)
         n_lines += len(got.splitlines())
     assert n_lines > 10
+
+
+def test_gpu_fuzz_configurations_through_the_emulated_pipeline(libs, oracle, wm):
+    """The seeded random configurations of tests/test_gpu_fuzz.py (every switch combination, decimations, the
+    polyphase pre-filter, push cuts, tunings, silent stretches), first capture of each, on the host emulation."""
+    import test_gpu_fuzz as FZ
+    from cases import flags_to_kwargs
+    n = int(os.environ.get("WMBUS_EMU_N", "6"))
+    ran = n_lines = 0
+    for k in range(n):
+        c = FZ.make_case(k, int(os.environ.get("WMBUS_EMU_SEED", "0")))
+        rng = np.random.default_rng(c["seed"])
+        kw = dict(seed=c["seed"], n_samples=min(c["n"], 1 << 17), fs_khz=FZ.FS[c["d"]], kinds=15, frames_per_s=90.0, amplitude=c["amp"])
+        if c["simultaneous"]:
+            kw.update(t1c1_center_khz=325.0, s1_center_khz=-325.0)
+        cu8 = wm.synth_capture(**kw)[0]
+        if c["silence"]:
+            a = int(rng.integers(0, cu8.size // 2)) & ~1
+            cu8[a:a + int(rng.integers(4096, cu8.size // 3))] = int(rng.choice([127, 128]))
+        oo = flags_to_oracle_opts(oracle, c["flags"])
+        oo.prefilter = c["prefilter"]
+        ref = oracle.run(cu8, oo)
+        pk = flags_to_kwargs(c["flags"])
+        flags = ((F_SHIFT if pk.get("simultaneous") else 0) | (F_ACCURATE if pk.get("accurate_atan", True) else 0) | (F_DC if pk.get("remove_dc") else 0) |
+                 (F_T1C1 if pk.get("t1c1", True) else 0) | (F_S1 if pk.get("s1", True) else 0) | (F_RLA if pk.get("rla", True) else 0) |
+                 (F_T2A if pk.get("time2", True) else 0))
+        t = c["tune"]
+        got = run_capture(libs, cu8, [min(c["push"], 1 << 20)], d=c["d"], flags=flags, polyphase=c["prefilter"], seg1=t.get("seg_len", 32768),
+                          seg0=t.get("rla_seg_len", 8192), warm=(t.get("warmup_t1c1", 12288), t.get("warmup_s1", 24576)), lookback=t.get("rla_lookback", 1024))
+        want = ref["text"] if "-v" in c["flags"] else ref["text"]
+        if "-v" not in c["flags"]:                           # the emulated collect always tags the framer: strip the tags
+            got = "".join(ln.split(";", 1)[1] + "\n" for ln in got.splitlines())
+        assert got == want, (k, c["flags"], c["tune"])
+        ran += 1; n_lines += len(got.splitlines())
+    assert ran >= n - 1 and (n < 6 or n_lines > 0)
