@@ -87,6 +87,13 @@ static inline unsigned long long __ballot(int pred)
     block_emu::yield(block_emu::WAIT_WAVE);
     return block_emu::cos[block_emu::cur].ballot;
 }
+/* a wave-level barrier (all live lanes of the wave arrive); a no-op when code runs outside run_block */
+static inline void emu_wave_barrier()
+{
+    if (block_emu::cur < 0) return;
+    block_emu::cos[block_emu::cur].pred = 0;
+    block_emu::yield(block_emu::WAIT_WAVE);
+}
 /* wave shuffles of 32-bit values: every lane posts its value, the wave meets, everyone reads the snapshot */
 static inline uint32_t emu_wave_exchange(uint32_t v, int src_lane)
 {

@@ -9,6 +9,8 @@
 #include <cstring>
 #include <vector>
 
+#include "block_emu.h"
+
 #define __device__
 #define __global__
 #define __forceinline__ inline
@@ -17,13 +19,11 @@
 struct uint4 { uint32_t x, y, z, w; };
 struct float4 { float x, y, z, w; };
 static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
-struct Idx3 { uint32_t x, y, z; };
-static Idx3 threadIdx, blockIdx;
 static inline int __ffs(int v) { return __builtin_ffs(v); }
 static inline uint32_t atomicOr(uint32_t *p, uint32_t v) { const uint32_t o = *p; *p |= v; return o; }
 static inline uint32_t __builtin_amdgcn_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31u)); }
 static inline void __builtin_amdgcn_sched_barrier(int) {}
-static inline void __builtin_amdgcn_wave_barrier() {}
+static inline void __builtin_amdgcn_wave_barrier() { emu_wave_barrier(); }   /* a real meeting point on the block emulator */
 #if !defined(__clang__)
 static inline uint32_t __builtin_bitreverse32(uint32_t v)
 {
@@ -74,6 +74,14 @@ long wm_emu_clock(const float *dphi, uint32_t S, uint32_t M, uint32_t Mcap, uint
          * end state BEFORE that predecessor's own re-run (same launch) has replaced it -- which is what
          * makes cascading rounds.  Lanes in descending order reproduce that; ascending order is the
          * other extreme (every lane already sees its predecessor's new state). */
+        if (lst == nullptr && S % 64u == 0u) {
+            /* first pass of a batch of whole waves: the kernel loads COOPERATIVELY (8 lanes fetch one row's
+             * line, the block is transposed through LDS between wave barriers) -- the 64 lanes of a wave
+             * really have to run together: one coroutine each on the block emulator */
+            for (uint32_t b = 0; b < n / 64; b++)
+                block_emu::run_block(64, [&] { if (dc) clock_lanes<true, 1>(a, b, lds); else clock_lanes<false, 1>(a, b, lds); });
+            return;
+        }
         for (uint32_t i = 0; i < n; i++) {
             const uint32_t l = wm_emu_descending ? n - 1 - i : i;
             threadIdx.x = l & 63u;

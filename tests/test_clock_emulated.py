@@ -20,10 +20,10 @@ F_DC, F_T1C1, F_S1, F_T2A = 4, 8, 16, 64                   # WM_F_* of wm_dev.h
 
 @pytest.fixture(scope="module")
 def emu():
-    deps = [SRC] + [os.path.join(CSRC, f) for f in ("wm_k2_clock.h", "wm_k2_common.h", "wm_dev.h", "wm_exact.h")]
+    deps = [SRC, os.path.join(HERE, "emu", "block_emu.h")] + [os.path.join(CSRC, f) for f in ("wm_k2_clock.h", "wm_k2_common.h", "wm_dev.h", "wm_exact.h")]
     if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
-        subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-I" + CSRC, "-Wno-unknown-pragmas",
-                        "-o", SO, SRC], check=True)
+        subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-I" + CSRC, "-I" + os.path.join(HERE, "emu"),
+                        "-Wno-unknown-pragmas", "-o", SO, SRC], check=True)
     L = ctypes.CDLL(SO)
     L.wm_emu_clock.restype = ctypes.c_long
     L.wm_emu_clock.argtypes = [ctypes.c_void_p] + [ctypes.c_uint] * 8 + [ctypes.c_void_p] * 6
@@ -109,3 +109,31 @@ def test_device_source_on_host_matches_oracle_randomised(emu, oracle, wm):
             assert np.array_equal(bits[ch], ref["bit"][ch]), (k, "bits", ch)
             assert np.array_equal(chips[ch], oracle_t2a_chips(ref, ch)), (k, "chips", ch, seg_len, warm)
     assert multi > 0                                           # cascading re-run rounds (where the checkpoint bug lived) occurred
+
+
+def test_cooperative_first_pass_of_a_whole_wave_on_the_block_emulator(emu, oracle, wm):
+    """64 captures = one wave per (chain, segment): the first pass fetches the rows cooperatively (8 lanes per
+    row, one 128-byte line each) and transposes the block through LDS between wave barriers.  The 64 lanes run
+    as coroutines on the block emulator; re-runs take the lane-private path."""
+    S, seg_len, warm = 64, 8192, (1024, 2048)
+    refs = []
+    for s in range(S):
+        cu8 = wm.synth_capture(seed=7000 + s, n_samples=1 << 16, kinds=15, frames_per_s=300.0, amplitude=60.0)[0]
+        refs.append(oracle.run(cu8, flags_to_oracle_opts(oracle, ["-v"]), taps=True, chips=True))
+    M = refs[0]["m"]; Mcap = (M + 255) // 256 * 256
+    x = np.zeros((2, S, Mcap), np.float32)
+    for s in range(S):
+        for ch in range(2):
+            x[ch, s, :M] = refs[s]["dphi_fir"][ch]
+    nseg, cap = (M + seg_len - 1) // seg_len, seg_len // 4 + 8
+    bits = np.zeros((2, S, Mcap // 32), np.uint32); chips = np.zeros((2, S, nseg, cap), np.uint32); counts = np.zeros((2, S, nseg), np.uint32)
+    carry = np.zeros(2 * S * emu.wm_emu_clock_state_bytes(), np.uint8); err = ctypes.c_uint(0); rounds = ctypes.c_uint(0)
+    r = emu.wm_emu_clock(x.ctypes.data, S, M, Mcap, F_T1C1 | F_S1 | F_T2A, seg_len, warm[0], warm[1], cap, carry.ctypes.data, bits.ctypes.data,
+                         chips.ctypes.data, counts.ctypes.data, ctypes.byref(err), ctypes.byref(rounds))
+    assert r > 0 and err.value == 0                        # short warm-ups: the re-run path ran too
+    for s in range(S):
+        for ch in range(2):
+            assert np.array_equal(np.unpackbits(bits[ch, s].view(np.uint8), bitorder="little")[:M], refs[s]["bit"][ch]), ("bits", s, ch)
+            got = np.concatenate([np.stack([g * seg_len + (chips[ch, s, g, :counts[ch, s, g]] >> 3), chips[ch, s, g, :counts[ch, s, g]] & 7], axis=1)
+                                  for g in range(nseg)])
+            assert np.array_equal(got, oracle_t2a_chips(refs[s], ch)), ("chips", s, ch)
