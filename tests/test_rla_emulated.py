@@ -31,7 +31,7 @@ def emu():
     return L
 
 
-def run_emulated(emu, bit_rows, pushes, seg_len, lookback, flags=F_T1C1 | F_S1, descending=True):
+def run_emulated(emu, bit_rows, pushes, seg_len, lookback, flags=F_T1C1 | F_S1, descending=True, cap=None, expect_overflow=False):
     """bit_rows: [2][M] uint8 slicer bits of one capture; pushes: decimated samples per push."""
     ctypes.c_int.in_dll(emu, "wm_emu_descending").value = int(descending)   # see rla_emu.cpp: launch semantics
     sb = emu.wm_emu_rla_state_bytes()
@@ -39,7 +39,10 @@ def run_emulated(emu, bit_rows, pushes, seg_len, lookback, flags=F_T1C1 | F_S1, 
     for r in range(2):
         emu.wm_emu_rla_reset_state(carry[r * sb:].ctypes.data)
     out, m0, reruns = [[], []], 0, 0
-    cap = seg_len + 8 + 8192
+    # the product sizes a region as seg_len + 8 + 8192 chips (wm_api.hip); an interferer that drags the bit-length
+    # tracker far below one sample per chip can exceed that -- reported as an error there; the parity runs here
+    # give the emulated kernel all the room the oracle's chip count may need
+    cap = cap or 8 * seg_len + 8 + 8192
     for M in pushes:
         Mcap = (M + 255) // 256 * 256
         words = np.zeros((2, Mcap // 32), np.uint32)
@@ -53,6 +56,8 @@ def run_emulated(emu, bit_rows, pushes, seg_len, lookback, flags=F_T1C1 | F_S1, 
         err = ctypes.c_uint(0)
         r = emu.wm_emu_rla(words.ctypes.data, 1, M, Mcap, flags, seg_len, lookback, cap, carry.ctypes.data,
                            chips.ctypes.data, counts.ctypes.data, ctypes.byref(err))
+        if expect_overflow and err.value == 2:
+            return None, -1
         assert r >= 0 and err.value == 0
         reruns += r
         for ch in range(2):
@@ -110,3 +115,26 @@ def test_device_source_on_host_matches_oracle_across_pushes_and_synthetic(emu, o
             start = np.maximum.accumulate(np.where(new_edge, np.arange(len(want)), 0)) if len(want) else np.zeros(0, int)
             want = want[np.arange(len(want)) - start < 8192]
             assert np.array_equal(got[ch], want), (k, ch)
+
+
+def test_chip_region_overflow_is_reported_not_silent(emu, oracle, wm):
+    """A strong square-wave FM interferer (period 29 samples) drags the T1/C1 bit-length tracker far below one sample
+    per chip: the reference emits three chips per sample for a while.  With the product's region size the kernel
+    must raise the overflow flag (wmbus_process then fails with WMBUS_EOVERFLOW); with enough room it is exact."""
+    # found by a long emulation campaign (WMBUS_EMU_SEED=1030, case 904): quiet capture (noise 0.5 LSB), then the interferer
+    cu8 = wm.synth_capture(seed=912168056, n_samples=1 << 18, kinds=15, frames_per_s=120.0, amplitude=60.0, noise_sigma=0.5)[0]
+    a, per = 147918, 29
+    n_sq = min(cu8.size - a, 60000) // 2
+    t = np.arange(n_sq); ph = (t // per) % 2
+    cu8[a:a + 2 * n_sq:2] = 128 + 60 * np.cos(2 * np.pi * 0.03 * t * (2 * ph - 1))
+    cu8[a + 1:a + 2 * n_sq:2] = 128 + 60 * np.sin(2 * np.pi * 0.03 * t * (2 * ph - 1))
+    ref = oracle.run(cu8, flags_to_oracle_opts(oracle, ["-v"]), taps=True, chips=True)
+    oc = oracle_rla_chips(ref, 0)
+    assert np.bincount(oc[:, 0] // 8192).max() > 8192 + 8 + 8192          # the oracle really emits more than a region holds
+    got, reruns = run_emulated(emu, ref["bit"], [ref["m"]], 8192, 1024, cap=8192 + 8 + 8192, expect_overflow=True)
+    assert got is None and reruns == -1                                        # flagged
+    got, _ = run_emulated(emu, ref["bit"], [ref["m"]], 8192, 1024)
+    want = oc
+    new_edge = np.concatenate([[True], want[1:, 0] != want[:-1, 0]])
+    start = np.maximum.accumulate(np.where(new_edge, np.arange(len(want)), 0))
+    assert np.array_equal(got[0], want[np.arange(len(want)) - start < 8192])
