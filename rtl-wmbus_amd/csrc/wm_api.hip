@@ -289,7 +289,11 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
     c->Mcap = (c->ntiles_cap * T + 255) / 256 * 256;     /* whole tiles (partial tiles still store full runs); slicer-word rows 32-byte aligned */
     for (int a = 0; a < 2; a++) c->nseg_cap[a] = (c->Mcap + c->C[a] - 1) / c->C[a];
     c->cap[1] = c->C[1] / 4 + 8;   /* time2: the lock logic needs >= 4 samples per chip */
-    c->cap[0] = c->C[0] + 8 + WM_RLA_RUN_LIMIT;   /* run-length: one chip per sample at worst, plus one long run ending here */
+    /* run-length: the reference's bit-length tracker has no floor -- switch combinations (-d 3 -s -o -a on a capture
+     * with both modes) and interferers drag it to a third of a sample per chip for a while (3.1 chips per sample
+     * seen, found by the host emulation campaigns) -- so four chips per sample, plus one long run ending here;
+     * beyond that the push fails with WMBUS_EOVERFLOW */
+    c->cap[0] = 4u * c->C[0] + 8 + WM_RLA_RUN_LIMIT;
     c->in_stride = (WM_HIST_BYTES + cfg->max_push_bytes + WM_IN_SLACK + 255) / 256 * 256;
 
     const uint64_t rows = 2ull * c->S;

@@ -61,7 +61,7 @@ def framers_on_host(emu_clock, emu_rla, ref, seg1=32768, seg0=8192):
     ctypes.c_void_p.in_dll(emu_clock, "wm_emu_seen_out").value = None
     assert r >= 0 and err.value == 0
     # run-length
-    nseg0, cap0 = (M + seg0 - 1) // seg0, seg0 + 8 + 8192
+    nseg0, cap0 = (M + seg0 - 1) // seg0, 4 * seg0 + 8 + 8192
     chips0 = np.zeros((2, nseg0, cap0), np.uint32); counts0 = np.zeros((2, nseg0), np.uint32); seen0 = np.zeros((2, nseg0), np.uint32)
     sb = emu_rla.wm_emu_rla_state_bytes(); carry0 = np.zeros(2 * sb, np.uint8)
     for rr in range(2):

@@ -70,13 +70,15 @@ class HostPipeline:
                                       self.clk_carry.ctypes.data, bits.ctypes.data, chips1.ctypes.data, counts1.ctypes.data, ctypes.byref(err), None)
             ctypes.c_void_p.in_dll(self.clk, "wm_emu_seen_out").value = None
             assert r >= 0 and err.value == 0
-            nseg0, cap0 = (M + self.seg0 - 1) // self.seg0, self.seg0 + 8 + 8192
+            nseg0, cap0 = (M + self.seg0 - 1) // self.seg0, 4 * self.seg0 + 8 + 8192      # wm_api.hip: cap[0]
             chips0 = np.zeros((2, nseg0, cap0), np.uint32); counts0 = np.zeros((2, nseg0), np.uint32); seen0 = np.zeros((2, nseg0), np.uint32)
             ctypes.c_void_p.in_dll(self.rla, "wm_emu_seen_out").value = seen0.ctypes.data
             r = 0 if not self.flags & F_RLA else self.rla.wm_emu_rla(bits.ctypes.data, 1, M, Mcap, self.flags & (F_T1C1 | F_S1), self.seg0, self.lookback, cap0, self.rla_carry.ctypes.data,
                                     chips0.ctypes.data, counts0.ctypes.data, ctypes.byref(err))
             ctypes.c_void_p.in_dll(self.rla, "wm_emu_seen_out").value = None
-            assert r >= 0 and err.value == 0
+            if err.value:
+                print("RLA overflow:", dict(M=M, seg0=self.seg0, flags=self.flags, n0=self.n0, d=self.d, counts=counts0.tolist(), cap=cap0))
+            assert r >= 0 and err.value == 0, ("run-length framer", r, err.value, dict(M=M, seg0=self.seg0, lookback=self.lookback, flags=self.flags, n0=self.n0, max_count=int(counts0.max()), cap=cap0))
             fr = dict(geo=np.array([M, Mcap, self.flags, m0, self.seg0, self.seg1, nseg0, nseg1, cap0, cap1], np.uint64), chips=(chips0, chips1),
                       counts=(counts0, counts1), seen=(seen0, seen1))
             pending = [self.decs[(ch, al)][1] for al in range(2) for ch in range(2)]          # [algo][chain]

@@ -39,9 +39,8 @@ def run_emulated(emu, bit_rows, pushes, seg_len, lookback, flags=F_T1C1 | F_S1, 
     for r in range(2):
         emu.wm_emu_rla_reset_state(carry[r * sb:].ctypes.data)
     out, m0, reruns = [[], []], 0, 0
-    # the product sizes a region as seg_len + 8 + 8192 chips (wm_api.hip); an interferer that drags the bit-length
-    # tracker far below one sample per chip can exceed that -- reported as an error there; the parity runs here
-    # give the emulated kernel all the room the oracle's chip count may need
+    # the product sizes a region as 4 * seg_len + 8 + 8192 chips (wm_api.hip): the bit-length tracker has no floor and
+    # 3.1 chips per sample have been seen; beyond that the push fails loudly.  The parity runs here get more room still.
     cap = cap or 8 * seg_len + 8 + 8192
     for M in pushes:
         Mcap = (M + 255) // 256 * 256
@@ -119,8 +118,8 @@ def test_device_source_on_host_matches_oracle_across_pushes_and_synthetic(emu, o
 
 def test_chip_region_overflow_is_reported_not_silent(emu, oracle, wm):
     """A strong square-wave FM interferer (period 29 samples) drags the T1/C1 bit-length tracker far below one sample
-    per chip: the reference emits three chips per sample for a while.  With the product's region size the kernel
-    must raise the overflow flag (wmbus_process then fails with WMBUS_EOVERFLOW); with enough room it is exact."""
+    per chip: the reference emits three chips per sample for a while.  With a region of one chip per sample (the product's size until
+    this case was found; it is four chips per sample now) the kernel must raise the overflow flag (wmbus_process then fails with WMBUS_EOVERFLOW); with enough room it is exact."""
     # found by a long emulation campaign (WMBUS_EMU_SEED=1030, case 904): quiet capture (noise 0.5 LSB), then the interferer
     cu8 = wm.synth_capture(seed=912168056, n_samples=1 << 18, kinds=15, frames_per_s=120.0, amplitude=60.0, noise_sigma=0.5)[0]
     a, per = 147918, 29
