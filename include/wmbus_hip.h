@@ -67,9 +67,14 @@ typedef struct wmbus_cfg {
      * POLYPHASE = lp_ppf_butter_1600kHz_160kHz_200kHz (rtl_wmbus.c:258-294 over ppf.h:46-59), which
      * the reference defines but never calls: an extension, 1.6 MS/s (decimation 2, no -s) only. */
     int prefilter;
+    /* Discriminator arctangent: WMBUS_ATAN_LIBM = cargf / pi, what the reference is built with (atan2.h:7-10,
+     * rtl_wmbus.c:523-529); WMBUS_ATAN_APPROX1 / 2 = atan2_approximation / atan2_approximation2 (atan2.h:14-74),
+     * the alternatives its source keeps behind `#elif 0` / `#else`: extensions, ignored with -a. */
+    int atan_mode;
 } wmbus_cfg;
 
 enum { WMBUS_PREFILTER_BOXCAR = 0, WMBUS_PREFILTER_POLYPHASE = 1 };
+enum { WMBUS_ATAN_LIBM = 0, WMBUS_ATAN_APPROX1 = 1, WMBUS_ATAN_APPROX2 = 2 };
 
 typedef struct wmbus_ctx wmbus_ctx;
 

@@ -15,6 +15,8 @@
  *                       (rtl_wmbus.c:258-294, ppf.h:46-59; defined by the reference but never called
  *                       from its main()) in place of the two moving averages: one (i,q) pair feeds
  *                       both chains.
+ *   atan <1|2>          stdin = float pairs (imaginary, real); stdout = the reference's atan2_approximation /
+ *                       atan2_approximation2 (atan2.h:14-74) of each pair, as raw floats
  *   chips <chain> <algo-tag>   stdin = (chip value, rssi) byte pairs -> reference packet decoder;
  *                       datagram lines appear on stdout exactly as the reference prints them.
  */
@@ -113,12 +115,24 @@ static int mode_chips(int chain, const char *tag)
     return 0;
 }
 
+static int mode_atan(int which)
+{
+    float p[2];
+    while (fread(p, sizeof(float), 2, stdin) == 2) {
+        const float complex s = p[1] + p[0] * _Complex_I;
+        const float r = which == 1 ? atan2_approximation(s) : atan2_approximation2(s);
+        fwrite(&r, sizeof r, 1, stdout);
+    }
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc >= 3 && !strcmp(argv[1], "atan")) return mode_atan(atoi(argv[2]));
     if (argc >= 2 && !strcmp(argv[1], "tables")) return mode_tables();
     if (argc >= 3 && !strcmp(argv[1], "stages"))
         return mode_stages(argv[2], argc >= 4 && strchr(argv[3], 'a') != NULL, argc >= 4 && strchr(argv[3], 'p') != NULL);
     if (argc >= 4 && !strcmp(argv[1], "chips")) { opts_show_used_algorithm = 1; return mode_chips(atoi(argv[2]), argv[3]); }
-    fprintf(stderr, "usage: ref_probe tables | stages <prefix> [a][p] | chips <chain> <tag>\n");
+    fprintf(stderr, "usage: ref_probe tables | stages <prefix> [a][p] | atan <1|2> | chips <chain> <tag>\n");
     return 2;
 }

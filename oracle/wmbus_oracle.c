@@ -413,6 +413,50 @@ struct wmo_ctx {
     wmo_taps *taps;
 };
 
+/* atan2.h:14-41 (y = imaginary, x = real part of s * conj(s_prev)).  `fabs` there is the double function:
+ * |y| + 1e-10f is formed in double and rounded to float by the assignment.  Note that the result is
+ * NOT divided by pi although the polynomial's coefficients are (the reference's text, kept as it is). */
+static float atan2_approx1(float y, float x)
+{
+    static const float ONEQTR_PI = M_PI / 4.0;
+    static const float THRQTR_PI = 3.0 * M_PI / 4.0;
+    float r, angle;
+    float abs_y = fabs(y) + 1e-10f;
+    if (x < 0.0f) { r = (x + abs_y) / (abs_y - x); angle = THRQTR_PI; }
+    else { r = (x - abs_y) / (x + abs_y); angle = ONEQTR_PI; }
+    angle += (0.1963f * (float)M_1_PI * r * r - 0.9817f * (float)M_1_PI) * r;
+    if (y < 0.0f) angle = -angle;
+    return angle;
+}
+
+/* atan2.h:44-74 */
+static float atan2_approx2(float y, float x)
+{
+    if (x == 0.0f) {
+        if (y > 0.0f) return 0.5f;
+        if (y == 0.0f) return 0.0f;
+        return -0.5f;
+    }
+    float atan;
+    const float z = y / x;
+    if (fabs(z) < 1.0f) {
+        atan = z / (1.0f * (float)M_PI + 0.28086f * (float)M_PI * z * z);
+        if (x < 0.0f) {
+            if (y < 0.0f) return atan - 1.0f;
+            return atan + 1.0f;
+        }
+    } else {
+        atan = 0.5f - z / (z * z + 0.28086f) * (float)M_1_PI;
+        if (y < 0.0f) return atan - 1.0f;
+    }
+    return atan;
+}
+
+void wmo_atan2_approx(int which, const float *im, const float *re, float *out, size_t n)
+{
+    for (size_t i = 0; i < n; i++) out[i] = which == 1 ? atan2_approx1(im[i], re[i]) : atan2_approx2(im[i], re[i]);
+}
+
 void wmo_default_opts(wmo_opts *o)
 {
     memset(o, 0, sizeof *o);
@@ -596,7 +640,7 @@ static void chain_step(wmo_ctx *c, chain_state *ch)
         const float cr = ch->pi, ci = -ch->pq;
         const float re = i * cr - q * ci;
         const float im = i * ci + q * cr;
-        dphi_raw = atan2f(im, re) * (float)M_1_PI;
+        dphi_raw = c->o.atan_mode == 1 ? atan2_approx1(im, re) : c->o.atan_mode == 2 ? atan2_approx2(im, re) : atan2f(im, re) * (float)M_1_PI;
     } else {
         dphi_raw = ch->pi * q - i * ch->pq;
     }

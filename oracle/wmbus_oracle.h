@@ -40,7 +40,13 @@ typedef struct wmo_opts {
     int prefilter;           /* 0: the moving averages main() calls (rtl_wmbus.c:1333-1344);
                                 1: the polyphase low-pass the reference defines but never calls
                                    (rtl_wmbus.c:258-294, ppf.h:46-59), d = 2 only, no -s */
+    int atan_mode;           /* 0: cargf / pi (what the reference is built with, atan2.h:7-10, rtl_wmbus.c:523-529);
+                                1, 2: atan2_approximation / atan2_approximation2 (atan2.h:14-74), the alternatives
+                                the reference keeps behind `#elif 0` / `#else` */
 } wmo_opts;
+
+/* The two approximations of atan2.h on arrays (for pinning against the reference's own functions). */
+void wmo_atan2_approx(int which, const float *im, const float *re, float *out, size_t n);
 
 void wmo_default_opts(wmo_opts *o);
 

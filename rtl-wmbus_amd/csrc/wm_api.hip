@@ -265,6 +265,8 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
         return bail(fail(c, WMBUS_EINVAL, "max_push_bytes must be a positive multiple of 4096"));
     if (cfg->prefilter != WMBUS_PREFILTER_BOXCAR && cfg->prefilter != WMBUS_PREFILTER_POLYPHASE)
         return bail(fail(c, WMBUS_EINVAL, "prefilter must be WMBUS_PREFILTER_BOXCAR or WMBUS_PREFILTER_POLYPHASE"));
+    if (cfg->atan_mode < WMBUS_ATAN_LIBM || cfg->atan_mode > WMBUS_ATAN_APPROX2)
+        return bail(fail(c, WMBUS_EINVAL, "atan_mode must be WMBUS_ATAN_LIBM, WMBUS_ATAN_APPROX1 or WMBUS_ATAN_APPROX2"));
     if (cfg->prefilter == WMBUS_PREFILTER_POLYPHASE && (cfg->decimation != 2 || cfg->simultaneous))
         return bail(fail(c, WMBUS_EINVAL, "the polyphase pre-filter is the 1.6 MS/s design of rtl_wmbus.c:258-294: decimation 2, no -s"));
     if (wmbus_device_count() <= cfg->device) return bail(fail(c, WMBUS_ENODEVICE, "no HIP device %d (this library has no CPU fallback)", cfg->device));
@@ -279,7 +281,8 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
     c->cfg.warmup_t1c1 = cfg->warmup_t1c1 ? (cfg->warmup_t1c1 + 31u) & ~31u : 12288u;   /* whole 32-sample blocks */
     c->cfg.warmup_s1 = cfg->warmup_s1 ? (cfg->warmup_s1 + 31u) & ~31u : 24576u;
     c->cfg.rla_lookback = cfg->rla_lookback ? (cfg->rla_lookback + 31u) & ~31u : 1024u;
-    c->flags = (cfg->simultaneous ? WM_F_SHIFT : 0) | (cfg->accurate_atan ? WM_F_ACCURATE : 0) | (cfg->remove_dc ? WM_F_DC : 0) |
+    c->flags = (cfg->atan_mode == WMBUS_ATAN_APPROX1 ? WM_F_APPROX1 : cfg->atan_mode == WMBUS_ATAN_APPROX2 ? WM_F_APPROX2 : 0) |
+               (cfg->simultaneous ? WM_F_SHIFT : 0) | (cfg->accurate_atan ? WM_F_ACCURATE : 0) | (cfg->remove_dc ? WM_F_DC : 0) |
                (cfg->t1c1_enabled ? WM_F_T1C1 : 0) | (cfg->s1_enabled ? WM_F_S1 : 0) | (cfg->rla_enabled ? WM_F_RLA : 0) |
                (cfg->time2_enabled ? WM_F_T2A : 0);
     c->T = (uint32_t)WM_K1_TILE2;

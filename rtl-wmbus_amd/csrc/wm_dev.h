@@ -89,7 +89,8 @@ struct WmPush {
 
 enum {
     WM_F_SHIFT = 1, WM_F_ACCURATE = 2, WM_F_DC = 4, WM_F_T1C1 = 8, WM_F_S1 = 16,
-    WM_F_RLA = 32, WM_F_T2A = 64
+    WM_F_RLA = 32, WM_F_T2A = 64,
+    WM_F_APPROX1 = 128, WM_F_APPROX2 = 256     /* atan2_approximation / atan2_approximation2 instead of cargf (options) */
 };
 
 /* error word bits (device -> host) */

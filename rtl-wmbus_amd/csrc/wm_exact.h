@@ -269,6 +269,45 @@ WM_HD float wm_discriminator(float i, float q, float pi_, float pq_)
     return wm_mul(wm_atan2f(im, re), wm_u2f(0x3ea2f983u));        /* (float)M_1_PI */
 }
 
+/* The two approximations the reference keeps behind `#elif 0` / `#else` (atan2.h:14-74), operation by
+ * operation; y = imaginary, x = real part of s * conj(s_prev).  Both only use ratios of x and y (and
+ * comparisons with zero), so they may be fed the unscaled boxcar sums like the exact version: every
+ * product and sum of those is an exactly representable integer, and the 1e-10 "kludge" of the first one
+ * only matters at y = 0.  Options (wmbus_cfg.atan_mode), never the default. */
+WM_HD float wm_atan2_approx1(float y, float x)
+{
+    const float oneqtr_pi = (float)(3.14159265358979323846 / 4.0), thrqtr_pi = (float)(3.0 * 3.14159265358979323846 / 4.0);
+    const float m_1_pi = wm_u2f(0x3ea2f983u);                                  /* (float)M_1_PI */
+    const float abs_y = (float)((double)wm_u2f(wm_f2u(y) & 0x7fffffffu) + (double)1e-10f);   /* fabs() is the double function there */
+    const int neg = x < 0.0f;
+    const float r = neg ? wm_div(wm_add(x, abs_y), wm_sub(abs_y, x)) : wm_div(wm_sub(x, abs_y), wm_add(x, abs_y));
+    float angle = neg ? thrqtr_pi : oneqtr_pi;
+    const float p = wm_sub(wm_mul(wm_mul(wm_mul(0.1963f, m_1_pi), r), r), wm_mul(0.9817f, m_1_pi));
+    angle = wm_add(angle, wm_mul(p, r));
+    return y < 0.0f ? -angle : angle;
+}
+
+WM_HD float wm_atan2_approx2(float y, float x)
+{
+    const float m_pi = (float)3.14159265358979323846, m_1_pi = wm_u2f(0x3ea2f983u);
+    if (x == 0.0f) return y > 0.0f ? 0.5f : y == 0.0f ? 0.0f : -0.5f;
+    const float z = wm_div(y, x);
+    if (wm_u2f(wm_f2u(z) & 0x7fffffffu) < 1.0f) {
+        const float at = wm_div(z, wm_add(wm_mul(1.0f, m_pi), wm_mul(wm_mul(wm_mul(0.28086f, m_pi), z), z)));
+        return x < 0.0f ? (y < 0.0f ? wm_sub(at, 1.0f) : wm_add(at, 1.0f)) : at;
+    }
+    const float at = wm_sub(0.5f, wm_mul(wm_div(z, wm_add(wm_mul(z, z), 0.28086f)), m_1_pi));
+    return y < 0.0f ? wm_sub(at, 1.0f) : at;
+}
+
+WM_HD float wm_discriminator_approx(float i, float q, float pi_, float pq_, int which)
+{
+    const float c = pi_, d = -pq_;
+    const float re = wm_sub(wm_mul(i, c), wm_mul(q, d));
+    const float im = wm_add(wm_mul(i, d), wm_mul(q, c));
+    return which == 1 ? wm_atan2_approx1(im, re) : wm_atan2_approx2(im, re);
+}
+
 /* -a variant (rtl_wmbus.c:536-551 / 572-586). */
 WM_HD float wm_discriminator_fast(float i, float q, float pi_, float pq_)
 {

@@ -271,6 +271,7 @@ __global__ __launch_bounds__(256) void k1_demod2(K1Args a)
     const int tn = min(T, (int)g.M - ts);
     const bool chT = g.flags & WM_F_T1C1, chS = g.flags & WM_F_S1;
     const bool accurate = g.flags & WM_F_ACCURATE;
+    const int approx = (g.flags & WM_F_APPROX1) ? 1 : (g.flags & WM_F_APPROX2) ? 2 : 0;   /* option: atan2.h's approximations */
 
     if (tid < WM_ATAN_TAB_WORDS) wm_atan_tab_word(tid, tab);   /* 5 range rows + range LUT */
 
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(256) void k1_demod2(K1Args a)
             fT[j][0] = (float)s8[j].x; fT[j][1] = (float)s8[j].y;          /* 8 x the reference's i, q */
             fS[j][0] = (float)s16[j].x; fS[j][1] = (float)s16[j].y;       /* 16 x */
         }
-        if (accurate && chT && chS) {                        /* default switches: no branch between the eight */
+        if (accurate && chT && chS && !approx) {             /* default switches: no branch between the eight */
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 drT[j] = wm_discriminator_tab(fT[j + 1][0], fT[j + 1][1], fT[j][0], fT[j][1], tab);
@@ -364,12 +365,15 @@ __global__ __launch_bounds__(256) void k1_demod2(K1Args a)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const float iT = fT[j + 1][0], qT = fT[j + 1][1], iS = fS[j + 1][0], qS = fS[j + 1][1];
-                drT[j] = !chT ? 0.0f : accurate ? wm_discriminator_tab(iT, qT, fT[j][0], fT[j][1], tab)
+                drT[j] = !chT ? 0.0f : accurate ? (approx ? wm_discriminator_approx(iT, qT, fT[j][0], fT[j][1], approx) : wm_discriminator_tab(iT, qT, fT[j][0], fT[j][1], tab))
                                                 : wm_mul(wm_discriminator_fast(iT, qT, fT[j][0], fT[j][1]), 0.015625f);
-                drS[j] = !chS ? 0.0f : accurate ? wm_discriminator_tab(iS, qS, fS[j][0], fS[j][1], tab)
+                drS[j] = !chS ? 0.0f : accurate ? (approx ? wm_discriminator_approx(iS, qS, fS[j][0], fS[j][1], approx) : wm_discriminator_tab(iS, qS, fS[j][0], fS[j][1], tab))
                                                 : wm_mul(wm_discriminator_fast(iS, qS, fS[j][0], fS[j][1]), 0.00390625f);
                 mgT[j] = chT ? wm_mul(wm_sqrt_dom(wm_add(wm_mul(iT, iT), wm_mul(qT, qT))), 0.125f) : 0.0f;
                 mgS[j] = chS ? wm_mul(wm_sqrt_dom(wm_add(wm_mul(iS, iS), wm_mul(qS, qS))), 0.0625f) : 0.0f;
+                /* before the first sample of the stream the FIR's delay line holds zeros, not the discriminator
+                 * of zero input -- the same thing for cargf and -a, but atan2_approximation(0, 0) is not 0 */
+                if (approx && (long)(g.m0 + (uint64_t)ts) + 4 * c + j < (long)WM_K1_HALO) { drT[j] = 0.0f; drS[j] = 0.0f; }
             }
         }
         /* element a of a discriminator row lives at word a + 4 */
@@ -428,6 +432,7 @@ __global__ __launch_bounds__(256) void k1_demod_ppf(K1Args a)
     const int tn = min(T, (int)g.M - ts);
     const bool chT = g.flags & WM_F_T1C1, chS = g.flags & WM_F_S1;
     const bool accurate = g.flags & WM_F_ACCURATE;
+    const int approx = (g.flags & WM_F_APPROX1) ? 1 : (g.flags & WM_F_APPROX2) ? 2 : 0;   /* option: atan2.h's approximations */
 
     /* ---- stage 0: bytes -> floats (rtl_wmbus.c:1312-1313), no truncation on this path; samples
      * before the start of the stream are the filters' zero history, not the byte the input window
@@ -479,7 +484,8 @@ __global__ __launch_bounds__(256) void k1_demod_ppf(K1Args a)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const float i = fi[j + 1], q = fq[j + 1], pi_ = fi[j], pq_ = fq[j];
-            dr[j] = accurate ? wm_discriminator(i, q, pi_, pq_) : wm_discriminator_fast(i, q, pi_, pq_);
+            dr[j] = !accurate ? wm_discriminator_fast(i, q, pi_, pq_) : approx ? wm_discriminator_approx(i, q, pi_, pq_, approx) : wm_discriminator(i, q, pi_, pq_);
+            if (approx && (long)(g.m0 + (uint64_t)ts) + 4 * tid + j < (long)WM_K1_HALO) dr[j] = 0.0f;   /* the FIR's delay line starts from zeros */
             mg[j] = wm_sqrt(wm_add(wm_mul(i, i), wm_mul(q, q)));
         }
         *(float4 *)(yDr + 4 * tid + 4) = make_float4(dr[0], dr[1], dr[2], dr[3]);

@@ -44,6 +44,7 @@ static void print_usage(const char *prog)
     fprintf(stdout, "\t-f exit if flow of incoming data stops\n");
     fprintf(stdout, "\t-B bytes per GPU push (multiple of 4096, default 1048576)\n");
     fprintf(stdout, "\t-G HIP device ordinal (default 0)\n");
+    fprintf(stdout, "\t-A 1|2 atan2_approximation / atan2_approximation2 (atan2.h) instead of cargf in the discriminator\n");
     fprintf(stdout, "\t-P polyphase low-pass (ppf.h) instead of the moving average before decimation (1.6 MS/s, -d 2, no -s)\n");
     fprintf(stdout, "\t-T host:port read the cu8 stream from a TCP server instead of stdin\n");
     fprintf(stdout, "\tFILE... batch mode: decode several cu8 files at once (lines prefixed with the file name)\n");
@@ -182,7 +183,7 @@ int main(int argc, char **argv)
     cfg.max_push_bytes = 1u << 20;
     int check_flow = 0, opt;
     const char *tcp = NULL;
-    while ((opt = getopt(argc, argv, "ofad:p:r:vVst:B:G:PT:")) != -1) {
+    while ((opt = getopt(argc, argv, "ofad:p:r:vVst:B:G:PT:A:")) != -1) {
         switch (opt) {
         case 'o': cfg.remove_dc = 1; break;
         case 'f': check_flow = 1; break;
@@ -201,6 +202,7 @@ int main(int argc, char **argv)
         case 'B': cfg.max_push_bytes = (size_t)strtoull(optarg, NULL, 10) / WMBUS_BLOCK_BYTES * WMBUS_BLOCK_BYTES; break;
         case 'G': cfg.device = atoi(optarg); break;
         case 'P': cfg.prefilter = WMBUS_PREFILTER_POLYPHASE; break;
+        case 'A': cfg.atan_mode = atoi(optarg); break;
         case 'T': tcp = optarg; break;
         default: print_usage(argv[0]); return EXIT_FAILURE;
         }

@@ -29,7 +29,8 @@ class Opts(ctypes.Structure):
                 ("accurate_atan", ctypes.c_int), ("remove_dc", ctypes.c_int),
                 ("t1c1_enabled", ctypes.c_int), ("s1_enabled", ctypes.c_int),
                 ("rla_enabled", ctypes.c_int), ("time2_enabled", ctypes.c_int),
-                ("show_algorithm", ctypes.c_int), ("fixed_timestamp", ctypes.c_int), ("prefilter", ctypes.c_int)]
+                ("show_algorithm", ctypes.c_int), ("fixed_timestamp", ctypes.c_int), ("prefilter", ctypes.c_int),
+                ("atan_mode", ctypes.c_int)]
 
 
 class Chip(ctypes.Structure):
@@ -73,13 +74,14 @@ def lib():
 
 
 def make_opts(decimation=2, simultaneous=0, accurate_atan=1, remove_dc=0, t1c1=1, s1=1, rla=1,
-              time2=1, show_algorithm=1, prefilter=0):
+              time2=1, show_algorithm=1, prefilter=0, atan_mode=0):
     o = Opts()
     lib().wmo_default_opts(ctypes.byref(o))
     o.decimation, o.simultaneous, o.accurate_atan, o.remove_dc = decimation, simultaneous, accurate_atan, remove_dc
     o.t1c1_enabled, o.s1_enabled, o.rla_enabled, o.time2_enabled = t1c1, s1, rla, time2
     o.show_algorithm, o.fixed_timestamp = show_algorithm, 1
     o.prefilter = prefilter
+    o.atan_mode = atan_mode
     return o
 
 

@@ -362,3 +362,21 @@ def test_full_size_batch_properties(wm):
         tx = {f["telegram"].hex() for f in sent[s]}
         assert good <= tx
         assert all(f["telegram"].hex() in good for f in sent[s] if f["complete"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("atan_mode", [1, 2])
+@pytest.mark.parametrize("flags,fs,kw", [(["-v"], 1600, {}), (["-v", "-d", "3", "-s"], 2400, dict(t1c1_center_khz=325.0, s1_center_khz=-325.0))])
+def test_atan2_approximation_options_match_oracle(wm, oracle, atan_mode, flags, fs, kw):
+    """wmbus_cfg.atan_mode (CLI -A): atan2.h's approximations in the discriminator; the oracle's functions are
+    pinned to the reference's own (test_oracle_units.py)."""
+    cu8 = wm.synth_capture(seed=31 + atan_mode, n_samples=1 << 19, fs_khz=fs, kinds=15, frames_per_s=150.0, amplitude=60.0, **kw)[0]
+    oo = flags_to_oracle_opts(oracle, flags)
+    oo.atan_mode = atan_mode
+    ref = oracle.run(cu8, oo, taps=True, chips=True)
+    with wm.Receiver(n_streams=1, max_push_bytes=cu8.size, atan_mode=atan_mode, **flags_to_kwargs(flags)) as rx:
+        assert rx.run(cu8, push_bytes=4096 * 50)[0] == ref["text"]
+    with wm.Receiver(n_streams=1, max_push_bytes=cu8.size, atan_mode=atan_mode, **flags_to_kwargs(flags)) as rx:
+        assert rx.run(cu8)[0] == ref["text"]
+        compare_taps(rx, ref)
+        compare_chips(rx, ref)

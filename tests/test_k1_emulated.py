@@ -68,11 +68,12 @@ def run_emulated(emu, cu8, d, flags, push_bytes, polyphase=0):
     return [np.concatenate(x) for x in out_d], [np.concatenate(x) for x in out_r], repaired
 
 
-def check(emu, oracle, cu8, flags_cli, d, pushes, polyphase=0):
+def check(emu, oracle, cu8, flags_cli, d, pushes, polyphase=0, atan_mode=0):
     oo = flags_to_oracle_opts(oracle, flags_cli)
     oo.prefilter = polyphase
+    oo.atan_mode = atan_mode
     ref = oracle.run(cu8, oo, taps=True)
-    flags = F_T1C1 | F_S1 | (F_SHIFT if "-s" in flags_cli else 0) | (0 if "-a" in flags_cli else F_ACCURATE)   # -a = the fast discriminator
+    flags = F_T1C1 | F_S1 | (F_SHIFT if "-s" in flags_cli else 0) | (0 if "-a" in flags_cli else F_ACCURATE) | (128 * atan_mode)   # -a = the fast discriminator; 128 / 256 = WM_F_APPROX1 / 2
     dphi, rssi, repaired = run_emulated(emu, cu8, d, flags, pushes, polyphase)
     for ch in (0, 1):
         assert len(dphi[ch]) == ref["m"]
@@ -122,3 +123,15 @@ def test_randomised_captures_on_host(emu, oracle, wm):
             cu8[a:a + int(rng.integers(4096, cu8.size // 2))] = int(rng.choice([0, 127, 128, 255]))
         flags_cli = ["-v"] + (["-d", str(d)] if d != 2 else []) + (["-s"] if shift else []) + (["-a"] if rng.random() < 0.2 else [])
         check(emu, oracle, cu8, flags_cli, d, [int(x) * 4096 for x in rng.integers(1, 30, 4)])
+
+
+@pytest.mark.parametrize("atan_mode", [1, 2])
+@pytest.mark.parametrize("d,extra,polyphase", [(2, [], 0), (3, ["-s"], 0), (2, [], 1)])
+def test_atan2_approximation_options_on_host(emu, oracle, wm, atan_mode, d, extra, polyphase):
+    """wmbus_cfg.atan_mode: atan2.h's two approximations in place of cargf (options of the reference's source,
+    never compiled into its binary): the kernel against the oracle, whose functions are pinned to the
+    reference's own (tests/test_oracle_units.py)."""
+    kw = dict(t1c1_center_khz=325.0, s1_center_khz=-325.0) if "-s" in extra else {}
+    cu8 = wm.synth_capture(seed=900 + d + atan_mode, n_samples=1 << 16, fs_khz=FS[d], kinds=15, frames_per_s=200.0, amplitude=50.0, **kw)[0]
+    cu8[cu8.size // 2: cu8.size // 2 + 20000] = 128                       # exact silence: x = y = 0
+    check(emu, oracle, cu8, ["-v"] + (["-d", str(d)] if d != 2 else []) + extra, d, [4096 * 9, 4096 * 2], polyphase, atan_mode)

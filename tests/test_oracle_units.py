@@ -75,3 +75,25 @@ def test_reference_decoder_accepts_oracle_chip_log(wm):
             got = O.mask_ts(out).decode().splitlines()
             want = [l for l in lines if l.startswith(tag) and l.split(";")[1] in mode]
             assert got == want
+
+
+@pytest.mark.parametrize("which", [1, 2])
+def test_atan2_approximations_equal_the_references_own_functions(which):
+    """atan2.h:14-74: the two approximations the reference keeps behind `#elif 0` / `#else` -- the oracle's
+    restatement (wmo_opts.atan_mode) against the reference's functions, bit for bit, on discriminator-like
+    operands (products of small integers), special values and random floats."""
+    import ctypes
+    rng = np.random.default_rng(which)
+    ints = rng.integers(-4000, 4001, (200000, 2)).astype(np.float32)
+    scaled = (ints * np.float32(1 / 64)).astype(np.float32)
+    rnd = rng.standard_normal((100000, 2)).astype(np.float32) * np.float32(10.0) ** rng.integers(-12, 6, (100000, 1)).astype(np.float32)
+    special = np.array([[0, 0], [0, 1], [0, -1], [1, 0], [-1, 0], [1e-10, 1], [-1e-10, 1], [1e-11, -1], [3, 3], [3, -3], [-3, 3], [-3, -3]], np.float32)
+    pairs = np.concatenate([ints, scaled, rnd, special]).astype(np.float32)            # columns: imaginary, real
+    p = subprocess.run([O.REF_PROBE, "atan", str(which)], input=pairs.tobytes(), stdout=subprocess.PIPE, check=True)
+    want = np.frombuffer(p.stdout, np.float32)
+    got = np.zeros(len(pairs), np.float32)
+    L = O.lib()
+    L.wmo_atan2_approx.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    im, re = np.ascontiguousarray(pairs[:, 0]), np.ascontiguousarray(pairs[:, 1])
+    L.wmo_atan2_approx(which, im.ctypes.data, re.ctypes.data, got.ctypes.data, len(pairs))
+    assert len(want) == len(got) and np.array_equal(want.view(np.uint32), got.view(np.uint32))

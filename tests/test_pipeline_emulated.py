@@ -59,7 +59,7 @@ class HostPipeline:
         if M > 0:
             Mcap = max(256, ((M + 975) // 976 * 976 + 255) // 256 * 256)
             dphi = np.zeros((2, Mcap), np.float32); rssi = np.zeros((2, Mcap), np.uint8); err = ctypes.c_uint(0)
-            assert self.k1.wm_emu_k1(self.row.ctypes.data, self.stride, 1, d, self.flags & 3 | F_T1C1 | F_S1, self.n0, n_new, Mcap, dphi.ctypes.data,
+            assert self.k1.wm_emu_k1(self.row.ctypes.data, self.stride, 1, d, self.flags & (3 | 128 | 256) | F_T1C1 | F_S1, self.n0, n_new, Mcap, dphi.ctypes.data,
                                      rssi.ctypes.data, self.ema.ctypes.data, ctypes.byref(err), self.polyphase) >= 0 and err.value == 0
             dphi[:, M:] = 0                                     # rows beyond M are scratch for the framers
             nseg1, cap1 = (M + self.seg1 - 1) // self.seg1, self.seg1 // 4 + 8
@@ -206,3 +206,13 @@ def test_gpu_fuzz_configurations_through_the_emulated_pipeline(libs, oracle, wm)
         assert got == want, (k, c["flags"], c["tune"])
         ran += 1; n_lines += len(got.splitlines())
     assert ran >= n - 1 and (n < 6 or n_lines > 0)
+
+
+@pytest.mark.parametrize("atan_mode", [1, 2])
+def test_atan2_approximation_options_through_the_emulated_pipeline(libs, oracle, wm, atan_mode):
+    cu8 = wm.synth_capture(seed=4242 + atan_mode, n_samples=1 << 18, kinds=15, frames_per_s=200.0, amplitude=60.0)[0]
+    oo = flags_to_oracle_opts(oracle, ["-v"])
+    oo.atan_mode = atan_mode
+    ref = oracle.run(cu8, oo)
+    got = run_capture(libs, cu8, [4096 * 21, 4096 * 4], flags=F_ACCURATE | F_T1C1 | F_S1 | F_RLA | F_T2A | (128 * atan_mode))
+    assert got == ref["text"] and len(got.splitlines()) > 4
