@@ -101,16 +101,41 @@ def cpu_baseline(caps, n_samples):
     finally:
         shutil.rmtree(d, ignore_errors=True)
     total = cores * reps * n_samples
-    return {"value": round(total / dt / 1e6, 2), "unit": "Msamples/s", "cores": cores, "kind": kind,
+    return {"value": round(total / dt / 1e6, 2), "unit": "Msamples/s", "cores": cores, "host_cores": os.cpu_count(), "kind": kind,
             "single_core_msamples_s": round(n_samples / one / 1e6, 2),
             "sample": f"{cores} concurrent processes x {reps} passes over a capture of {n_samples} IQ samples "
                       f"({os.path.basename(exe)} -O3, default switches, input from /dev/shm), {dt:.1f} s wall"}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: become the launcher.  One child per GPU with the
+    environment torch.distributed.run would give it (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*); rank 0's
+    stdout (the JSON line) passes through.  Fails loudly when the node has fewer than N devices."""
+    import socket
+    wm = importlib.import_module("rtl-wmbus_amd")
+    have = wm.device_count()
+    if have < n and not os.environ.get("WMBUS_BENCH_DEVICE"):
+        raise SystemExit(f"bench.py: --gpus {n} but only {have} HIP device(s) visible")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rcs = [p.wait() for p in procs]
+    raise SystemExit(max(rcs, key=abs))
+
+
 def main():
     a = parse()
     shard = importlib.import_module("rtl-wmbus_amd.shard")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        spawn_ranks(a.gpus)
     rank, world, local = shard.rank_env()
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
     # WMBUS_BENCH_BACKEND=gloo WMBUS_BENCH_DEVICE=0: several ranks on ONE GPU, to exercise the N > 1
     # code path on a single-GPU box (RCCL refuses two ranks on one device); never set by the driver
     dist = shard.init(world, local, backend=os.environ.get("WMBUS_BENCH_BACKEND"))   # imports torch BEFORE the HIP library
@@ -191,8 +216,32 @@ def main():
         res = list(pool.map(lambda i: run_ctx(i, k_steps, stagger_s), range(nctx)))
         return sum(r[0] for r in res), [r[1] for r in res]
 
+    def texts_of_last_push():
+        """Datagram text of every capture (index within the rank's batch) as its context's last push printed it."""
+        per, base_ = collections.defaultdict(list), 0
+        for i, rx in enumerate(rxs):
+            for ln in rx.lines():
+                per[base_ + ln["stream"]].append(ln["text"])
+            base_ += per_ctx[i]
+        return ["".join(per[s_]) for s_ in range(S)]
+
+    # ---- parity, part 1 (untimed, before the warm-up): the FIRST pass of every context starts from the
+    # reference's zero-initialised state, exactly like a fresh oracle run, so EVERY capture of EVERY context is
+    # compared with the oracle's text (farmed over this host's cores).
+    parity, passes_done = None, 0
+    if not a.no_check:
+        import oracle_ffi as O
+        run_steps(1, 0.0)
+        passes_done += 1
+        got = texts_of_last_push()
+        t_o = time.perf_counter()
+        want = O.run_many(caps, O.make_opts(), threads=max(1, (os.cpu_count() or 1) // max(1, world)))
+        bad = [s_ for s_ in range(S) if got[s_] != want[s_]]
+        parity = {"first_pass": {"captures_compared": S, "contexts": nctx, "mismatches": len(bad), "first_bad": bad[:4],
+                                 "datagrams": sum(len(t.splitlines()) for t in want), "oracle_s": round(time.perf_counter() - t_o, 1)}}
     if a.warmup:
         run_steps(a.warmup, 0.0)
+        passes_done += a.warmup
     stagger = max(0.0, a.stagger)
 
     def barrier():
@@ -203,6 +252,7 @@ def main():
     lines_total, tim_ctx = run_steps(a.steps, stagger if nctx > 1 else 0.0)
     barrier()
     elapsed = time.perf_counter() - t0
+    passes_done += a.steps
     elapsed = shard.max_over_ranks(dist, elapsed)
     lines_total = int(shard.sum_over_ranks(dist, lines_total))
     demod_ms = sum(tm["demod_ms"] for tims in tim_ctx for tm in tims)
@@ -222,6 +272,7 @@ def main():
             rx.process(push_bytes)
             rx.collect()
             alone_ms.append(rx.timing()["demod_ms"])
+        passes_done += 1
     k1_avg_s = sum(alone_ms) / max(1, len(alone_ms)) / 1e3
     k1_concurrent_ms = demod_ms / max(1, k1_launches)
     achieved = BYTES_PER_SAMPLE * samples_per_launch / k1_avg_s / 1e9 if k1_avg_s > 0 else 0.0
@@ -232,6 +283,26 @@ def main():
             traffic = int(json.load(open(tf))["k1_demod_hbm_bytes_per_input_sample"] * samples_per_launch)
         except Exception:
             traffic = None
+
+    # ---- parity, part 2: the LAST pass (carried filter / framer / decoder state of every earlier pass) of the
+    # first and last capture of every 64-capture wave of every context, against an oracle instance that has been
+    # fed the same capture the same number of times.
+    if parity is not None:
+        got = texts_of_last_push()
+        picks, base_ = [], 0
+        for i in range(nctx):
+            for w0 in range(0, per_ctx[i], 64):
+                picks += sorted({base_ + w0, base_ + min(w0 + 63, per_ctx[i] - 1)})
+            base_ += per_ctx[i]
+        t_o = time.perf_counter()
+        want = O.run_many([caps[s_] for s_ in picks], O.make_opts(), passes=passes_done,
+                          threads=max(1, (os.cpu_count() or 1) // max(1, world)))
+        bad = [s_ for s_, w in zip(picks, want) if got[s_] != w]
+        parity["last_pass"] = {"captures_compared": len(picks), "contexts": nctx, "pass_number": passes_done, "mismatches": len(bad),
+                               "first_bad": bad[:4], "oracle_s": round(time.perf_counter() - t_o, 1)}
+        n_bad = int(shard.sum_over_ranks(dist, parity["first_pass"]["mismatches"] + len(bad)))
+        parity["ranks"] = world
+        parity["ok"] = n_bad == 0
 
     if rank == 0:
         last = tim_acc[-1]
@@ -263,17 +334,12 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(caps, n)
-        if not a.no_check:
-            import oracle_ffi as O
-            # strict end-to-end check on the bench's own configuration: the datagram text of four captures
-            # of context 0 (first and last wave of its batch), as produced by its last pass, against the oracle
-            rx = rxs[0]
-            per = collections.defaultdict(list)
-            for ln in rx.lines():
-                per[ln["stream"]].append(ln["text"])
-            picks = sorted({0, 1, per_ctx[0] // 2, per_ctx[0] - 1})
-            ok = all("".join(per[s]) == O.run(caps[s], O.make_opts())["text"] for s in picks)
-            out["parity_check"] = f"{len(picks)} captures of context 0 identical to the oracle" if ok else "MISMATCH"
+        if parity is not None:
+            fp, lp = parity["first_pass"], parity["last_pass"]
+            out["parity"] = parity
+            out["parity_check"] = (f"{fp['captures_compared']} captures x {nctx} contexts (first pass, all of them) and {lp['captures_compared']} captures "
+                                   f"across {nctx} contexts (pass {lp['pass_number']}, carried state) identical to the oracle"
+                                   if parity["ok"] else "MISMATCH")
         print(json.dumps(out), flush=True)
     for rx in rxs:
         rx.close()

@@ -177,13 +177,21 @@ __global__ void k_carry(const uint32_t *fin, uint32_t *carry, uint32_t words, ui
     for (uint32_t k = 0; k < words; k++) carry[(uint64_t)r * words + k] = fin[((uint64_t)r * nseg_cap + nseg - 1) * words + k];
 }
 
-template <int D, bool SHIFT> int launch_k1v2(wmbus_ctx *c, const K1Args &a, dim3 grid)
+template <int D, bool SHIFT, bool GEN> int launch_k1v3(wmbus_ctx *c, const K1Args &a, dim3 grid)
 {
     const size_t sm = K1Geo::smem(D ? D : (int)c->d, SHIFT);
-    HIPCHK(c, hipFuncSetAttribute((const void *)k1_demod2<D, SHIFT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-    hipLaunchKernelGGL((k1_demod2<D, SHIFT>), grid, dim3(256), sm, c->stream, a);
+    HIPCHK(c, hipFuncSetAttribute((const void *)k1_demod2<D, SHIFT, GEN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+    hipLaunchKernelGGL((k1_demod2<D, SHIFT, GEN>), grid, dim3(256), sm, c->stream, a);
     HIPCHK(c, hipGetLastError());
     return 0;
+}
+
+/* the default switches' first pass runs the kernel without the option paths (k1_demod2<.., GEN = false>) */
+template <int D, bool SHIFT> int launch_k1v2(wmbus_ctx *c, const K1Args &a, dim3 grid)
+{
+    const uint32_t need = WM_F_ACCURATE | WM_F_T1C1 | WM_F_S1, never = WM_F_APPROX1 | WM_F_APPROX2;
+    if (D != 0 && a.relist == nullptr && (c->flags & need) == need && !(c->flags & never)) return launch_k1v3<D, SHIFT, false>(c, a, grid);
+    return launch_k1v3<D, SHIFT, true>(c, a, grid);
 }
 
 int launch_k1_ppf(wmbus_ctx *c, const K1Args &a, dim3 grid)

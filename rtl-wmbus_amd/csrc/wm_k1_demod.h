@@ -167,6 +167,7 @@ __device__ __forceinline__ void k1_fir_s(const K1Args &a, const float *yDrS, con
  * Work split: waves 0 and 1 run one chain's EMA each (16 samples per lane behind the warm-up) and
  * the 11-tap FIR of half the tile; waves 2 and 3 the 46-tap FIR of half the tile each -- 630 against
  * 860 instructions, instead of 960 on the EMA waves and 530 on the others. */
+template <bool GEN>
 __device__ __forceinline__ void k1_stage_b(const K1Args &a, const int tid, const int tile, const int stream, const int ts, const int tn,
                                            const bool chT, const bool chS, const float *yDrT, const float *yDrS,
                                            const float *yMgT, const float *yMgS, float *sFin, float *sHead)
@@ -184,7 +185,7 @@ __device__ __forceinline__ void k1_stage_b(const K1Args &a, const int tid, const
     const int m0l = 16 * e;
     const uint64_t row = (uint64_t)ch * g.S + stream;
     const uint64_t rows = 2ull * g.S, ti = (uint64_t)tile * rows + row;
-    if (a.relist != nullptr) {
+    if (GEN && a.relist != nullptr) {
         /* REPAIR: a hand-off of this tile could not be certified (e.g. exact-zero input after a
          * signal: the true state decays through 90 more samples while a warm-up from zero is already
          * at zero).  One lane per chain runs the whole tile sequentially from the predecessor's exact
@@ -249,7 +250,10 @@ __device__ __forceinline__ void k1_stage_b(const K1Args &a, const int tid, const
     }
 }
 
-template <int D, bool SHIFT>
+/* GEN = false: the kernel of the DEFAULT switches (both chains, cargf arctangent, first pass): the switch tests, the
+ * -a / -A / -p paths and the RSSI repair walk are not compiled in, so the default path carries no cost for the options
+ * (any other configuration, and every repair launch, runs the GEN = true kernel: same arithmetic, same results). */
+template <int D, bool SHIFT, bool GEN = true>
 __global__ __launch_bounds__(256) void k1_demod2(K1Args a)
 {
     using G = K1Geo;
@@ -265,13 +269,14 @@ __global__ __launch_bounds__(256) void k1_demod2(K1Args a)
     float *sFin = yDrS + YD, *sHead = sFin + 128, *tab = sHead + 128;
 
     const int tid = threadIdx.x;
-    const int tile = a.relist ? (int)(a.relist[blockIdx.x] % a.ntiles) : (int)blockIdx.x;
-    const int stream = a.relist ? (int)(a.relist[blockIdx.x] / a.ntiles) : (int)blockIdx.y;
+    const bool listed = GEN && a.relist != nullptr;
+    const int tile = listed ? (int)(a.relist[blockIdx.x] % a.ntiles) : (int)blockIdx.x;
+    const int stream = listed ? (int)(a.relist[blockIdx.x] / a.ntiles) : (int)blockIdx.y;
     const int ts = tile * T;
     const int tn = min(T, (int)g.M - ts);
-    const bool chT = g.flags & WM_F_T1C1, chS = g.flags & WM_F_S1;
-    const bool accurate = g.flags & WM_F_ACCURATE;
-    const int approx = (g.flags & WM_F_APPROX1) ? 1 : (g.flags & WM_F_APPROX2) ? 2 : 0;   /* option: atan2.h's approximations */
+    const bool chT = !GEN || (g.flags & WM_F_T1C1), chS = !GEN || (g.flags & WM_F_S1);
+    const bool accurate = !GEN || (g.flags & WM_F_ACCURATE);
+    const int approx = !GEN ? 0 : (g.flags & WM_F_APPROX1) ? 1 : (g.flags & WM_F_APPROX2) ? 2 : 0;   /* option: atan2.h's approximations */
 
     if (tid < WM_ATAN_TAB_WORDS) wm_atan_tab_word(tid, tab);   /* 5 range rows + range LUT */
 
@@ -387,7 +392,7 @@ __global__ __launch_bounds__(256) void k1_demod2(K1Args a)
         for (int j = 0; j < 4; j++) { yMgT[qb + j] = mgT[j]; yMgS[qb + j] = mgS[j]; }
     }
 
-    k1_stage_b(a, tid, tile, stream, ts, tn, chT, chS, yDrT, yDrS, yMgT, yMgS, sFin, sHead);
+    k1_stage_b<GEN>(a, tid, tile, stream, ts, tn, chT, chS, yDrT, yDrS, yMgT, yMgS, sFin, sHead);
 }
 
 /* =============================================================================================
@@ -496,7 +501,7 @@ __global__ __launch_bounds__(256) void k1_demod_ppf(K1Args a)
 #pragma unroll
         for (int j = 0; j < 4; j++) yMg[qb + j] = mg[j];
     }
-    k1_stage_b(a, tid, tile, stream, ts, tn, chT, chS, yDr, yDr, yMg, yMg, sFin, sHead);
+    k1_stage_b<true>(a, tid, tile, stream, ts, tn, chT, chS, yDr, yDr, yMg, yMg, sFin, sHead);
 }
 
 /* head[tile] must equal tail[tile-1] (or the value carried from the previous push).  One thread

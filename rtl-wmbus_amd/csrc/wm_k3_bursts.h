@@ -139,11 +139,8 @@ __device__ void burst_item(const K3Args &a, const uint32_t item, const uint32_t 
     if (chip0 >= total) return;
     const uint32_t avail = total - chip0;        /* chips from the hit to the end of the push */
 
-    const uint32_t c_first = seg < nseg ? min(cnt[seg], cap) : 0u;   /* most chips of a burst lie in the hit's own segment */
     auto locate = [&](uint32_t j, uint32_t &sg, uint32_t &kk) {   /* chip0 + j -> (segment, index) */
         sg = seg; kk = k + j;
-        if (kk < c_first) return;                                   /* no load on the common path */
-        kk -= c_first; sg++;
         while (sg < nseg) { const uint32_t c = min(cnt[sg], cap); if (kk < c) break; kk -= c; sg++; }
     };
 
@@ -163,26 +160,15 @@ __device__ void burst_item(const K3Args &a, const uint32_t item, const uint32_t 
     if (hslot >= a.hdr_cap || woff + n > a.words_cap) { if (ln == 0) atomicOr(a.err, WM_ERR_BURST_OVERFLOW); return; }
     uint32_t sg0, k0; locate(0, sg0, k0);
     const uint64_t pos0 = g.m0 + (uint64_t)sg0 * seg_len + WM_CHIP_POS(base[(uint64_t)sg0 * cap + k0]);
-    /* four chips per lane and trip: the copy is a chain of dependent loads (chip -> its RSSI byte), so
-     * independent chains in flight are what shortens it */
-    for (uint32_t j0 = ln; j0 < n; j0 += 256u) {
-        uint32_t w[4], pm[4], rs[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t j = j0 + 64u * (uint32_t)u;
-            w[u] = 0u; pm[u] = 0u;
-            if (j < n) { uint32_t sg, kk; locate(j, sg, kk); w[u] = base[(uint64_t)sg * cap + kk]; pm[u] = sg * seg_len; }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            pm[u] += WM_CHIP_POS(w[u]);                                      /* push-relative decimated sample */
-            rs[u] = j0 + 64u * (uint32_t)u < n ? a.rssi[row * g.Mcap + pm[u]] : 0u;   /* (unsigned)EMA at the chip's sample */
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t j = j0 + 64u * (uint32_t)u;
-            if (j < n) a.words[woff + j] = ((uint32_t)(g.m0 + pm[u] - pos0) << 11) | (rs[u] << 3) | (WM_CHIP_VAL(w[u]) & 7u);
-        }
+    /* one chip per lane and trip.  (Four independent chip -> RSSI load chains per lane were measured at -3 % for the whole
+     * job, round 2 bisect: the kernel got shorter, its register and issue footprint beside the demodulation kernel larger.) */
+    for (uint32_t j = ln; j < n; j += 64u) {
+        uint32_t sg, kk; locate(j, sg, kk);
+        const uint32_t w = base[(uint64_t)sg * cap + kk];
+        const uint32_t pm = sg * seg_len + WM_CHIP_POS(w);               /* push-relative decimated sample */
+        const uint64_t pos = g.m0 + pm;
+        const uint32_t rssi = a.rssi[row * g.Mcap + pm];                 /* (unsigned)EMA at the chip's sample */
+        a.words[woff + j] = ((uint32_t)(pos - pos0) << 11) | (rssi << 3) | (WM_CHIP_VAL(w) & 7u);
     }
     if (ln == 0) {
         WmBurstHdr h;

@@ -57,7 +57,12 @@ template <int D, bool SHIFT> static void run_k1(const K1Args &a, uint32_t gx, ui
     for (uint32_t y = 0; y < gy; y++)
         for (uint32_t x = 0; x < gx; x++) {
             blockIdx = {x, y, 0};
-            block_emu::run_block(256, [&] { k1_demod2<D, SHIFT>(a); });
+            /* the host's selection (launch_k1v2 in wm_api.hip): default switches, first pass -> the kernel without the option paths */
+            const uint32_t need = WM_F_ACCURATE | WM_F_T1C1 | WM_F_S1, never = WM_F_APPROX1 | WM_F_APPROX2;
+            if (D != 0 && a.relist == nullptr && (a.g.flags & need) == need && !(a.g.flags & never))
+                block_emu::run_block(256, [&] { k1_demod2<D, SHIFT, false>(a); });
+            else
+                block_emu::run_block(256, [&] { k1_demod2<D, SHIFT, true>(a); });
         }
 }
 

@@ -140,6 +140,31 @@ def run(cu8, opts, taps=False, chips=False):
     return out
 
 
+def run_many(caps, opts, threads=None, passes=1):
+    """Datagram text of many captures, farmed over the host's cores (the ctypes call releases the GIL).
+    passes > 1: the capture is fed `passes` times to one oracle instance and only the text of the LAST
+    pass is returned -- the twin of a receiver that has been pushed the same bytes that many times."""
+    import concurrent.futures as cf
+    L = lib()
+    L.wmo_clear_output.argtypes = [ctypes.c_void_p]
+
+    def one(cu8):
+        cu8 = np.ascontiguousarray(cu8, dtype=np.uint8)
+        ctx = L.wmo_new(ctypes.byref(opts))
+        for k in range(passes):
+            if k == passes - 1:
+                L.wmo_clear_output(ctx)
+            L.wmo_feed(ctx, cu8.ctypes.data, cu8.size)
+        n = ctypes.c_size_t()
+        p = L.wmo_output(ctx, ctypes.byref(n))
+        text = ctypes.string_at(p, n.value).decode() if n.value else ""
+        L.wmo_free(ctx)
+        return text
+
+    with cf.ThreadPoolExecutor(threads or min(len(caps), os.cpu_count() or 1)) as ex:
+        return list(ex.map(one, caps))
+
+
 def mask_ts(b):
     return _TS.sub(b"TS", b)
 

@@ -23,13 +23,13 @@ prepare)
 run)
     export TMPDIR=/tmp
     mkdir -p gpurun_out/next
-    ( timeout 120 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 ) | tee gpurun_out/next/suite.txt
+    ( timeout 420 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 ) | tee gpurun_out/next/suite.txt
     F="--steps 10 --warmup 2"
     ./tools/gpu_env.sh "WMBUS_HIP_LIB=$L/libwmbus_hip_r1gpu.so -- $F" "A=1 -- $F" "WMBUS_HIP_LIB=$L/libwmbus_hip_rlav3.so -- $F" \
         "WMBUS_HIP_LIB=$L/libwmbus_hip_fb4.so -- $F" "WMBUS_HIP_LIB=$L/libwmbus_hip_lean.so -- $F" "WMBUS_FUSE_FRAMERS=0 -- $F" \
         "WMBUS_HIP_LIB=$L/libwmbus_hip_rlav3.so,WMBUS_FUSE_FRAMERS=0 -- $F" "WMBUS_HIP_LIB=$L/libwmbus_hip_r1gpu.so -- $F" "A=1 -- $F" 2>&1 | tee gpurun_out/next/ab.txt
     # the parked run-length framer must pass the suite before it may replace the current one
-    ( WMBUS_HIP_LIB=$L/libwmbus_hip_rlav3.so timeout 120 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 ) | tee gpurun_out/next/suite_rlav3.txt
+    ( WMBUS_HIP_LIB=$L/libwmbus_hip_rlav3.so timeout 420 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 ) | tee gpurun_out/next/suite_rlav3.txt
     ;;
 *) echo "usage: $0 prepare | run"; exit 2;;
 esac
