@@ -61,7 +61,7 @@ typedef struct wmbus_cfg {
     unsigned warmup_s1;         /* IIR warm-up before a segment, S1 chain            */
     unsigned rla_lookback;      /* speculative run-length lookback                   */
     unsigned host_threads;      /* host decoder threads, 0 = auto                    */
-    int keep_taps;              /* 1: keep soft symbols readable via wmbus_read_tap  */
+    int keep_taps;              /* 1: wmbus_read_tap may be used (the debug views of the last push) */
     /* Low-pass in front of the decimator.  BOXCAR = the moving averages the reference's main()
      * runs (rtl_wmbus.c:1333-1344): what every reference binary computes, bit for bit.
      * POLYPHASE = lp_ppf_butter_1600kHz_160kHz_200kHz (rtl_wmbus.c:258-294 over ppf.h:46-59), which
@@ -97,7 +97,7 @@ typedef struct wmbus_timing {
     float gpu_total_ms;         /* first kernel start -> last copy done               */
     float host_decode_ms;       /* packet decoders + formatting (wall clock)          */
     unsigned clock_reruns, rla_reruns, ema_retries;
-    uint64_t chips[2][2];       /* chips produced per chain/algo                      */
+    uint64_t chips[2][2];       /* chips produced in this push, [chain][algo]         */
     uint64_t bursts;            /* candidate bursts handed to the host decoders       */
     float turn_wait_ms;         /* host time spent waiting for this process's turn in the demodulation kernel */
 } wmbus_timing;

@@ -59,8 +59,10 @@ class Timing(ctypes.Structure):
                 ("turn_wait_ms", ctypes.c_float)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k in ("demod_ms", "clock_ms", "rla_ms", "gather_ms", "d2h_ms", "gpu_total_ms",
-                                              "host_decode_ms", "clock_reruns", "rla_reruns", "ema_retries", "bursts", "turn_wait_ms")}
+        d = {k: getattr(self, k) for k in ("demod_ms", "clock_ms", "rla_ms", "gather_ms", "d2h_ms", "gpu_total_ms",
+                                           "host_decode_ms", "clock_reruns", "rla_reruns", "ema_retries", "bursts", "turn_wait_ms")}
+        d["chips"] = [[int(self.chips[ch][al]) for al in range(2)] for ch in range(2)]      # [chain][algo]
+        return d
 
 
 EXPORTS = ["wmbus_default_cfg", "wmbus_open", "wmbus_close", "wmbus_last_error", "wmbus_stage", "wmbus_device_input",
@@ -138,7 +140,7 @@ class Receiver:
     def __init__(self, n_streams=1, max_push_bytes=4 << 20, decimation=2, simultaneous=False, accurate_atan=True,
                  remove_dc=False, t1c1=True, s1=True, rla=True, time2=True, show_algorithm=True, device=0,
                  seg_len=0, rla_seg_len=0, warmup_t1c1=0, warmup_s1=0, rla_lookback=0, host_threads=0, fixed_timestamp=True,
-                 prefilter=0, atan_mode=0):
+                 prefilter=0, atan_mode=0, keep_taps=True):
         L = lib()
         c = Cfg()
         L.wmbus_default_cfg(ctypes.byref(c))
@@ -148,7 +150,7 @@ class Receiver:
         c.n_streams, c.device, c.max_push_bytes = n_streams, device, max_push_bytes
         c.seg_len, c.rla_seg_len, c.warmup_t1c1, c.warmup_s1 = seg_len, rla_seg_len, warmup_t1c1, warmup_s1
         c.rla_lookback, c.host_threads = rla_lookback, host_threads
-        c.keep_taps = 1
+        c.keep_taps = int(keep_taps)
         c.prefilter = prefilter
         c.atan_mode = atan_mode
         self.cfg = c

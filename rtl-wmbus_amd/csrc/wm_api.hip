@@ -51,24 +51,25 @@ public:
     unsigned size() const { return (unsigned)th_.size(); }
     template <typename F> void run(unsigned n, F &&f)
     {
-        std::function<void(unsigned)> fn = f;
         {
             std::lock_guard<std::mutex> lk(m_);
-            job_ = &fn; next_ = 0; total_ = n; done_ = 0; gen_++;
+            job_ = f; next_ = 0; total_ = n; done_ = 0; gen_++;      /* the job lives in the pool, not on this stack frame */
         }
         cv_.notify_all();
-        work(fn);                                            /* the caller helps */
+        work();                                              /* the caller helps */
         std::unique_lock<std::mutex> lk(m_);
-        cv_done_.wait(lk, [&] { return done_ == total_; });
+        /* every item done AND every worker that picked this generation up has left work(): nothing of
+         * this run can still be executing when the caller's captures go out of scope */
+        cv_done_.wait(lk, [&] { return done_ == total_ && active_ == 0; });
         job_ = nullptr;
     }
 private:
-    void work(const std::function<void(unsigned)> &fn)
+    void work()
     {
         for (;;) {
             unsigned i;
             { std::lock_guard<std::mutex> lk(m_); if (next_ >= total_) return; i = next_++; }
-            fn(i);
+            job_(i);                                         /* job_ only changes while no item is outstanding */
             { std::lock_guard<std::mutex> lk(m_); if (++done_ == total_) cv_done_.notify_all(); }
         }
     }
@@ -76,21 +77,21 @@ private:
     {
         uint64_t seen = 0;
         for (;;) {
-            const std::function<void(unsigned)> *fn;
             {
                 std::unique_lock<std::mutex> lk(m_);
                 cv_.wait(lk, [&] { return stop_ || (gen_ != seen && job_ != nullptr); });
                 if (stop_) return;
-                seen = gen_; fn = job_;
+                seen = gen_; active_++;
             }
-            work(*fn);
+            work();
+            { std::lock_guard<std::mutex> lk(m_); if (--active_ == 0) cv_done_.notify_all(); }
         }
     }
     std::vector<std::thread> th_;
     std::mutex m_;
     std::condition_variable cv_, cv_done_;
-    const std::function<void(unsigned)> *job_ = nullptr;
-    unsigned next_ = 0, total_ = 0, done_ = 0;
+    std::function<void(unsigned)> job_;
+    unsigned next_ = 0, total_ = 0, done_ = 0, active_ = 0;
     uint64_t gen_ = 0;
     bool stop_ = false;
 };
@@ -135,6 +136,7 @@ struct wmbus_ctx {
     std::unique_ptr<WorkerPool> pool;                   /* packet-decoder workers, created on first use */
     std::vector<wmbus_line> lines; std::string text;
     WmPush last{}; bool have_last = false, in_flight = false;
+    std::atomic<uint32_t> short_burst{0};               /* set by the decoder threads of one collect: 1 + header index */
     wmbus_timing tim{};
 };
 
@@ -153,7 +155,7 @@ int fail(wmbus_ctx *c, int code, const char *fmt, ...)
 
 template <typename T> hipError_t dalloc(T **p, size_t n) { return hipMalloc((void **)p, n * sizeof(T)); }
 
-enum { SC_ERR = 0, SC_NLIST = 1, SC_NHITS = 2, SC_NHDR = 3, SC_NWORDS = 4, SC_NLIST2 = 5, SC_COUNT = 8 };
+enum { SC_ERR = 0, SC_NLIST = 1, SC_NHITS = 2, SC_NHDR = 3, SC_NWORDS = 4, SC_NLIST2 = 5, SC_CHIPS = 8 /* [algo][chain] */, SC_COUNT = 16 };
 
 __global__ void k_roll_history(uint8_t *in, uint64_t stride, uint32_t nbytes)
 {
@@ -175,6 +177,19 @@ __global__ void k_carry(const uint32_t *fin, uint32_t *carry, uint32_t words, ui
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
     for (uint32_t k = 0; k < words; k++) carry[(uint64_t)r * words + k] = fin[((uint64_t)r * nseg_cap + nseg - 1) * words + k];
+}
+
+/* wmbus_timing.chips: chips produced per (framer, chain) in this push = sum of the settled segment counts */
+__global__ void k_sum_counts(WmPush g, const uint32_t *counts0, const uint32_t *counts1, uint32_t *sums)
+{
+    const uint32_t n0 = 2u * g.nseg_cap[0] * g.S, n1 = 2u * g.nseg_cap[1] * g.S;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, algo = 0;
+    if (i >= n0) { i -= n0; algo = 1; }
+    if (i >= (algo ? n1 : n0)) return;
+    const uint32_t seg = i % g.nseg_cap[algo], ch = i / g.nseg_cap[algo] / g.S;
+    if (seg >= g.nseg[algo] || !(g.flags & (algo ? WM_F_T2A : WM_F_RLA))) return;
+    const uint32_t c = min((algo ? counts1 : counts0)[i], g.cap[algo]);
+    if (c) atomicAdd(sums + algo * 2u + ch, c);
 }
 
 template <int D, bool SHIFT, bool GEN> int launch_k1v3(wmbus_ctx *c, const K1Args &a, dim3 grid)
@@ -305,7 +320,9 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
      * seen, found by the host emulation campaigns) -- so four chips per sample, plus one long run ending here;
      * beyond that the push fails with WMBUS_EOVERFLOW */
     c->cap[0] = 4u * c->C[0] + 8 + WM_RLA_RUN_LIMIT;
-    c->in_stride = (WM_HIST_BYTES + cfg->max_push_bytes + WM_IN_SLACK + 255) / 256 * 256;
+    /* K1 stages whole tiles: the partial last tile of a push reads up to (tile + halo) x d input samples past the
+     * staged bytes (never used: they only feed outputs beyond M) -- the row must hold them */
+    c->in_stride = (WM_HIST_BYTES + cfg->max_push_bytes + 2ull * (WM_K1_TILE2 + WM_K1_HALO + 16) * WM_MAX_DECIM + WM_IN_SLACK + 255) / 256 * 256;
 
     const uint64_t rows = 2ull * c->S;
     hipError_t e = hipSuccess;
@@ -603,6 +620,8 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
 
         /* K3: access-code hits of the settled chip streams, then bursts */
         HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
+        hipLaunchKernelGGL(k_sum_counts, dim3((2u * (c->nseg_cap[0] + c->nseg_cap[1]) * c->S + 255u) / 256u), dim3(256), 0, c->stream, g,
+                           c->d_counts[0], c->d_counts[1], c->d_scalars + SC_CHIPS);
         hipLaunchKernelGGL(k3_scan, dim3((2u * (g.nseg[0] + g.nseg[1]) * g.S + 255u) / 256u), dim3(256), 0, c->stream, g, c->d_chips[0], c->d_chips[1],
                            c->d_counts[0], c->d_counts[1], c->d_sync_seen[0], c->d_sync_seen[1], c->d_hits, c->d_scalars + SC_NHITS,
                            c->hits_cap, c->d_scalars + SC_ERR);
@@ -631,6 +650,7 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
         const uint32_t err = c->h_scalars[SC_ERR];
         if (err & (WM_ERR_CHIP_OVERFLOW | WM_ERR_BURST_OVERFLOW)) return fail(c, WMBUS_EOVERFLOW, "chip/burst buffer overflow (err=%u)", err);
         c->n_hdr = c->h_scalars[SC_NHDR]; c->n_words = c->h_scalars[SC_NWORDS];
+        for (int al = 0; al < 2; al++) for (int ch = 0; ch < 2; ch++) c->tim.chips[ch][al] = c->h_scalars[SC_CHIPS + al * 2 + ch];
         if (c->n_hdr) HIPCHK(c, hipMemcpyAsync(c->h_hdr, c->d_hdr, (size_t)c->n_hdr * sizeof(WmBurstHdr), hipMemcpyDeviceToHost, c->stream));
         if (c->n_words) HIPCHK(c, hipMemcpyAsync(c->h_words, c->d_words, (size_t)c->n_words * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
@@ -687,8 +707,10 @@ static void decode_stream_range(wmbus_ctx *c, const std::vector<uint32_t> &order
             }
             next_free = (uint64_t)h.chip0 + k;
             cut = st == WM_DEC_RECEIVING;
-            if (cut && h.n_chips != h.avail)                   /* device under-estimated the burst: a bug */
-                snprintf(c->err, sizeof c->err, "burst too short: stream %u chain %u algo %u chip %u", h.stream, h.chain, h.algo, h.chip0);
+            if (cut && h.n_chips != h.avail) {                 /* device under-estimated the burst: a bug */
+                uint32_t none = 0;
+                c->short_burst.compare_exchange_strong(none, 1u + order[j]);
+            }
             hd.owed = cut ? std::max(1u, wm_decoder_chips_owed(&hd.dec)) : 0u;
         }
         i = j;
@@ -699,6 +721,7 @@ int wmbus_collect(wmbus_ctx *c)
 {
     if (!c) return WMBUS_EINVAL;
     c->lines.clear(); c->text.clear();
+    c->short_burst.store(0);
     if (!c->in_flight) return WMBUS_OK;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->in_flight = false;
@@ -763,7 +786,11 @@ int wmbus_collect(wmbus_ctx *c)
         c->lines.push_back(l);
     }
     c->tim.host_decode_ms = (float)(now_ms() - t0);
-    return c->err[0] && strstr(c->err, "burst too short") ? WMBUS_EDEVICE : WMBUS_OK;
+    if (const uint32_t sb = c->short_burst.load()) {       /* formatted once, after the pool has joined */
+        const WmBurstHdr &h = c->h_hdr[sb - 1u];
+        return fail(c, WMBUS_EDEVICE, "burst too short: stream %u chain %u algo %u chip %u", h.stream, h.chain, h.algo, h.chip0);
+    }
+    return WMBUS_OK;
 }
 
 size_t wmbus_lines(const wmbus_ctx *c, const wmbus_line **lines)
@@ -790,6 +817,7 @@ int wmbus_get_timing(const wmbus_ctx *c, wmbus_timing *t)
 long wmbus_read_tap(wmbus_ctx *c, const char *what, int chain, unsigned stream, void *dst, size_t max_elems)
 {
     if (!c || !what || !dst || chain < 0 || chain > 1 || stream >= c->S || !c->have_last) return WMBUS_EINVAL;
+    if (!c->cfg.keep_taps) return fail(c, WMBUS_EINVAL, "read_tap: the context was opened without cfg.keep_taps");
     hipStreamSynchronize(c->stream);
     const size_t n = std::min<size_t>(max_elems, c->last.M);
     const size_t row = (size_t)chain * c->S + stream;
@@ -811,7 +839,10 @@ long wmbus_read_chips(wmbus_ctx *c, int chain, int algo, unsigned stream, uint32
     hipStreamSynchronize(c->stream);
     uint32_t *d_dst = nullptr, *d_n = nullptr; uint64_t *d_pos = nullptr;
     if (hipMalloc((void **)&d_dst, max_elems * 4) != hipSuccess || hipMalloc((void **)&d_pos, max_elems * 8) != hipSuccess ||
-        hipMalloc((void **)&d_n, 4) != hipSuccess) return WMBUS_ENOMEM;
+        hipMalloc((void **)&d_n, 4) != hipSuccess) {
+        hipFree(d_dst); hipFree(d_pos); hipFree(d_n);            /* hipFree(nullptr) is a no-op */
+        return WMBUS_ENOMEM;
+    }
     hipLaunchKernelGGL(k4_flatten, dim3(1), dim3(1), 0, c->stream, c->last, (uint32_t)algo, c->d_chips[algo], c->d_counts[algo],
                        c->d_rssi, c->cap[algo], (uint32_t)chain, stream, d_dst, d_pos, (uint32_t)max_elems, d_n);
     uint32_t n = 0;

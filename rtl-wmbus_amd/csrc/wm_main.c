@@ -12,7 +12,9 @@
  * the role of the reference's unused net_support.h:15-44 / rtl_wmbus.c:1281), and
  *   rtl_wmbus_hip [switches] a.cu8 b.cu8 ...      batch mode: one capture per file, all of them in
  * lock step on one GPU, lines prefixed "a.cu8: "; a reader thread fills one pinned slab while the
- * GPU works on the other (double-buffered H2D).
+ * GPU works on the other (double-buffered H2D).  With -G all (or -G 0,2,5) batch mode shards the files over the
+ * GPUs of the node, file i on device list[i mod n] (file-per-GPU, no collective): one receiver
+ * context and one worker thread per device, each file's lines in its own order.  -M prints that map and exits.
  */
 #include <arpa/inet.h>
 #include <netdb.h>
@@ -43,7 +45,8 @@ static void print_usage(const char *prog)
     fprintf(stdout, "\t-p [T,S] to disable processing T1/C1 or S1 mode\n");
     fprintf(stdout, "\t-f exit if flow of incoming data stops\n");
     fprintf(stdout, "\t-B bytes per GPU push (multiple of 4096, default 1048576)\n");
-    fprintf(stdout, "\t-G HIP device ordinal (default 0)\n");
+    fprintf(stdout, "\t-G HIP device ordinal (default 0); batch mode: 'all' or a list '0,2,5' shards the files, file i on device list[i mod n]\n");
+    fprintf(stdout, "\t-M batch mode: print the file -> device map and exit\n");
     fprintf(stdout, "\t-A 1|2 atan2_approximation / atan2_approximation2 (atan2.h) instead of cargf in the discriminator\n");
     fprintf(stdout, "\t-P polyphase low-pass (ppf.h) instead of the moving average before decimation (1.6 MS/s, -d 2, no -s)\n");
     fprintf(stdout, "\t-T host:port read the cu8 stream from a TCP server instead of stdin\n");
@@ -100,6 +103,12 @@ static void batch_fill(struct batch *b, int k)
 struct fill_job { struct batch *b; int k; };
 static void *fill_thread(void *p) { struct fill_job *j = p; batch_fill(j->b, j->k); return NULL; }
 
+static pthread_mutex_t out_lock = PTHREAD_MUTEX_INITIALIZER;      /* one push's lines leave as a unit */
+
+/* File i of a batch -> position in the device list (stream s -> GPU s mod n).  The only place
+ * the map is defined; -M prints it, tests/test_multi_gloo.py holds it against rtl-wmbus_amd/shard.py. */
+static int shard_slot(int file_index, int n_devices) { return file_index % n_devices; }
+
 static int run_batch(wmbus_cfg cfg, int n, char **names)
 {
     struct batch b;
@@ -138,11 +147,13 @@ static int run_batch(wmbus_cfg cfg, int n, char **names)
             const size_t nl = wmbus_lines(ctx, &ln);
             size_t len = 0;
             const char *text = wmbus_lines_text(ctx, &len);
+            pthread_mutex_lock(&out_lock);
             for (size_t i = 0; i < nl; i++) {
                 fputs(names[ln[i].stream], stdout); fputs(": ", stdout);
                 fwrite(text + ln[i].text_off, 1, ln[i].text_len, stdout);
             }
             fflush(stdout);
+            pthread_mutex_unlock(&out_lock);
         }
         pthread_join(th, NULL);
         cur ^= 1;
@@ -152,6 +163,52 @@ static int run_batch(wmbus_cfg cfg, int n, char **names)
     free(b.f); free(b.live);
     wmbus_close(ctx);
     return rc ? EXIT_FAILURE : EXIT_SUCCESS;
+}
+
+/* ---- batch mode over several GPUs: one run_batch per device, each on its own thread ---------- */
+struct shard_job { wmbus_cfg cfg; int n; char **names; int rc; };
+static void *shard_thread(void *p) { struct shard_job *j = p; j->rc = j->n ? run_batch(j->cfg, j->n, j->names) : EXIT_SUCCESS; return NULL; }
+
+static int run_sharded(wmbus_cfg cfg, int n, char **names, const int *devs, int n_devs, int map_only)
+{
+    struct shard_job *jobs = calloc((size_t)n_devs, sizeof *jobs);
+    pthread_t *th = calloc((size_t)n_devs, sizeof *th);
+    for (int k = 0; k < n_devs; k++) { jobs[k].cfg = cfg; jobs[k].cfg.device = devs[k]; jobs[k].names = calloc((size_t)n, sizeof(char *)); }
+    for (int i = 0; i < n; i++) {
+        const int k = shard_slot(i, n_devs);
+        jobs[k].names[jobs[k].n++] = names[i];
+        if (map_only) fprintf(stdout, "%s -> device %d\n", names[i], devs[k]);
+    }
+    int rc = EXIT_SUCCESS;
+    if (!map_only) {
+        for (int k = 0; k < n_devs; k++) pthread_create(&th[k], NULL, shard_thread, &jobs[k]);
+        for (int k = 0; k < n_devs; k++) { pthread_join(th[k], NULL); if (jobs[k].rc) rc = jobs[k].rc; }
+    }
+    for (int k = 0; k < n_devs; k++) free(jobs[k].names);
+    free(jobs); free(th);
+    return rc;
+}
+
+/* -G: "3" | "all" | "0,2,5" -> device list; returns the count or -1 */
+static int parse_devices(const char *arg, int *devs, int cap)
+{
+    if (!strcmp(arg, "all")) {
+        int n = wmbus_device_count();
+        if (n > cap) n = cap;
+        for (int k = 0; k < n; k++) devs[k] = k;
+        return n;                                            /* 0: no HIP device */
+    }
+    int n = 0;
+    const char *p = arg;
+    while (*p) {
+        char *end;
+        const long v = strtol(p, &end, 10);
+        if (end == p || v < 0 || n == cap) return -1;
+        devs[n++] = (int)v;
+        if (*end == ',') end++; else if (*end) return -1;
+        p = end;
+    }
+    return n ? n : -1;
 }
 
 static void on_alarm(int signo)
@@ -181,9 +238,9 @@ int main(int argc, char **argv)
     wmbus_cfg cfg;
     wmbus_default_cfg(&cfg);
     cfg.max_push_bytes = 1u << 20;
-    int check_flow = 0, opt;
+    int check_flow = 0, opt, map_only = 0, devs[64], n_devs = 0;
     const char *tcp = NULL;
-    while ((opt = getopt(argc, argv, "ofad:p:r:vVst:B:G:PT:A:")) != -1) {
+    while ((opt = getopt(argc, argv, "ofad:p:r:vVst:B:G:PT:A:M")) != -1) {
         switch (opt) {
         case 'o': cfg.remove_dc = 1; break;
         case 'f': check_flow = 1; break;
@@ -200,7 +257,13 @@ int main(int argc, char **argv)
         case 'v': cfg.show_algorithm = 1; break;
         case 'V': fprintf(stdout, "rtl_wmbus: " VERSION "\n"); return EXIT_SUCCESS;
         case 'B': cfg.max_push_bytes = (size_t)strtoull(optarg, NULL, 10) / WMBUS_BLOCK_BYTES * WMBUS_BLOCK_BYTES; break;
-        case 'G': cfg.device = atoi(optarg); break;
+        case 'G':
+            n_devs = parse_devices(optarg, devs, 64);
+            if (n_devs < 0) { print_usage(argv[0]); return EXIT_FAILURE; }
+            if (n_devs == 0) { fprintf(stderr, "rtl_wmbus_hip: -G all: no HIP device (this program has no CPU fallback)\n"); return EXIT_FAILURE; }
+            cfg.device = devs[0];
+            break;
+        case 'M': map_only = 1; break;
         case 'P': cfg.prefilter = WMBUS_PREFILTER_POLYPHASE; break;
         case 'A': cfg.atan_mode = atoi(optarg); break;
         case 'T': tcp = optarg; break;
@@ -218,7 +281,11 @@ int main(int argc, char **argv)
         sigaction(SIGALRM, &sa, NULL);
     }
 
-    if (optind < argc) return run_batch(cfg, argc - optind, argv + optind);
+    if (optind < argc) {
+        if (n_devs == 0) { devs[0] = cfg.device; n_devs = 1; }
+        if (n_devs == 1 && !map_only) return run_batch(cfg, argc - optind, argv + optind);
+        return run_sharded(cfg, argc - optind, argv + optind, devs, n_devs, map_only);
+    }
 
     FILE *input = stdin;
     if (tcp && !(input = open_tcp(tcp))) return EXIT_FAILURE;

@@ -16,6 +16,12 @@ def capture_seed(rank, streams_per_rank, s):
     return BASE_SEED + rank * streams_per_rank + s
 
 
+def device_of(file_index, n_devices):
+    """File-per-GPU map of the batch CLI (`rtl_wmbus_hip -G all|list FILE...`, wm_main.c shard_slot) and of
+    SURVEY.md 8(e): stream s -> position s mod n in the device list."""
+    return file_index % n_devices
+
+
 def owned_captures(rank, world, total):
     """Contiguous block partition of `total` captures (used when a fixed file list is sharded)."""
     per = (total + world - 1) // world

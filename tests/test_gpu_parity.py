@@ -380,3 +380,50 @@ def test_atan2_approximation_options_match_oracle(wm, oracle, atan_mode, flags, 
         assert rx.run(cu8)[0] == ref["text"]
         compare_taps(rx, ref)
         compare_chips(rx, ref)
+
+
+def test_abi_details_on_the_device(wm, oracle, samples):
+    """wmbus_timing.chips is filled ([chain][algo], the chips of the last push), cfg.keep_taps gates wmbus_read_tap,
+    and a full-size push at the largest decimation stays inside the input window (the last partial tile of a push
+    stages a whole tile of input: ADVICE r1)."""
+    cu8 = samples["samples2"]
+    ref = oracle.run(cu8, flags_to_oracle_opts(oracle, ["-v"]), chips=True)
+    with wm.Receiver(n_streams=1, max_push_bytes=cu8.size) as rx:
+        rx.run(cu8)
+        tim = rx.timing()
+        for ch in (0, 1):
+            for al in (0, 1):
+                assert tim["chips"][ch][al] == int(((ref["chips"]["chain"] == ch) & (ref["chips"]["algo"] == al)).sum())
+    with wm.Receiver(n_streams=1, max_push_bytes=cu8.size, keep_taps=False) as rx:
+        rx.run(cu8)
+        with pytest.raises(wm.WmbusError):
+            rx.read_tap("dphi", 0, 0, 16)
+    # d = 16 (run-time decimation kernel), nbytes == max_push_bytes, several streams: the LAST stream's last tile reads
+    # the furthest past its staged bytes
+    n = 1 << 19
+    caps = [wm.synth_capture(seed=7100 + s, n_samples=n, fs_khz=12800, kinds=7, frames_per_s=200.0)[0] for s in range(3)]
+    oo = flags_to_oracle_opts(oracle, ["-d", "16", "-v"])
+    with wm.Receiver(n_streams=3, max_push_bytes=2 * n, decimation=16) as rx:
+        texts = rx.run(caps)
+    assert texts == oracle.run_many(caps, oo)
+
+
+def test_cli_batch_mode_sharded_over_devices(wm, oracle, samples, tmp_path):
+    """`-G all` (every device of the box: one here) and `-G 0,0` (two device slots -> two receiver contexts on two
+    worker threads, files dealt round robin: the multi-GPU code path on a single GPU): each file's lines are what the
+    capture gives alone, whatever slot it landed on."""
+    env = dict(os.environ, WMBUS_FIXED_TS="1")
+    caps = {f"f{i}.cu8": (samples["samples2"] if i == 0 else
+                          wm.synth_capture(seed=620 + i, n_samples=(2 + i % 3) << 17, kinds=15, frames_per_s=90.0)[0]) for i in range(5)}
+    want = {}
+    for name, cu8 in caps.items():
+        cu8.tofile(tmp_path / name)
+        want[name] = oracle.run(cu8, flags_to_oracle_opts(oracle, ["-v"]))["text"]
+    for g in ("all", "0,0"):
+        p = subprocess.run([wm.CLI_PATH, "-v", "-B", str(1 << 19), "-G", g] + list(caps), cwd=tmp_path, capture_output=True, env=env)
+        assert p.returncode == 0, p.stderr
+        got = {name: "" for name in caps}
+        for line in p.stdout.decode().splitlines(True):
+            name, rest = line.split(": ", 1)
+            got[name] += rest
+        assert got == want, g
