@@ -31,7 +31,7 @@ enum {
     WMBUS_EINVAL = -1,      /* bad argument / configuration                         */
     WMBUS_ENOMEM = -2,      /* host or device allocation failed                     */
     WMBUS_EDEVICE = -3,     /* HIP runtime error (see wmbus_last_error)             */
-    WMBUS_EOVERFLOW = -4,   /* a chip or window buffer overflowed (raise capacities) */
+    WMBUS_EOVERFLOW = -4,   /* (no longer returned: exhausted chip / burst storage is a wmbus_timing.warnings bit) */
     WMBUS_ENODEVICE = -5    /* no HIP device: this library has no CPU fallback      */
 };
 
@@ -71,6 +71,7 @@ typedef struct wmbus_cfg {
      * rtl_wmbus.c:523-529); WMBUS_ATAN_APPROX1 / 2 = atan2_approximation / atan2_approximation2 (atan2.h:14-74),
      * the alternatives its source keeps behind `#elif 0` / `#else`: extensions, ignored with -a. */
     int atan_mode;
+    unsigned spill_words;       /* tuning: run-length chip spill arena, 32-bit words (0 = default) */
 } wmbus_cfg;
 
 enum { WMBUS_PREFILTER_BOXCAR = 0, WMBUS_PREFILTER_POLYPHASE = 1 };
@@ -100,7 +101,13 @@ typedef struct wmbus_timing {
     uint64_t chips[2][2];       /* chips produced in this push, [chain][algo]         */
     uint64_t bursts;            /* candidate bursts handed to the host decoders       */
     float turn_wait_ms;         /* host time spent waiting for this process's turn in the demodulation kernel */
+    unsigned warnings;          /* WMBUS_WARN_* of this push (the push succeeded)     */
 } wmbus_timing;
+
+/* The reference never gives up on an input (rtl_wmbus.c:729-803 has no bound); neither does a push.  When an
+ * interferer makes the run-length framer emit more chips than even the spill arena holds, or more candidate bursts
+ * than the burst arena, the excess is dropped (datagrams inside it may be lost), all carried state stays exact. */
+enum { WMBUS_WARN_CHIPS_DROPPED = 1, WMBUS_WARN_BURSTS_DROPPED = 2 };
 
 void wmbus_default_cfg(wmbus_cfg *cfg);
 

@@ -122,6 +122,8 @@ struct wmbus_ctx {
     uint32_t *d_list2 = nullptr;                        /* run-length re-run list of the fused framer launches */
     uint32_t *d_list = nullptr, *d_scalars = nullptr;   /* scalars: err, n_list, n_hits, n_hdr, n_words */
     uint32_t *d_sync_seen[2] = {};                      /* per framer: [2][S][nseg_cap] access-code chip seen in region */
+    uint32_t *d_spill = nullptr, *d_chain = nullptr, *d_nchain = nullptr; uint32_t spill_words = 0;   /* WmSpill (wm_dev.h) */
+    bool poisoned = false;                              /* an internal error left the carried state undefined */
     uint32_t *d_first_bad = nullptr;                    /* [2][S] first uncertified EMA tile of a row, or ~0 */
     uint32_t *d_ckpt = nullptr; uint32_t nck = 0;       /* clock kernel checkpoints [2][S][nseg_cap][nck][16] */
     uint2 *d_hits = nullptr; uint32_t hits_cap = 0;
@@ -188,7 +190,7 @@ __global__ void k_sum_counts(WmPush g, const uint32_t *counts0, const uint32_t *
     if (i >= (algo ? n1 : n0)) return;
     const uint32_t seg = i % g.nseg_cap[algo], ch = i / g.nseg_cap[algo] / g.S;
     if (seg >= g.nseg[algo] || !(g.flags & (algo ? WM_F_T2A : WM_F_RLA))) return;
-    const uint32_t c = min((algo ? counts1 : counts0)[i], g.cap[algo]);
+    const uint32_t c = (algo ? counts1 : counts0)[i];
     if (c) atomicAdd(sums + algo * 2u + ch, c);
 }
 
@@ -262,7 +264,7 @@ void wmbus_close(wmbus_ctx *c)
 {
     if (!c) return;
     if (c->stream) hipStreamSynchronize(c->stream);
-    void *dev[] = {c->d_list2, c->d_sync_seen[0], c->d_sync_seen[1], c->d_first_bad, c->d_ckpt, c->d_in, c->d_dphi, c->d_rssi, c->d_bits, c->d_lut, c->d_ema_head, c->d_ema_tail, c->d_ema_carry,
+    void *dev[] = {c->d_spill, c->d_chain, c->d_nchain, c->d_list2, c->d_sync_seen[0], c->d_sync_seen[1], c->d_first_bad, c->d_ckpt, c->d_in, c->d_dphi, c->d_rssi, c->d_bits, c->d_lut, c->d_ema_head, c->d_ema_tail, c->d_ema_carry,
                    c->d_chips[0], c->d_chips[1], c->d_counts[0], c->d_counts[1], c->d_st_start[0], c->d_st_start[1],
                    c->d_st_final[0], c->d_st_final[1], c->d_st_carry[0], c->d_st_carry[1], c->d_list, c->d_scalars,
                    c->d_hits, c->d_pending, c->d_hdr, c->d_words};
@@ -315,11 +317,12 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
     c->Mcap = (c->ntiles_cap * T + 255) / 256 * 256;     /* whole tiles (partial tiles still store full runs); slicer-word rows 32-byte aligned */
     for (int a = 0; a < 2; a++) c->nseg_cap[a] = (c->Mcap + c->C[a] - 1) / c->C[a];
     c->cap[1] = c->C[1] / 4 + 8;   /* time2: the lock logic needs >= 4 samples per chip */
-    /* run-length: the reference's bit-length tracker has no floor -- switch combinations (-d 3 -s -o -a on a capture
-     * with both modes) and interferers drag it to a third of a sample per chip for a while (3.1 chips per sample
-     * seen, found by the host emulation campaigns) -- so four chips per sample, plus one long run ending here;
-     * beyond that the push fails with WMBUS_EOVERFLOW */
-    c->cap[0] = 4u * c->C[0] + 8 + WM_RLA_RUN_LIMIT;
+    /* run-length: a primary region of half a chip per sample (four times the nominal eight samples per chip); the
+     * reference's bit-length tracker has no floor -- switch combinations (-d 3 -s -o -a on a capture with both modes)
+     * and interferers drag it to a third of a sample per chip for a while (3.1 chips per sample seen, found by the host
+     * emulation campaigns), and exact silence ends in one long run -- such segments continue in the spill arena
+     * (WmSpill, wm_dev.h); a push never fails for want of chip storage */
+    c->cap[0] = (c->C[0] / 2 + 8 + 7) / 8 * 8;
     /* K1 stages whole tiles: the partial last tile of a push reads up to (tile + halo) x d input samples past the
      * staged bytes (never used: they only feed outputs beyond M) -- the row must hold them */
     c->in_stride = (WM_HIST_BYTES + cfg->max_push_bytes + 2ull * (WM_K1_TILE2 + WM_K1_HALO + 16) * WM_MAX_DECIM + WM_IN_SLACK + 255) / 256 * 256;
@@ -346,6 +349,14 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
         A(hipMalloc(&c->d_st_start[a], (size_t)rows * c->nseg_cap[a] * stw[a]));
         A(hipMalloc(&c->d_st_final[a], (size_t)rows * c->nseg_cap[a] * stw[a]));
         A(hipMalloc(&c->d_st_carry[a], (size_t)rows * stw[a]));
+    }
+    {
+        const uint64_t dec_total_ = (uint64_t)c->S * c->Mcap;
+        const uint64_t want = cfg->spill_words ? cfg->spill_words : std::max<uint64_t>(1u << 20, dec_total_ / 16);
+        c->spill_words = (uint32_t)std::min<uint64_t>((want + WM_SPILL_CHUNK - 1) / WM_SPILL_CHUNK * WM_SPILL_CHUNK, 0xFFFF0000u);
+        A(dalloc(&c->d_spill, (size_t)c->spill_words));
+        A(dalloc(&c->d_chain, (size_t)rows * c->nseg_cap[0] * WM_SPILL_LEVELS));
+        A(dalloc(&c->d_nchain, (size_t)rows * c->nseg_cap[0] + 1));          /* + the arena's bump counter */
     }
     A(dalloc(&c->d_list, (size_t)rows * std::max(c->nseg_cap[0], c->nseg_cap[1])));
     A(dalloc(&c->d_list2, (size_t)rows * c->nseg_cap[0]));
@@ -518,6 +529,7 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
     if (nbytes == 0 || nbytes > c->cfg.max_push_bytes || nbytes % WMBUS_BLOCK_BYTES)
         return fail(c, WMBUS_EINVAL, "process: nbytes must be a positive multiple of 4096 and <= max_push_bytes");
     if (c->in_flight) return fail(c, WMBUS_EINVAL, "process: previous push not collected");
+    if (c->poisoned) return fail(c, WMBUS_EDEVICE, "process: an earlier internal error left this context unusable; close it");
     c->tim = wmbus_timing{};
     const uint32_t n_new = (uint32_t)(nbytes / 2);
     WmPush g{};
@@ -530,6 +542,8 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
         g.seg_len[al] = c->C[al]; g.nseg[al] = (g.M + c->C[al] - 1) / c->C[al]; g.nseg_cap[al] = c->nseg_cap[al]; g.cap[al] = c->cap[al];
     }
     g.warm[0] = c->cfg.warmup_t1c1; g.warm[1] = c->cfg.warmup_s1; g.lookback = c->cfg.rla_lookback;
+    g.sp.arena = c->d_spill; g.sp.arena_words = c->spill_words; g.sp.chain = c->d_chain; g.sp.nchain = c->d_nchain;
+    g.sp.used = c->d_nchain + (size_t)2 * c->S * c->nseg_cap[0];
     c->last = g; c->have_last = true;
     c->n_hdr = c->n_words = 0;
 
@@ -595,6 +609,7 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
         k2.err = c->d_scalars + SC_ERR;
         for (int al = 0; al < 2; al++)
             HIPCHK(c, hipMemsetAsync(c->d_sync_seen[al], 0, (size_t)2 * c->S * c->nseg_cap[al] * sizeof(uint32_t), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_nchain, 0, ((size_t)2 * c->S * c->nseg_cap[0] + 1) * sizeof(uint32_t), c->stream));   /* spill chains + bump counter */
         k2.ckpt = c->d_ckpt; k2.nck = c->nck;
         K2Args ka = k2, kr = k2;
         ka.algo = WMBUS_ALGO_T2A;
@@ -648,7 +663,13 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
         HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, SC_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         const uint32_t err = c->h_scalars[SC_ERR];
-        if (err & (WM_ERR_CHIP_OVERFLOW | WM_ERR_BURST_OVERFLOW)) return fail(c, WMBUS_EOVERFLOW, "chip/burst buffer overflow (err=%u)", err);
+        if (err & WM_ERR_CHIP_OVERFLOW) {            /* a time2 region over its proven bound: a defect, not an input property */
+            c->poisoned = true;
+            return fail(c, WMBUS_EDEVICE, "internal error: time2 chip region overflow (err=%u)", err);
+        }
+        /* storage exhausted (spill arena / burst arena): chips or candidate bursts were dropped; every carried state
+         * is exact, so the stream goes on -- reported, never fatal (the reference never gives up either) */
+        c->tim.warnings = ((err & WM_ERR_CHIP_TRUNC) ? WMBUS_WARN_CHIPS_DROPPED : 0u) | ((err & WM_ERR_BURST_OVERFLOW) ? WMBUS_WARN_BURSTS_DROPPED : 0u);
         c->n_hdr = c->h_scalars[SC_NHDR]; c->n_words = c->h_scalars[SC_NWORDS];
         for (int al = 0; al < 2; al++) for (int ch = 0; ch < 2; ch++) c->tim.chips[ch][al] = c->h_scalars[SC_CHIPS + al * 2 + ch];
         if (c->n_hdr) HIPCHK(c, hipMemcpyAsync(c->h_hdr, c->d_hdr, (size_t)c->n_hdr * sizeof(WmBurstHdr), hipMemcpyDeviceToHost, c->stream));

@@ -63,6 +63,23 @@ struct WmRlaState {
     int32_t  spb0, spb1;   /* S1 samples-per-bit trackers                          */
 };
 
+/* Run-length chip storage beyond a segment's primary region.  The reference's bit-length tracker has no floor
+ * (rtl_wmbus.c:792-796): an interferer, or a switch combination like -d 3 -s -o -a on a two-mode capture, makes it
+ * emit several chips per sample for a while, and its chip loop (:765-779) never gives up.  A segment's primary region
+ * holds cap[0] chips; a lane that needs more takes WM_SPILL_CHUNK-word chunks from a per-push arena (atomic bump
+ * allocator) and records them in the segment's chain, which later passes over the same segment (re-runs) reuse.
+ * Chip i of a segment lives at primary[i] for i < cap[0], else in chunk (i - cap[0]) / WM_SPILL_CHUNK of its chain.
+ * Only when the arena (or the chain) is exhausted are chips dropped -- counted, reported as a warning, never an error. */
+#define WM_SPILL_CHUNK  2048u      /* words; a multiple of 8 (chips leave in 32-byte groups) */
+#define WM_SPILL_LEVELS 16u        /* chunks per segment chain: 32 768 chips beyond the primary region */
+struct WmSpill {
+    uint32_t *arena;         /* [arena_words], nullptr: no spill storage (host emulation of single kernels) */
+    uint32_t *used;          /* words handed out this push                                     */
+    uint32_t *chain;         /* [2][S][nseg_cap[0]][WM_SPILL_LEVELS] arena offsets            */
+    uint32_t *nchain;        /* [2][S][nseg_cap[0]] chunks the segment owns (reset per push)   */
+    uint32_t arena_words;
+};
+
 /* Per-push geometry handed to every kernel by value. */
 struct WmPush {
     const uint8_t *in;       /* base of stream 0's buffer (history first)             */
@@ -85,6 +102,7 @@ struct WmPush {
     uint32_t cap[2];         /* chips per segment region                              */
     uint32_t warm[2];        /* IIR warm-up per chain                                 */
     uint32_t lookback;       /* RLA speculative lookback                              */
+    WmSpill sp;              /* run-length chips beyond cap[0]                        */
 };
 
 enum {
@@ -93,8 +111,9 @@ enum {
     WM_F_APPROX1 = 128, WM_F_APPROX2 = 256     /* atan2_approximation / atan2_approximation2 instead of cargf (options) */
 };
 
-/* error word bits (device -> host) */
-enum { WM_ERR_CHIP_OVERFLOW = 2, WM_ERR_BURST_OVERFLOW = 4 };
+/* error word bits (device -> host).  CHIP_OVERFLOW: a time2 region over its proven bound (an internal error);
+ * CHIP_TRUNC / BURST_OVERFLOW: storage exhausted, chips / bursts dropped -- warnings, the push still succeeds. */
+enum { WM_ERR_CHIP_OVERFLOW = 2, WM_ERR_BURST_OVERFLOW = 4, WM_ERR_CHIP_TRUNC = 8 };
 
 /* Burst = the chips a packet decoder needs after one access-code hit. */
 struct WmBurstHdr {

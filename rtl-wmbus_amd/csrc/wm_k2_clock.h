@@ -374,7 +374,7 @@ __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t bloc
                      * than it had: its tail is partly overwritten -- run on to the segment's end.) */
                     for (uint32_t i = 0; i < pend; i++) out[n_fl + i] = my_chip[i];
                     if (n1 < n0) {
-                        const uint32_t total0 = min(a.counts[sidx], cap_t2);
+                        const uint32_t total0 = a.counts[sidx];
                         for (uint32_t i = n0; i < total0; i++) {
                             const uint32_t w = out[i];
                             out[n1 + (i - n0)] = w;
@@ -416,9 +416,9 @@ __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t bloc
         emit_block(m, smask, bitw, true);
     }
     stF[sidx] = s;
-    a.counts[sidx] = n_out;
+    a.counts[sidx] = min(n_out, cap_t2);
     if (saw_sync) a.sync_seen[sidx] = 1u;
-    if (n_out > cap_t2) atomicOr(a.err, WM_ERR_CHIP_OVERFLOW);
+    if (n_out > cap_t2) atomicOr(a.err, WM_ERR_CHIP_OVERFLOW);       /* cannot happen: the lock pattern takes >= 4 samples per chip */
 }
 
 template <bool DC>

@@ -36,4 +36,13 @@ __device__ __forceinline__ void lane_decode(const WmPush &g, uint32_t algo, uint
     ch = r / g.nseg[algo];
 }
 
+/* Chip i of segment region sidx of framer `algo` (see WmSpill): the primary region, then the segment's chunks. */
+__device__ __forceinline__ const uint32_t *wm_chip_ptr(const WmPush &g, const uint32_t *primary, uint32_t algo, uint64_t sidx, uint32_t i)
+{
+    const uint32_t cap = g.cap[algo];
+    if (algo != 0u || i < cap) return primary + sidx * cap + i;
+    const uint32_t j = i - cap;
+    return g.sp.arena + g.sp.chain[sidx * WM_SPILL_LEVELS + j / WM_SPILL_CHUNK] + j % WM_SPILL_CHUNK;
+}
+
 #endif /* WM_K2_COMMON_H */

@@ -95,14 +95,34 @@ __device__ __forceinline__ void rla_lanes(const K2Args &a, const uint32_t block_
      * into read-modify-write traffic at the memory side and cost 3 of the kernel's 8.4 ms. */
     uint32_t *my_chip = s_chip + threadIdx.x * WM_RLA_CROW;
     uint32_t pend = 0, n_fl = 0, saw_sync = 0;               /* staged chips; chips already in HBM (multiple of 8) */
+    /* beyond the primary region: the segment's spill chain (WmSpill).  cur_lvl/cur_base cache the chunk in use. */
+    uint32_t n_chain = 0xFFFFFFFFu, cur_lvl = 0xFFFFFFFFu, cur_base = 0, n_stored = 0xFFFFFFFFu;   /* n_stored: chips kept, once some were dropped */
+    auto spill_slot = [&](uint32_t j) -> uint32_t * {        /* 8 words at offset j (multiple of 8) behind the primary region */
+        const uint32_t lvl = j / WM_SPILL_CHUNK;
+        if (g.sp.arena == nullptr || lvl >= WM_SPILL_LEVELS) return nullptr;
+        if (lvl != cur_lvl) {
+            if (n_chain == 0xFFFFFFFFu) n_chain = g.sp.nchain[sidx];       /* chunks an earlier pass over this segment took */
+            uint32_t base;
+            if (lvl < n_chain) base = g.sp.chain[sidx * WM_SPILL_LEVELS + lvl];
+            else {
+                base = atomicAdd(g.sp.used, WM_SPILL_CHUNK);
+                if (base > g.sp.arena_words || g.sp.arena_words - base < WM_SPILL_CHUNK) return nullptr;    /* arena exhausted */
+                g.sp.chain[sidx * WM_SPILL_LEVELS + lvl] = base;
+                n_chain = lvl + 1u; g.sp.nchain[sidx] = n_chain;
+            }
+            cur_lvl = lvl; cur_base = base;
+        }
+        return g.sp.arena + cur_base + j % WM_SPILL_CHUNK;
+    };
     auto flush8 = [&]() {                                    /* the oldest 8 staged words -> HBM */
         uint32_t w[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) w[i] = my_chip[i];
-        if (n_fl + 8u <= cap_rl) {
-            *(uint4 *)(out + n_fl) = make_uint4(w[0], w[1], w[2], w[3]);
-            *(uint4 *)(out + n_fl + 4) = make_uint4(w[4], w[5], w[6], w[7]);
-        }
+        uint32_t *dst = n_fl + 8u <= cap_rl ? out + n_fl : spill_slot(n_fl - cap_rl);
+        if (dst != nullptr && n_stored == 0xFFFFFFFFu) {
+            *(uint4 *)(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+            *(uint4 *)(dst + 4) = make_uint4(w[4], w[5], w[6], w[7]);
+        } else if (n_stored == 0xFFFFFFFFu) n_stored = n_fl;   /* storage exhausted: this and every later chip of the segment is dropped */
         for (uint32_t i = 8; i < pend; i++) my_chip[i - 8] = my_chip[i];
         n_fl += 8u; pend = pend > 8u ? pend - 8u : 0u;
     };
@@ -204,9 +224,9 @@ __device__ __forceinline__ void rla_lanes(const K2Args &a, const uint32_t block_
     const uint32_t n_out = n_fl + pend;
     while (pend) flush8();                               /* last group: the slots beyond n_out are never read */
     stF[sidx] = s;
-    a.counts[sidx] = n_out;
+    a.counts[sidx] = n_stored < n_out ? n_stored : n_out;        /* chips that can be read back */
     if (saw_sync) a.sync_seen[sidx] = 1u;
-    if (n_out > cap_rl) atomicOr(a.err, WM_ERR_CHIP_OVERFLOW);
+    if (n_stored < n_out) atomicOr(a.err, WM_ERR_CHIP_TRUNC);     /* a warning: the framer state is exact, some chips of this segment are lost */
 }
 
 __global__ __launch_bounds__(64 * WM_RLA_WPB) void k2_rla(K2Args a)

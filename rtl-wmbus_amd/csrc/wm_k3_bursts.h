@@ -75,19 +75,20 @@ __global__ __launch_bounds__(256) void k3_scan(WmPush g, const uint32_t *chips0,
         const uint32_t sidx = (ch * g.S + stream) * g.nseg_cap[algo] + seg;
         if ((g.flags & (ch ? WM_F_S1 : WM_F_T1C1)) && (g.flags & (algo ? WM_F_T2A : WM_F_RLA)) && (algo ? seen1 : seen0)[sidx]) {
             my_sidx = sidx;
-            my_cnt = min((algo ? counts1 : counts0)[sidx], g.cap[algo]);
+            my_cnt = (algo ? counts1 : counts0)[sidx];           /* chips that can be read back (time2: <= cap by construction) */
         }
     }
     for (uint64_t todo = __ballot(my_cnt != 0u); todo; todo &= todo - 1ull) {
         const int src = __ffsll((long long)todo) - 1;
         const uint32_t cnt = __shfl(my_cnt, src), sidx = __shfl(my_sidx, src), r_lane = __shfl(lane, src), r_algo = __shfl(algo, src);
-        const uint32_t *w = (r_algo ? chips1 : chips0) + (uint64_t)sidx * g.cap[r_algo];
+        const uint32_t *prim = r_algo ? chips1 : chips0;
         /* four 16-byte loads in flight per lane (a region of the clock framer is 8 k chips: 32 dependent
          * trips of one load each were most of this kernel's time) */
-        for (uint32_t kb = 4u * ln; kb < cnt; kb += 1024u) {            /* regions are 32-byte aligned, cap % 8 == 0 */
+        for (uint32_t kb = 4u * ln; kb < cnt; kb += 1024u) {            /* regions and spill chunks are 32-byte aligned, cap % 8 == 0 */
             uint4 v[4];
 #pragma unroll
-            for (uint32_t u = 0; u < 4; u++) v[u] = kb + 256u * u < cnt ? *(const uint4 *)(w + kb + 256u * u) : uint4{0u, 0u, 0u, 0u};
+            for (uint32_t u = 0; u < 4; u++)
+                v[u] = kb + 256u * u < cnt ? *(const uint4 *)wm_chip_ptr(g, prim, r_algo, sidx, kb + 256u * u) : uint4{0u, 0u, 0u, 0u};
 #pragma unroll
             for (uint32_t u = 0; u < 4; u++) {
                 const uint32_t k4 = kb + 256u * u;
@@ -122,17 +123,18 @@ __device__ void burst_item(const K3Args &a, const uint32_t item, const uint32_t 
         lane_decode(g, algo, h.x & 0x7FFFFFFFu, ch, stream, seg);
         k = h.y; want = 0;
     }
-    const uint32_t cap = g.cap[algo], nseg = g.nseg[algo], seg_len = g.seg_len[algo];
+    const uint32_t nseg = g.nseg[algo], seg_len = g.seg_len[algo];
     const uint64_t row = (uint64_t)ch * g.S + stream;
     const uint32_t *cnt = a.counts[algo] + row * g.nseg_cap[algo];
-    const uint32_t *base = a.chips[algo] + row * g.nseg_cap[algo] * (uint64_t)cap;
+    const uint64_t sidx0 = row * g.nseg_cap[algo];
+    auto chip = [&](uint32_t sg, uint32_t kk) { return *wm_chip_ptr(g, a.chips[algo], algo, sidx0 + sg, kk); };
     if (!cont) {                                 /* stale record of a re-run segment?         */
-        if (k >= min(cnt[seg], cap) || !(base[(uint64_t)seg * cap + k] & 2u)) return;
+        if (k >= cnt[seg] || !(chip(seg, k) & 2u)) return;
     }
     /* chips before / from the hit in this push's chip stream: the wave sums the segment counts in
      * parallel (a serial scan of up to 256 dependent loads per wave was most of this kernel's time) */
     uint32_t before = 0, total = 0;
-    for (uint32_t s = ln; s < nseg; s += 64u) { const uint32_t c = min(cnt[s], cap); if (s < seg) before += c; total += c; }
+    for (uint32_t s = ln; s < nseg; s += 64u) { const uint32_t c = cnt[s]; if (s < seg) before += c; total += c; }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) { before += __shfl_xor(before, off); total += __shfl_xor(total, off); }
     const uint32_t chip0 = before + k;
@@ -141,14 +143,14 @@ __device__ void burst_item(const K3Args &a, const uint32_t item, const uint32_t 
 
     auto locate = [&](uint32_t j, uint32_t &sg, uint32_t &kk) {   /* chip0 + j -> (segment, index) */
         sg = seg; kk = k + j;
-        while (sg < nseg) { const uint32_t c = min(cnt[sg], cap); if (kk < c) break; kk -= c; sg++; }
+        while (sg < nseg) { const uint32_t c = cnt[sg]; if (kk < c) break; kk -= c; sg++; }
     };
 
     uint32_t n;
     if (cont) n = min(want, avail);
     else {
         uint32_t bit = 0;
-        if (ln < 24u && 1u + ln < avail) { uint32_t sg, kk; locate(1u + ln, sg, kk); bit = base[(uint64_t)sg * cap + kk] & 1u; }
+        if (ln < 24u && 1u + ln < avail) { uint32_t sg, kk; locate(1u + ln, sg, kk); bit = chip(sg, kk) & 1u; }
         const unsigned long long m = __ballot(bit);
         uint32_t hb = 0;
         for (int j = 0; j < 24; j++) hb |= (uint32_t)((m >> j) & 1ull) << (23 - j);
@@ -159,12 +161,12 @@ __device__ void burst_item(const K3Args &a, const uint32_t item, const uint32_t 
     hslot = __shfl(hslot, 0); woff = __shfl(woff, 0);
     if (hslot >= a.hdr_cap || woff + n > a.words_cap) { if (ln == 0) atomicOr(a.err, WM_ERR_BURST_OVERFLOW); return; }
     uint32_t sg0, k0; locate(0, sg0, k0);
-    const uint64_t pos0 = g.m0 + (uint64_t)sg0 * seg_len + WM_CHIP_POS(base[(uint64_t)sg0 * cap + k0]);
+    const uint64_t pos0 = g.m0 + (uint64_t)sg0 * seg_len + WM_CHIP_POS(chip(sg0, k0));
     /* one chip per lane and trip.  (Four independent chip -> RSSI load chains per lane were measured at -3 % for the whole
      * job, round 2 bisect: the kernel got shorter, its register and issue footprint beside the demodulation kernel larger.) */
     for (uint32_t j = ln; j < n; j += 64u) {
         uint32_t sg, kk; locate(j, sg, kk);
-        const uint32_t w = base[(uint64_t)sg * cap + kk];
+        const uint32_t w = chip(sg, kk);
         const uint32_t pm = sg * seg_len + WM_CHIP_POS(w);               /* push-relative decimated sample */
         const uint64_t pos = g.m0 + pm;
         const uint32_t rssi = a.rssi[row * g.Mcap + pm];                 /* (unsigned)EMA at the chip's sample */
@@ -196,10 +198,10 @@ __global__ void k4_flatten(WmPush g, uint32_t algo, const uint32_t *chips, const
     const uint64_t row = (uint64_t)ch * g.S + stream;
     uint32_t n = 0;
     for (uint32_t s = 0; s < g.nseg[algo]; s++) {
-        const uint32_t c = min(counts[row * g.nseg_cap[algo] + s], cap);
+        const uint32_t c = counts[row * g.nseg_cap[algo] + s];
         for (uint32_t k = 0; k < c; k++, n++)
             if (n < max_out) {
-                const uint32_t w = chips[(row * g.nseg_cap[algo] + s) * (uint64_t)cap + k];
+                const uint32_t w = *wm_chip_ptr(g, chips, algo, row * g.nseg_cap[algo] + s, k);
                 dst[n] = WM_CHIP_VAL(w) | ((uint32_t)rssi[row * g.Mcap + s * g.seg_len[algo] + WM_CHIP_POS(w)] << 8);
                 if (pos) pos[n] = g.m0 + (uint64_t)s * g.seg_len[algo] + WM_CHIP_POS(w);
             }

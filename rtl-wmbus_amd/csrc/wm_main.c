@@ -105,6 +105,18 @@ static void *fill_thread(void *p) { struct fill_job *j = p; batch_fill(j->b, j->
 
 static pthread_mutex_t out_lock = PTHREAD_MUTEX_INITIALIZER;      /* one push's lines leave as a unit */
 
+/* The reference never stops on an input; neither do we: exhausted chip / burst storage is reported once and the
+ * stream goes on (wmbus_hip.h, WMBUS_WARN_*). */
+static void report_warnings(wmbus_ctx *ctx)
+{
+    static unsigned told = 0;
+    wmbus_timing t;
+    if (wmbus_get_timing(ctx, &t) || !(t.warnings & ~told)) return;
+    if (t.warnings & ~told & WMBUS_WARN_CHIPS_DROPPED) fprintf(stderr, "rtl_wmbus_hip: warning: run-length chip storage exhausted (interferer?), some chips dropped; continuing\n");
+    if (t.warnings & ~told & WMBUS_WARN_BURSTS_DROPPED) fprintf(stderr, "rtl_wmbus_hip: warning: burst storage exhausted, some candidate telegrams dropped; continuing\n");
+    told |= t.warnings;
+}
+
 /* File i of a batch -> position in the device list (stream s -> GPU s mod n).  The only place
  * the map is defined; -M prints it, tests/test_multi_gloo.py holds it against rtl-wmbus_amd/shard.py. */
 static int shard_slot(int file_index, int n_devices) { return file_index % n_devices; }
@@ -148,6 +160,7 @@ static int run_batch(wmbus_cfg cfg, int n, char **names)
             size_t len = 0;
             const char *text = wmbus_lines_text(ctx, &len);
             pthread_mutex_lock(&out_lock);
+            report_warnings(ctx);
             for (size_t i = 0; i < nl; i++) {
                 fputs(names[ln[i].stream], stdout); fputs(": ", stdout);
                 fwrite(text + ln[i].text_off, 1, ln[i].text_len, stdout);
@@ -225,6 +238,7 @@ static int flush_push(wmbus_ctx *ctx, const unsigned char *buf, size_t n)
     if (!rc) rc = wmbus_process(ctx, n);
     if (!rc) rc = wmbus_collect(ctx);
     if (rc) { fprintf(stderr, "rtl_wmbus_hip: %s\n", wmbus_last_error(ctx)); return rc; }
+    report_warnings(ctx);
     size_t len = 0;
     const char *text = wmbus_lines_text(ctx, &len);
     if (len) { fwrite(text, 1, len, stdout); fflush(stdout); }

@@ -30,6 +30,12 @@ extern "C" {
 
 unsigned wm_emu_hdr_bytes(void) { return sizeof(WmBurstHdr); }
 
+static WmSpill emu_spill = {};            /* run-length chips beyond the primary regions, as the framer emulation left them */
+void wm_emu_k3_set_spill(uint32_t *arena, uint32_t arena_words, uint32_t *chain, uint32_t *nchain, uint32_t *used)
+{
+    emu_spill.arena = arena; emu_spill.arena_words = arena_words; emu_spill.chain = chain; emu_spill.nchain = nchain; emu_spill.used = used;
+}
+
 /* geo: M, Mcap, flags, m0, seg_len[2], nseg[2], cap[2] (S = 1).  Returns the number of bursts, or -1 on overflow. */
 long wm_emu_k3(const uint64_t *geo, const uint32_t *chips0, const uint32_t *chips1, const uint32_t *counts0, const uint32_t *counts1,
                const uint32_t *seen0, const uint32_t *seen1, const uint8_t *rssi, const uint32_t *pending, void *hdr_out, uint32_t hdr_cap,
@@ -40,6 +46,7 @@ long wm_emu_k3(const uint64_t *geo, const uint32_t *chips0, const uint32_t *chip
     for (int a = 0; a < 2; a++) {
         g.seg_len[a] = (uint32_t)geo[4 + a]; g.nseg[a] = (uint32_t)geo[6 + a]; g.nseg_cap[a] = g.nseg[a]; g.cap[a] = (uint32_t)geo[8 + a];
     }
+    g.sp = emu_spill;
     std::vector<uint2> hits(hdr_cap);
     uint32_t n_hits = 0, err = 0, n_hdr = 0, n_words = 0;
     const uint32_t lanes = 2u * (g.nseg[0] + g.nseg[1]) * g.S;

@@ -24,6 +24,7 @@ static inline int __ffs(int v) { return __builtin_ffs(v); }
 static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 static inline float __frcp_rn(float x) { return 1.0f / x; }          /* correctly rounded on both sides */
 static inline uint32_t atomicOr(uint32_t *p, uint32_t v) { const uint32_t o = *p; *p |= v; return o; }
+static inline uint32_t atomicAdd(uint32_t *p, uint32_t v) { const uint32_t o = *p; *p += v; return o; }
 using std::min;
 
 #include "wm_dev.h"
@@ -33,6 +34,15 @@ using std::min;
 extern "C" {
 
 int wm_emu_descending = 1;
+/* optional spill storage (WmSpill, wm_dev.h) for the next wm_emu_rla call: arena, chain [2][S][nseg][WM_SPILL_LEVELS],
+ * nchain [2][S][nseg] followed by the bump counter; all zero = none */
+static WmSpill emu_spill = {};
+void wm_emu_rla_set_spill(uint32_t *arena, uint32_t arena_words, uint32_t *chain, uint32_t *nchain, uint32_t *used)
+{
+    emu_spill.arena = arena; emu_spill.arena_words = arena_words; emu_spill.chain = chain; emu_spill.nchain = nchain; emu_spill.used = used;
+}
+unsigned wm_emu_spill_chunk(void) { return WM_SPILL_CHUNK; }
+unsigned wm_emu_spill_levels(void) { return WM_SPILL_LEVELS; }
 uint32_t *wm_emu_seen_out = nullptr;      /* optional: receives the per-region "access-code chip seen" flags */
 
 /* One push of `M` decimated samples for S captures.  bits: [2][S][Mcap/32] slicer words; carry:
@@ -46,6 +56,7 @@ long wm_emu_rla(const uint32_t *bits, uint32_t S, uint32_t M, uint32_t Mcap, uin
     g.M = M; g.Mcap = Mcap; g.S = S; g.flags = flags; g.d = 2;
     g.seg_len[0] = seg_len; g.nseg[0] = (M + seg_len - 1) / seg_len; g.nseg_cap[0] = g.nseg[0]; g.cap[0] = cap;
     g.lookback = lookback;
+    g.sp = emu_spill;
     const uint32_t rows = 2 * S, nseg = g.nseg[0], lanes = rows * nseg;
     std::vector<WmRlaState> st_start((size_t)rows * nseg), st_final((size_t)rows * nseg);
     std::vector<uint32_t> seen((size_t)rows * nseg, 0), list;

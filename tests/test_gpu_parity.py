@@ -427,3 +427,63 @@ def test_cli_batch_mode_sharded_over_devices(wm, oracle, samples, tmp_path):
             name, rest = line.split(": ", 1)
             got[name] += rest
         assert got == want, g
+
+
+def _interferer_capture(wm):
+    from test_rla_emulated import interferer_capture
+    return interferer_capture(wm)
+
+
+@pytest.mark.parametrize("flags", [["-v"], ["-o", "-v"]], ids=lambda f: " ".join(f))
+def test_chip_flood_spills_instead_of_failing(wm, oracle, flags):
+    """a square-wave FM interferer makes the reference emit three chips per sample for a while; its chip
+    loop never gives up (rtl_wmbus.c:729-803).  The product's run-length segments continue in the spill arena: no push
+    fails, chips (read back through the chains) and text equal the oracle's, one-shot and streamed."""
+    cu8 = _interferer_capture(wm)
+    ref = oracle.run(cu8, flags_to_oracle_opts(oracle, flags), taps=True, chips=True)
+    oc = ref["chips"][(ref["chips"]["chain"] == 0) & (ref["chips"]["algo"] == 0)]
+    assert np.bincount(oc["sample"] // 8192).max() > 2 * 8192            # more than the primary region (half a chip per sample) by far
+    kw = flags_to_kwargs(flags)
+    with wm.Receiver(n_streams=1, max_push_bytes=cu8.size, **kw) as rx:
+        assert rx.run(cu8)[0] == ref["text"]
+        assert rx.timing()["warnings"] == 0
+        compare_chips(rx, ref)
+    with wm.Receiver(n_streams=1, max_push_bytes=1 << 18, **kw) as rx:
+        assert rx.run(cu8, push_bytes=1 << 18)[0] == ref["text"]
+
+
+def test_two_mode_capture_with_d3_s_o_a_spills(wm, oracle):
+    """The switch combination the emulation campaign found (-d 3 -s -o -a on a capture carrying both modes): the
+    bit-length tracker collapses without any interferer (3.1 chips per sample for a while)."""
+    flags = ["-d", "3", "-s", "-o", "-a", "-v"]
+    n_chips = 0
+    for seed in (3, 4, 5):
+        cu8 = wm.synth_capture(seed=880 + seed, n_samples=1 << 19, fs_khz=2400, kinds=15, frames_per_s=150.0, amplitude=60.0,
+                               t1c1_center_khz=325.0, s1_center_khz=-325.0)[0]
+        ref = oracle.run(cu8, flags_to_oracle_opts(oracle, flags), taps=True, chips=True)
+        oc = ref["chips"][(ref["chips"]["chain"] == 0) & (ref["chips"]["algo"] == 0)]
+        for seg in (0, 1024):                                  # 1024-sample segments: a primary region of 520 chips, outgrown here
+            with wm.Receiver(n_streams=1, max_push_bytes=cu8.size, rla_seg_len=seg, **flags_to_kwargs(flags)) as rx:
+                assert rx.run(cu8)[0] == ref["text"]
+                assert rx.timing()["warnings"] == 0
+                compare_chips(rx, ref)
+        n_chips += int(np.bincount(oc["sample"] // 1024).max() > 520)
+    assert n_chips > 0                                         # the spill path really ran
+
+
+def test_exhausted_spill_arena_is_a_warning_not_an_error(wm, oracle):
+    """A spill arena of two chunks cannot hold the flood: chips are dropped and wmbus_timing.warnings says so, but the
+    push succeeds, the context stays usable and -- every carried state being exact -- the following pushes are the
+    oracle's text again."""
+    cu8 = _interferer_capture(wm)
+    quiet = wm.synth_capture(seed=4711, n_samples=1 << 18, kinds=15, frames_per_s=120.0, amplitude=60.0)[0]
+    both = np.concatenate([cu8, quiet])
+    ref = oracle.run(both, flags_to_oracle_opts(oracle, ["-v"]))["text"]
+    ref_first = oracle.run(cu8, flags_to_oracle_opts(oracle, ["-v"]))["text"]
+    with wm.Receiver(n_streams=1, max_push_bytes=cu8.size, spill_words=4096) as rx:
+        first = rx.push([cu8])
+        assert rx.timing()["warnings"] & 1
+        second = rx.push([quiet])
+        assert rx.timing()["warnings"] == 0
+    assert ref.startswith(ref_first) and second == ref[len(ref_first):]
+    assert set(first.splitlines()) <= set(ref_first.splitlines())          # nothing invented; lines inside the flood may be lost

@@ -26,12 +26,13 @@ def emu():
     L = ctypes.CDLL(SO)
     L.wm_emu_rla.restype = ctypes.c_long
     L.wm_emu_rla.argtypes = [ctypes.c_void_p] + [ctypes.c_uint] * 7 + [ctypes.c_void_p] * 4
+    L.wm_emu_rla_set_spill.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     L.wm_emu_rla_state_bytes.restype = ctypes.c_uint
     L.wm_emu_rla_reset_state.argtypes = [ctypes.c_void_p]
     return L
 
 
-def run_emulated(emu, bit_rows, pushes, seg_len, lookback, flags=F_T1C1 | F_S1, descending=True, cap=None, expect_overflow=False):
+def run_emulated(emu, bit_rows, pushes, seg_len, lookback, flags=F_T1C1 | F_S1, descending=True, cap=None, spill_words=None):
     """bit_rows: [2][M] uint8 slicer bits of one capture; pushes: decimated samples per push."""
     ctypes.c_int.in_dll(emu, "wm_emu_descending").value = int(descending)   # see rla_emu.cpp: launch semantics
     sb = emu.wm_emu_rla_state_bytes()
@@ -39,9 +40,12 @@ def run_emulated(emu, bit_rows, pushes, seg_len, lookback, flags=F_T1C1 | F_S1, 
     for r in range(2):
         emu.wm_emu_rla_reset_state(carry[r * sb:].ctypes.data)
     out, m0, reruns = [[], []], 0, 0
-    # the product sizes a region as 4 * seg_len + 8 + 8192 chips (wm_api.hip): the bit-length tracker has no floor and
-    # 3.1 chips per sample have been seen; beyond that the push fails loudly.  The parity runs here get more room still.
+    # spill_words None: one roomy region per segment (no spill storage); else the product's layout: a primary region of
+    # `cap` chips (wm_api.hip: seg_len / 2 + 8) and the chunk arena of WmSpill behind it.  Returns chips, re-runs and,
+    # with spill storage, the device's warning word of the last push.
     cap = cap or 8 * seg_len + 8 + 8192
+    CH, LV = emu.wm_emu_spill_chunk(), emu.wm_emu_spill_levels()
+    warn = 0
     for M in pushes:
         Mcap = (M + 255) // 256 * 256
         words = np.zeros((2, Mcap // 32), np.uint32)
@@ -53,18 +57,28 @@ def run_emulated(emu, bit_rows, pushes, seg_len, lookback, flags=F_T1C1 | F_S1, 
         chips = np.zeros((2, nseg, cap), np.uint32)
         counts = np.zeros((2, nseg), np.uint32)
         err = ctypes.c_uint(0)
+        if spill_words is not None:
+            arena = np.zeros(max(1, spill_words), np.uint32); chain = np.zeros((2, nseg, LV), np.uint32); nchain = np.zeros(2 * nseg + 1, np.uint32)
+            emu.wm_emu_rla_set_spill(arena.ctypes.data, spill_words, chain.ctypes.data, nchain.ctypes.data, nchain[2 * nseg:].ctypes.data)
+        else:
+            emu.wm_emu_rla_set_spill(None, 0, None, None, None)
         r = emu.wm_emu_rla(words.ctypes.data, 1, M, Mcap, flags, seg_len, lookback, cap, carry.ctypes.data,
                            chips.ctypes.data, counts.ctypes.data, ctypes.byref(err))
-        if expect_overflow and err.value == 2:
-            return None, -1
-        assert r >= 0 and err.value == 0
+        assert r >= 0 and err.value in ((0, 8) if spill_words is not None else (0,))      # 8 = WM_ERR_CHIP_TRUNC: chips dropped, a warning
+        warn |= err.value
         reruns += r
         for ch in range(2):
             for s in range(nseg):
-                w = chips[ch, s, :counts[ch, s]]
+                n = int(counts[ch, s])
+                w = chips[ch, s, :min(n, cap)]
+                if n > cap:                                  # the segment's spill chain
+                    rest = n - cap
+                    assert nchain[ch * nseg + s] * CH >= rest
+                    w = np.concatenate([w] + [arena[chain[ch, s, l]: chain[ch, s, l] + min(CH, rest - l * CH)] for l in range((rest + CH - 1) // CH)])
                 out[ch].append(np.stack([m0 + s * seg_len + (w >> 3), w & 7], axis=1))
         m0 += M
-    return [np.concatenate(o) if o else np.zeros((0, 2), np.uint32) for o in out], reruns
+    res = [np.concatenate(o) if o else np.zeros((0, 2), np.uint32) for o in out]
+    return (res, reruns) if spill_words is None else (res, reruns, warn)
 
 
 def oracle_rla_chips(ref, ch):
@@ -116,24 +130,59 @@ def test_device_source_on_host_matches_oracle_across_pushes_and_synthetic(emu, o
             assert np.array_equal(got[ch], want), (k, ch)
 
 
-def test_chip_region_overflow_is_reported_not_silent(emu, oracle, wm):
-    """A strong square-wave FM interferer (period 29 samples) drags the T1/C1 bit-length tracker far below one sample
-    per chip: the reference emits three chips per sample for a while.  With a region of one chip per sample (the product's size until
-    this case was found; it is four chips per sample now) the kernel must raise the overflow flag (wmbus_process then fails with WMBUS_EOVERFLOW); with enough room it is exact."""
-    # found by a long emulation campaign (WMBUS_EMU_SEED=1030, case 904): quiet capture (noise 0.5 LSB), then the interferer
+def truncate_runs(want):
+    """the kernel materialises at most 8192 chips per edge"""
+    new_edge = np.concatenate([[True], want[1:, 0] != want[:-1, 0]]) if len(want) else np.zeros(0, bool)
+    start = np.maximum.accumulate(np.where(new_edge, np.arange(len(want)), 0)) if len(want) else np.zeros(0, int)
+    return want[np.arange(len(want)) - start < 8192]
+
+
+def interferer_capture(wm):
+    """A strong square-wave FM interferer (period 29 samples) drags the T1/C1 bit-length tracker far below one sample per
+    chip: the reference emits three chips per sample for a while.  Found by a long emulation campaign (WMBUS_EMU_SEED=1030,
+    case 904): quiet capture (noise 0.5 LSB), then the interferer."""
     cu8 = wm.synth_capture(seed=912168056, n_samples=1 << 18, kinds=15, frames_per_s=120.0, amplitude=60.0, noise_sigma=0.5)[0]
     a, per = 147918, 29
     n_sq = min(cu8.size - a, 60000) // 2
     t = np.arange(n_sq); ph = (t // per) % 2
     cu8[a:a + 2 * n_sq:2] = 128 + 60 * np.cos(2 * np.pi * 0.03 * t * (2 * ph - 1))
     cu8[a + 1:a + 2 * n_sq:2] = 128 + 60 * np.sin(2 * np.pi * 0.03 * t * (2 * ph - 1))
+    return cu8
+
+
+def test_chip_flood_continues_in_the_spill_arena(emu, oracle, wm):
+    """The reference's chip loop never gives up (rtl_wmbus.c:765-779); a segment that outgrows its primary region (the
+    product's half a chip per sample) continues in chunks of the spill arena, re-runs reuse the segment's chain, and the
+    chip stream read back through the chain is the oracle's, chip for chip."""
+    cu8 = interferer_capture(wm)
     ref = oracle.run(cu8, flags_to_oracle_opts(oracle, ["-v"]), taps=True, chips=True)
     oc = oracle_rla_chips(ref, 0)
-    assert np.bincount(oc[:, 0] // 8192).max() > 8192 + 8 + 8192          # the oracle really emits more than a region holds
-    got, reruns = run_emulated(emu, ref["bit"], [ref["m"]], 8192, 1024, cap=8192 + 8 + 8192, expect_overflow=True)
-    assert got is None and reruns == -1                                        # flagged
-    got, _ = run_emulated(emu, ref["bit"], [ref["m"]], 8192, 1024)
-    want = oc
-    new_edge = np.concatenate([[True], want[1:, 0] != want[:-1, 0]])
-    start = np.maximum.accumulate(np.where(new_edge, np.arange(len(want)), 0))
-    assert np.array_equal(got[0], want[np.arange(len(want)) - start < 8192])
+    assert np.bincount(oc[:, 0] // 8192).max() > 2 * 8192                     # the oracle really emits more than two chips per sample
+    for seg_len, lookback, pushes in ((8192, 1024, [ref["m"]]), (2048, 64, [ref["m"] // 3 // 2048 * 2048, ref["m"] - ref["m"] // 3 // 2048 * 2048])):
+        got, reruns, warn = run_emulated(emu, ref["bit"], pushes, seg_len, lookback, cap=seg_len // 2 + 8, spill_words=1 << 20)
+        assert warn == 0
+        for ch in (0, 1):
+            assert np.array_equal(got[ch], truncate_runs(oracle_rla_chips(ref, ch))), (seg_len, ch)
+    assert reruns > 0
+
+
+def test_exhausted_spill_arena_drops_chips_but_keeps_the_framer_exact(emu, oracle, wm):
+    """Arena too small for the flood: the segment's surplus chips are dropped and the warning bit is raised -- nothing
+    fails, every carried state is still exact, so everything outside the starved segments (and the next push) is still
+    the oracle's chip stream."""
+    cu8 = interferer_capture(wm)
+    ref = oracle.run(cu8, flags_to_oracle_opts(oracle, ["-v"]), taps=True, chips=True)
+    M = ref["m"]; half = M // 2 // 8192 * 8192
+    got, _, warn = run_emulated(emu, ref["bit"], [half, M - half], 8192, 1024, cap=8192 // 2 + 8, spill_words=2 * 2048)
+    assert warn == 8
+    for ch in (0, 1):
+        want = truncate_runs(oracle_rla_chips(ref, ch))
+        g, k = got[ch], 0
+        # got is a subsequence of want: whole tails of segments are missing, nothing else
+        seg_of = lambda a: a[:, 0] // 8192
+        lost = 0
+        for sg in np.unique(seg_of(want)):
+            w, h = want[seg_of(want) == sg], g[seg_of(g) == sg]
+            assert len(h) <= len(w) and np.array_equal(h, w[:len(h)]), (ch, sg)
+            lost += len(w) - len(h)
+        assert (lost > 0) == (ch == 0)
