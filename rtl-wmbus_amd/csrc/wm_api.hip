@@ -181,17 +181,24 @@ __global__ void k_carry(const uint32_t *fin, uint32_t *carry, uint32_t words, ui
     for (uint32_t k = 0; k < words; k++) carry[(uint64_t)r * words + k] = fin[((uint64_t)r * nseg_cap + nseg - 1) * words + k];
 }
 
-/* wmbus_timing.chips: chips produced per (framer, chain) in this push = sum of the settled segment counts */
-__global__ void k_sum_counts(WmPush g, const uint32_t *counts0, const uint32_t *counts1, uint32_t *sums)
+/* wmbus_timing.chips: chips produced per (framer, chain) in this push = sum of the settled segment counts.  One
+ * atomic per wave and sum (82 000 threads adding to four words directly cost the whole GPU 15 % while they ran). */
+__global__ __launch_bounds__(256) void k_sum_counts(WmPush g, const uint32_t *counts0, const uint32_t *counts1, uint32_t *sums)
 {
     const uint32_t n0 = 2u * g.nseg_cap[0] * g.S, n1 = 2u * g.nseg_cap[1] * g.S;
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, algo = 0;
-    if (i >= n0) { i -= n0; algo = 1; }
-    if (i >= (algo ? n1 : n0)) return;
-    const uint32_t seg = i % g.nseg_cap[algo], ch = i / g.nseg_cap[algo] / g.S;
-    if (seg >= g.nseg[algo] || !(g.flags & (algo ? WM_F_T2A : WM_F_RLA))) return;
-    const uint32_t c = (algo ? counts1 : counts0)[i];
-    if (c) atomicAdd(sums + algo * 2u + ch, c);
+    uint32_t part[4] = {0u, 0u, 0u, 0u};
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n0 + n1; t += gridDim.x * blockDim.x) {
+        const uint32_t algo = t >= n0, i = algo ? t - n0 : t;
+        const uint32_t seg = i % g.nseg_cap[algo], ch = i / g.nseg_cap[algo] / g.S;
+        if (seg < g.nseg[algo] && (g.flags & (algo ? WM_F_T2A : WM_F_RLA))) part[algo * 2u + ch] += (algo ? counts1 : counts0)[i];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t v = part[k];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+        if ((threadIdx.x & 63u) == 0u && v) atomicAdd(sums + k, v);
+    }
 }
 
 template <int D, bool SHIFT, bool GEN> int launch_k1v3(wmbus_ctx *c, const K1Args &a, dim3 grid)
@@ -635,7 +642,7 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
 
         /* K3: access-code hits of the settled chip streams, then bursts */
         HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
-        hipLaunchKernelGGL(k_sum_counts, dim3((2u * (c->nseg_cap[0] + c->nseg_cap[1]) * c->S + 255u) / 256u), dim3(256), 0, c->stream, g,
+        hipLaunchKernelGGL(k_sum_counts, dim3(std::min(64u, (2u * (c->nseg_cap[0] + c->nseg_cap[1]) * c->S + 255u) / 256u)), dim3(256), 0, c->stream, g,
                            c->d_counts[0], c->d_counts[1], c->d_scalars + SC_CHIPS);
         hipLaunchKernelGGL(k3_scan, dim3((2u * (g.nseg[0] + g.nseg[1]) * g.S + 255u) / 256u), dim3(256), 0, c->stream, g, c->d_chips[0], c->d_chips[1],
                            c->d_counts[0], c->d_counts[1], c->d_sync_seen[0], c->d_sync_seen[1], c->d_hits, c->d_scalars + SC_NHITS,

@@ -442,7 +442,8 @@ def test_chip_flood_spills_instead_of_failing(wm, oracle, flags):
     cu8 = _interferer_capture(wm)
     ref = oracle.run(cu8, flags_to_oracle_opts(oracle, flags), taps=True, chips=True)
     oc = ref["chips"][(ref["chips"]["chain"] == 0) & (ref["chips"]["algo"] == 0)]
-    assert np.bincount(oc["sample"] // 8192).max() > 2 * 8192            # more than the primary region (half a chip per sample) by far
+    if "-o" not in flags:                                                # (the DC remover tames this interferer: 1 037 chips per segment at most)
+        assert np.bincount(oc["sample"] // 8192).max() > 2 * 8192        # far more than a primary region (half a chip per sample) holds
     kw = flags_to_kwargs(flags)
     with wm.Receiver(n_streams=1, max_push_bytes=cu8.size, **kw) as rx:
         assert rx.run(cu8)[0] == ref["text"]
