@@ -72,6 +72,10 @@ typedef struct wmbus_cfg {
      * the alternatives its source keeps behind `#elif 0` / `#else`: extensions, ignored with -a. */
     int atan_mode;
     unsigned spill_words;       /* tuning: run-length chip spill arena, 32-bit words (0 = default) */
+    unsigned input_windows;     /* 1 (default, also for 0): one device input window per stream; 2: two, used alternately, so
+                                   that wmbus_stage() for the next push may run while the previous one is in flight (the
+                                   copies run on their own HIP stream).  wmbus_device_input() names the window the next
+                                   wmbus_process() will read. */
 } wmbus_cfg;
 
 enum { WMBUS_PREFILTER_BOXCAR = 0, WMBUS_PREFILTER_POLYPHASE = 1 };
@@ -102,6 +106,7 @@ typedef struct wmbus_timing {
     uint64_t bursts;            /* candidate bursts handed to the host decoders       */
     float turn_wait_ms;         /* host time spent waiting for this process's turn in the demodulation kernel */
     unsigned warnings;          /* WMBUS_WARN_* of this push (the push succeeded)     */
+    unsigned slow_path;         /* 1: hand-off verification needed more rounds than run on the device unattended */
 } wmbus_timing;
 
 /* The reference never gives up on an input (rtl_wmbus.c:729-803 has no bound); neither does a push.  When an
@@ -117,7 +122,8 @@ void wmbus_close(wmbus_ctx *ctx);
 const char *wmbus_last_error(const wmbus_ctx *ctx);
 
 /* Replaces fread() at rtl_wmbus.c:1301: copy `nbytes` (multiple of 4096) of stream `stream`
- * from host memory into the device input window of the next push. */
+ * from host memory into the device input window of the next push (asynchronously, on the context's copy stream;
+ * wmbus_process orders its kernels behind the copies). */
 int  wmbus_stage(wmbus_ctx *ctx, unsigned stream, const uint8_t *cu8, size_t nbytes);
 /* Page-locked host memory for wmbus_stage sources (hipHostMalloc): copies from it run at the PCIe
  * rate and asynchronously; any other host pointer works too, through the driver's bounce buffer. */

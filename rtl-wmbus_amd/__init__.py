@@ -42,7 +42,7 @@ class Cfg(ctypes.Structure):
                 ("max_push_bytes", ctypes.c_size_t), ("seg_len", ctypes.c_uint), ("rla_seg_len", ctypes.c_uint),
                 ("warmup_t1c1", ctypes.c_uint),
                 ("warmup_s1", ctypes.c_uint), ("rla_lookback", ctypes.c_uint), ("host_threads", ctypes.c_uint),
-                ("keep_taps", ctypes.c_int), ("prefilter", ctypes.c_int), ("atan_mode", ctypes.c_int), ("spill_words", ctypes.c_uint)]
+                ("keep_taps", ctypes.c_int), ("prefilter", ctypes.c_int), ("atan_mode", ctypes.c_int), ("spill_words", ctypes.c_uint), ("input_windows", ctypes.c_uint)]
 
 
 class Line(ctypes.Structure):
@@ -56,11 +56,11 @@ class Timing(ctypes.Structure):
                 ("gather_ms", ctypes.c_float), ("d2h_ms", ctypes.c_float), ("gpu_total_ms", ctypes.c_float),
                 ("host_decode_ms", ctypes.c_float), ("clock_reruns", ctypes.c_uint), ("rla_reruns", ctypes.c_uint),
                 ("ema_retries", ctypes.c_uint), ("chips", (ctypes.c_uint64 * 2) * 2), ("bursts", ctypes.c_uint64),
-                ("turn_wait_ms", ctypes.c_float), ("warnings", ctypes.c_uint)]
+                ("turn_wait_ms", ctypes.c_float), ("warnings", ctypes.c_uint), ("slow_path", ctypes.c_uint)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k in ("demod_ms", "clock_ms", "rla_ms", "gather_ms", "d2h_ms", "gpu_total_ms",
-                                           "host_decode_ms", "clock_reruns", "rla_reruns", "ema_retries", "bursts", "turn_wait_ms", "warnings")}
+                                           "host_decode_ms", "clock_reruns", "rla_reruns", "ema_retries", "bursts", "turn_wait_ms", "warnings", "slow_path")}
         d["chips"] = [[int(self.chips[ch][al]) for al in range(2)] for ch in range(2)]      # [chain][algo]
         return d
 
@@ -140,7 +140,7 @@ class Receiver:
     def __init__(self, n_streams=1, max_push_bytes=4 << 20, decimation=2, simultaneous=False, accurate_atan=True,
                  remove_dc=False, t1c1=True, s1=True, rla=True, time2=True, show_algorithm=True, device=0,
                  seg_len=0, rla_seg_len=0, warmup_t1c1=0, warmup_s1=0, rla_lookback=0, host_threads=0, fixed_timestamp=True,
-                 prefilter=0, atan_mode=0, keep_taps=True, spill_words=0):
+                 prefilter=0, atan_mode=0, keep_taps=True, spill_words=0, input_windows=1):
         L = lib()
         c = Cfg()
         L.wmbus_default_cfg(ctypes.byref(c))
@@ -154,6 +154,7 @@ class Receiver:
         c.prefilter = prefilter
         c.atan_mode = atan_mode
         c.spill_words = spill_words
+        c.input_windows = input_windows
         self.cfg = c
         self.n_streams = n_streams
         self._h = ctypes.c_void_p()

@@ -106,34 +106,46 @@ struct HostDecoder {           /* persistent across pushes */
 struct wmbus_ctx {
     wmbus_cfg cfg{};
     char err[256] = {0};
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;                      /* every kernel of the context */
+    hipStream_t copy_stream = nullptr;                 /* wmbus_stage's H2D copies (north_star: "pinned hipMemcpyAsync on a side stream") */
     hipEvent_t ev[9] = {};
+    hipEvent_t ev_staged = nullptr;                    /* recorded on copy_stream at process(): the push's input is in HBM */
+    uint32_t n_win = 1, fill = 0;                      /* input windows (cfg.input_windows) and the one wmbus_stage fills now */
     /* geometry */
     uint32_t d = 2, S = 1, C[2] = {8192, 32768}, Mcap = 0, nseg_cap[2] = {0, 0}, ntiles_cap = 0, T = WM_K1_TILE2;
     uint32_t cap[2] = {0, 0}, flags = 0;
     uint64_t in_stride = 0, n0 = 0;
     size_t staged = 0;
     /* device buffers */
-    uint8_t *d_in = nullptr; float *d_dphi = nullptr; uint8_t *d_rssi = nullptr; uint32_t *d_bits = nullptr;
+    uint8_t *d_in = nullptr;                           /* [n_win][S][in_stride] */
+    float *d_dphi = nullptr; uint8_t *d_rssi = nullptr; uint32_t *d_bits = nullptr;
     float *d_lut = nullptr;
-    float *d_ema_head = nullptr, *d_ema_tail = nullptr, *d_ema_carry = nullptr;
+    float *d_ema_head = nullptr, *d_ema_tail = nullptr, *d_ema_carry = nullptr;   /* carry: [2][rows], see carry_in */
+    /* Carried state is double-buffered: a push reads the exact end state of the previous one from half `carry_in` and
+     * commits its own into the other half.  The commits are enqueued before the host knows whether every hand-off was
+     * certified; if wmbus_collect has to finish rounds, the re-runs of first tiles / segments still find the state
+     * they must start from, and the commit is simply made again. */
+    uint32_t carry_in = 0; bool committed = false;
     uint32_t *d_chips[2] = {}, *d_counts[2] = {};
     void *d_st_start[2] = {}, *d_st_final[2] = {}, *d_st_carry[2] = {};
     uint32_t *d_list2 = nullptr;                        /* run-length re-run list of the fused framer launches */
     uint32_t *d_list = nullptr, *d_scalars = nullptr;   /* scalars: err, n_list, n_hits, n_hdr, n_words */
     uint32_t *d_sync_seen[2] = {};                      /* per framer: [2][S][nseg_cap] access-code chip seen in region */
     uint32_t *d_spill = nullptr, *d_chain = nullptr, *d_nchain = nullptr; uint32_t spill_words = 0;   /* WmSpill (wm_dev.h) */
-    bool poisoned = false;                              /* an internal error left the carried state undefined */
+    bool poisoned = false, gpu_decode = true;                              /* an internal error left the carried state undefined */
     uint32_t *d_first_bad = nullptr;                    /* [2][S] first uncertified EMA tile of a row, or ~0 */
     uint32_t *d_ckpt = nullptr; uint32_t nck = 0;       /* clock kernel checkpoints [2][S][nseg_cap][nck][16] */
     uint2 *d_hits = nullptr; uint32_t hits_cap = 0;
     uint32_t *d_pending = nullptr;
-    WmBurstHdr *d_hdr = nullptr; uint32_t hdr_cap = 0;
-    uint32_t *d_words = nullptr; uint32_t words_cap = 0;
-    /* host */
-    uint32_t *h_scalars = nullptr;                      /* pinned */
+    uint32_t hdr_cap = 0, words_cap = 0, pkts_cap = 0, bytes_cap = 0;
+    /* host (pinned).  The burst kernel writes its results straight into h_hdr / h_words / h_pkts / h_bytes (zero-copy over
+     * PCIe: ~1 MB per push once the bursts are decoded on the GPU), so no copy has to wait for a size. */
+    uint32_t *h_scalars = nullptr;
     WmBurstHdr *h_hdr = nullptr; uint32_t *h_words = nullptr; uint32_t *h_pending = nullptr;
-    uint32_t n_hdr = 0, n_words = 0;
+    WmPkt *h_pkts = nullptr; uint8_t *h_bytes = nullptr;
+    void *dv_hdr = nullptr, *dv_words = nullptr, *dv_pkts = nullptr, *dv_bytes = nullptr;    /* their device views */
+    uint32_t n_hdr = 0, n_words = 0, n_pkts = 0;
+    K1Args k1a{}; K2Args k2clk{}, k2rla{}; uint32_t ntiles = 0; bool fused = false;    /* this push's launch arguments (collect's slow path re-uses them) */
     std::vector<HostDecoder> decs;                      /* [stream][chain][algo] */
     std::unique_ptr<WorkerPool> pool;                   /* packet-decoder workers, created on first use */
     std::vector<wmbus_line> lines; std::string text;
@@ -157,16 +169,26 @@ int fail(wmbus_ctx *c, int code, const char *fmt, ...)
 
 template <typename T> hipError_t dalloc(T **p, size_t n) { return hipMalloc((void **)p, n * sizeof(T)); }
 
-enum { SC_ERR = 0, SC_NLIST = 1, SC_NHITS = 2, SC_NHDR = 3, SC_NWORDS = 4, SC_NLIST2 = 5, SC_CHIPS = 8 /* [algo][chain] */, SC_COUNT = 16 };
+/* Hand-off verification runs a few rounds WITHOUT asking the host: verify -> re-run list on the device -> list launch
+ * with a fixed grid -> verify ..., each round with its own counter; the host only looks at the last counters when it
+ * collects the push and finishes the (rare) leftovers round by round. */
+enum { WM_EMA_ROUNDS = 2, WM_FR_ROUNDS = 3 };
+/* debugging aid: WMBUS_OPT_ROUNDS=0 skips the unattended re-run launches (the counters of the rounds stay zero), so
+ * that every hand-off failure is finished by the host-driven path */
+static const bool opt_rounds = !(getenv("WMBUS_OPT_ROUNDS") && atoi(getenv("WMBUS_OPT_ROUNDS")) == 0);
+enum { SC_ERR = 0, SC_NHITS = 1, SC_NHDR = 2, SC_NWORDS = 3, SC_NPKTS = 4, SC_NBYTES = 5, SC_SLOW = 6, SC_CHIPS = 8 /* [algo][chain] */,
+       SC_EMA = 16 /* [WM_EMA_ROUNDS + 1] */, SC_CLK = 24 /* [WM_FR_ROUNDS + 1] */, SC_RLA = 32 /* [WM_FR_ROUNDS + 1] */, SC_COUNT = 40 };
 
-__global__ void k_roll_history(uint8_t *in, uint64_t stride, uint32_t nbytes)
+__global__ void k_roll_history(const uint8_t *in, uint8_t *next, uint64_t stride, uint32_t nbytes)
 {
-    /* new history = the 4096 bytes that end at the end of the staged data */
-    uint8_t *row = in + (uint64_t)blockIdx.x * stride;
-    const uint4 v = *(const uint4 *)(row + nbytes + 16u * threadIdx.x);
+    /* history of the next push (front of the window it will be staged into; the same window when there is only
+     * one) = the 4096 bytes that end at the end of the staged data */
+    const uint4 v = *(const uint4 *)(in + (uint64_t)blockIdx.x * stride + nbytes + 16u * threadIdx.x);
     __syncthreads();
-    *(uint4 *)(row + 16u * threadIdx.x) = v;
+    *(uint4 *)(next + (uint64_t)blockIdx.x * stride + 16u * threadIdx.x) = v;
 }
+
+__global__ void k_copy_word(uint32_t *dst, uint32_t v) { *dst = v; }
 
 __global__ void k_fill(uint8_t *p, uint64_t stride, uint32_t n, uint8_t v)
 {
@@ -204,7 +226,11 @@ __global__ __launch_bounds__(256) void k_sum_counts(WmPush g, const uint32_t *co
 template <int D, bool SHIFT, bool GEN> int launch_k1v3(wmbus_ctx *c, const K1Args &a, dim3 grid)
 {
     const size_t sm = K1Geo::smem(D ? D : (int)c->d, SHIFT);
-    HIPCHK(c, hipFuncSetAttribute((const void *)k1_demod2<D, SHIFT, GEN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+    static size_t set_for[16] = {};                         /* per device: the attribute call is not free, a push makes several launches */
+    if (set_for[c->cfg.device & 15] < sm) {
+        HIPCHK(c, hipFuncSetAttribute((const void *)k1_demod2<D, SHIFT, GEN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+        set_for[c->cfg.device & 15] = sm;
+    }
     hipLaunchKernelGGL((k1_demod2<D, SHIFT, GEN>), grid, dim3(256), sm, c->stream, a);
     HIPCHK(c, hipGetLastError());
     return 0;
@@ -221,7 +247,11 @@ template <int D, bool SHIFT> int launch_k1v2(wmbus_ctx *c, const K1Args &a, dim3
 int launch_k1_ppf(wmbus_ctx *c, const K1Args &a, dim3 grid)
 {
     const size_t sm = K1PpfGeo::smem();
-    HIPCHK(c, hipFuncSetAttribute((const void *)k1_demod_ppf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+    static size_t set_for[16] = {};
+    if (set_for[c->cfg.device & 15] < sm) {
+        HIPCHK(c, hipFuncSetAttribute((const void *)k1_demod_ppf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+        set_for[c->cfg.device & 15] = sm;
+    }
     hipLaunchKernelGGL(k1_demod_ppf, grid, dim3(256), sm, c->stream, a);
     HIPCHK(c, hipGetLastError());
     return 0;
@@ -240,6 +270,14 @@ __global__ void k_selftest(const float *a, const float *b, float *o_sqrt, float 
     o_atan2[i] = wm_atan2f_tab(a[i], b[i], tab);
     o_disc[i] = wm_discriminator_tab(a[i], b[i], b[(i + 1) % n], a[(i + 1) % n], tab);
 }
+
+/* The demodulation kernels of one device's contexts run ONE AFTER THE OTHER (each fills the GPU on its own -- VALU
+ * bound -- so two of them side by side only time-slice, while one of them beside the other contexts' latency- and
+ * memory-bound framer kernels is complementary).  The order is kept on the GPU: a context's K1 waits for the event
+ * behind the K1 launched before it, so no host thread sits in the way (a host-side turn held across the launches of
+ * everything behind K1 made the turn 2.9 ms longer than the kernel). */
+struct K1Chain { std::mutex m; hipEvent_t last = nullptr; const wmbus_ctx *owner = nullptr; };
+K1Chain k1_chain[16];
 
 double now_ms()
 {
@@ -271,14 +309,21 @@ void wmbus_close(wmbus_ctx *c)
 {
     if (!c) return;
     if (c->stream) hipStreamSynchronize(c->stream);
+    {
+        K1Chain &kc = k1_chain[c->cfg.device & 15];
+        std::lock_guard<std::mutex> lk(kc.m);
+        if (kc.owner == c) { kc.last = nullptr; kc.owner = nullptr; }      /* nobody may wait on an event that is about to go */
+    }
     void *dev[] = {c->d_spill, c->d_chain, c->d_nchain, c->d_list2, c->d_sync_seen[0], c->d_sync_seen[1], c->d_first_bad, c->d_ckpt, c->d_in, c->d_dphi, c->d_rssi, c->d_bits, c->d_lut, c->d_ema_head, c->d_ema_tail, c->d_ema_carry,
                    c->d_chips[0], c->d_chips[1], c->d_counts[0], c->d_counts[1], c->d_st_start[0], c->d_st_start[1],
                    c->d_st_final[0], c->d_st_final[1], c->d_st_carry[0], c->d_st_carry[1], c->d_list, c->d_scalars,
-                   c->d_hits, c->d_pending, c->d_hdr, c->d_words};
+                   c->d_hits, c->d_pending};
     for (void *p : dev) if (p) hipFree(p);
-    void *host[] = {c->h_scalars, c->h_hdr, c->h_words, c->h_pending};
+    void *host[] = {c->h_scalars, c->h_hdr, c->h_words, c->h_pending, c->h_pkts, c->h_bytes};
     for (void *p : host) if (p) hipHostFree(p);
     for (auto &e : c->ev) if (e) hipEventDestroy(e);
+    if (c->ev_staged) hipEventDestroy(c->ev_staged);
+    if (c->copy_stream && c->copy_stream != c->stream) { hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); }
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -338,15 +383,21 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
     hipError_t e = hipSuccess;
     auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
     A(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->n_win = cfg->input_windows == 2 ? 2u : 1u;
+    /* the side stream for wmbus_stage's copies exists where it can overlap something: with two input windows.  (Every
+     * stream takes a hardware queue -- ROCm maps streams onto GPU_MAX_HW_QUEUES of them round robin -- and two contexts'
+     * compute streams that end up on one queue serialise: an idle copy stream per context halved the 8-context rate.) */
+    if (c->n_win == 2) A(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking)); else c->copy_stream = c->stream;
     for (auto &ev : c->ev) A(hipEventCreate(&ev));
-    A(dalloc(&c->d_in, (size_t)c->in_stride * c->S));
+    A(hipEventCreateWithFlags(&c->ev_staged, hipEventDisableTiming));
+    A(dalloc(&c->d_in, (size_t)c->in_stride * c->S * c->n_win));
     A(dalloc(&c->d_dphi, (size_t)rows * c->Mcap));
     A(dalloc(&c->d_rssi, (size_t)rows * c->Mcap));
     A(dalloc(&c->d_bits, (size_t)rows * (c->Mcap / 32)));
     A(dalloc(&c->d_lut, (size_t)2 * 32 * WM_MAX_DECIM));
     A(dalloc(&c->d_ema_head, (size_t)rows * c->ntiles_cap));
     A(dalloc(&c->d_ema_tail, (size_t)rows * c->ntiles_cap));
-    A(dalloc(&c->d_ema_carry, (size_t)rows));
+    A(dalloc(&c->d_ema_carry, (size_t)2 * rows));
     A(dalloc(&c->d_first_bad, (size_t)rows));
     const size_t stw[2] = {sizeof(WmRlaState), sizeof(WmClkState)};
     for (int a = 0; a < 2; a++) {
@@ -355,7 +406,7 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
         A(dalloc(&c->d_sync_seen[a], (size_t)rows * c->nseg_cap[a]));
         A(hipMalloc(&c->d_st_start[a], (size_t)rows * c->nseg_cap[a] * stw[a]));
         A(hipMalloc(&c->d_st_final[a], (size_t)rows * c->nseg_cap[a] * stw[a]));
-        A(hipMalloc(&c->d_st_carry[a], (size_t)rows * stw[a]));
+        A(hipMalloc(&c->d_st_carry[a], (size_t)2 * rows * stw[a]));
     }
     {
         const uint64_t dec_total_ = (uint64_t)c->S * c->Mcap;
@@ -373,29 +424,43 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
     const uint64_t dec_total = (uint64_t)c->S * c->Mcap;
     c->hdr_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(65536, dec_total / 1024), 1u << 24);
     c->hits_cap = c->hdr_cap;
-    c->words_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1u << 20, dec_total / 8), 1u << 29);
+    /* bursts that still travel as chips are the ones cut by the end of a push (and their continuations): at most one
+     * per (capture, chain, framer) and push, each at most 16 x 290 + 1 chips */
+    c->gpu_decode = !(getenv("WMBUS_GPU_DECODE") && atoi(getenv("WMBUS_GPU_DECODE")) == 0);    /* 0: every burst to the host decoders as chips (A/B, tests) */
+    c->words_cap = c->gpu_decode ? (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1u << 20, 4ull * c->S * 1024), 1u << 28)
+                                 : (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1u << 20, dec_total / 8), 1u << 29);
+    c->pkts_cap = c->hdr_cap;
+    c->bytes_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1u << 20, dec_total / 64), 1u << 30);
     A(dalloc(&c->d_hits, (size_t)c->hits_cap));
     A(dalloc(&c->d_pending, (size_t)4 * c->S));
-    A(dalloc(&c->d_hdr, (size_t)c->hdr_cap));
-    A(dalloc(&c->d_words, (size_t)c->words_cap));
     A(hipHostMalloc((void **)&c->h_scalars, SC_COUNT * sizeof(uint32_t)));
     A(hipHostMalloc((void **)&c->h_hdr, (size_t)c->hdr_cap * sizeof(WmBurstHdr)));
     A(hipHostMalloc((void **)&c->h_words, (size_t)c->words_cap * sizeof(uint32_t)));
+    A(hipHostMalloc((void **)&c->h_pkts, (size_t)c->pkts_cap * sizeof(WmPkt)));
+    A(hipHostMalloc((void **)&c->h_bytes, (size_t)c->bytes_cap));
     A(hipHostMalloc((void **)&c->h_pending, (size_t)4 * c->S * sizeof(uint32_t)));
+    if (e == hipSuccess) {
+        A(hipHostGetDevicePointer(&c->dv_hdr, c->h_hdr, 0)); A(hipHostGetDevicePointer(&c->dv_words, c->h_words, 0));
+        A(hipHostGetDevicePointer(&c->dv_pkts, c->h_pkts, 0)); A(hipHostGetDevicePointer(&c->dv_bytes, c->h_bytes, 0));
+    }
     if (e != hipSuccess) return bail(fail(c, e == hipErrorOutOfMemory ? WMBUS_ENOMEM : WMBUS_EDEVICE, "allocation failed: %s", hipGetErrorString(e)));
 
     /* initial state = the reference's zero-initialised statics */
-    A(hipMemsetAsync(c->d_ema_carry, 0, rows * sizeof(float), c->stream));
+    A(hipMemsetAsync(c->d_ema_carry, 0, 2 * rows * sizeof(float), c->stream));
+    /* a disabled chain (-p T / -p S) never writes its hand-off records: they must compare equal, not hold what an
+     * earlier context left in the recycled allocation */
+    A(hipMemsetAsync(c->d_ema_head, 0, (size_t)rows * c->ntiles_cap * sizeof(float), c->stream));
+    A(hipMemsetAsync(c->d_ema_tail, 0, (size_t)rows * c->ntiles_cap * sizeof(float), c->stream));
     A(hipMemsetAsync(c->d_first_bad, 0xFF, rows * sizeof(uint32_t), c->stream));
-    A(hipMemsetAsync(c->d_st_carry[1], 0, rows * sizeof(WmClkState), c->stream));
+    A(hipMemsetAsync(c->d_st_carry[1], 0, 2 * rows * sizeof(WmClkState), c->stream));
     {
-        std::vector<WmRlaState> init(rows, WmRlaState{0, 8 * 256, 0, 0u, 0u, 0u, 24, 24});   /* rtl_wmbus.c:628-637,717-726 */
-        A(hipMemcpyAsync(c->d_st_carry[0], init.data(), rows * sizeof(WmRlaState), hipMemcpyHostToDevice, c->stream));
+        std::vector<WmRlaState> init(2 * rows, WmRlaState{0, 8 * 256, 0, 0u, 0u, 0u, 24, 24});   /* rtl_wmbus.c:628-637,717-726 */
+        A(hipMemcpyAsync(c->d_st_carry[0], init.data(), 2 * rows * sizeof(WmRlaState), hipMemcpyHostToDevice, c->stream));
         A(hipStreamSynchronize(c->stream));
     }
     A(hipMemsetAsync(c->d_scalars, 0, SC_COUNT * sizeof(uint32_t), c->stream));
     A(hipMemsetAsync(c->d_pending, 0, 4 * c->S * sizeof(uint32_t), c->stream));
-    hipLaunchKernelGGL(k_fill, dim3(c->S), dim3(256), 0, c->stream, c->d_in, c->in_stride, (uint32_t)c->in_stride, (uint8_t)128);
+    hipLaunchKernelGGL(k_fill, dim3(c->S * c->n_win), dim3(256), 0, c->stream, c->d_in, c->in_stride, (uint32_t)c->in_stride, (uint8_t)128);
     /* frequency-translation LUT, built with the host libm exactly like rtl_wmbus.c:974-993 */
     {
         const int fs_khz = (int)c->d * 800;
@@ -434,98 +499,133 @@ void wmbus_free_pinned(void *p) { if (p) hipHostFree(p); }
 void *wmbus_device_input(wmbus_ctx *c, unsigned stream)
 {
     if (!c || stream >= c->S) return nullptr;
-    return c->d_in + (size_t)stream * c->in_stride + WM_HIST_BYTES;
+    return c->d_in + ((size_t)c->fill * c->S + stream) * c->in_stride + WM_HIST_BYTES;
 }
 
 int wmbus_stage(wmbus_ctx *c, unsigned stream, const uint8_t *cu8, size_t nbytes)
 {
     if (!c || stream >= c->S || !cu8) return WMBUS_EINVAL;
     if (nbytes > c->cfg.max_push_bytes || nbytes % WMBUS_BLOCK_BYTES) return fail(c, WMBUS_EINVAL, "stage: nbytes must be a multiple of 4096 and <= max_push_bytes");
-    HIPCHK(c, hipMemcpyAsync(wmbus_device_input(c, stream), cu8, nbytes, hipMemcpyHostToDevice, c->stream));
+    /* with one input window the kernels of a push in flight still read it; with two (cfg.input_windows = 2) the next
+     * push is staged into the other one while they run */
+    if (c->in_flight && c->n_win == 1) return fail(c, WMBUS_EINVAL, "stage: a push is in flight and the context has one input window (cfg.input_windows = 2 overlaps them)");
+    HIPCHK(c, hipMemcpyAsync(wmbus_device_input(c, stream), cu8, nbytes, hipMemcpyHostToDevice, c->copy_stream));
     return WMBUS_OK;
 }
 
-static int run_segments(wmbus_ctx *c, int algo, K2Args a, float *ms, unsigned *reruns)
+/* ---- launches --------------------------------------------------------------------------------- */
+static float *ema_carry(wmbus_ctx *c, bool out) { return c->d_ema_carry + (size_t)(c->carry_in ^ (out ? 1u : 0u)) * 2 * c->S; }
+static void *st_carry(wmbus_ctx *c, int algo, bool out)
 {
-    const WmPush &g = a.g;
-    const uint32_t lanes = 2u * g.nseg[algo] * g.S;
-    const uint32_t words = (algo == WMBUS_ALGO_RLA ? sizeof(WmRlaState) : sizeof(WmClkState)) / 4;
-    auto launch = [&](const uint32_t *list, uint32_t n) {
-        a.list = list; a.n_lanes = n;
-        if (algo == WMBUS_ALGO_RLA) hipLaunchKernelGGL(k2_rla, dim3((n + 64 * WM_RLA_WPB - 1) / (64 * WM_RLA_WPB)), dim3(64 * WM_RLA_WPB), 0, c->stream, a);
-        else if (c->flags & WM_F_DC) hipLaunchKernelGGL(k2_clock<true>, dim3((n + 64 * WM_CLK_WPB - 1) / (64 * WM_CLK_WPB)), dim3(64 * WM_CLK_WPB), 0, c->stream, a);
-        else hipLaunchKernelGGL(k2_clock<false>, dim3((n + 64 * WM_CLK_WPB - 1) / (64 * WM_CLK_WPB)), dim3(64 * WM_CLK_WPB), 0, c->stream, a);
-    };
-    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-    launch(nullptr, lanes);
-    for (unsigned round = 0;; round++) {
-        HIPCHK(c, hipMemsetAsync(c->d_scalars + SC_NLIST, 0, sizeof(uint32_t), c->stream));
-        hipLaunchKernelGGL(k2_verify, dim3((lanes + 255) / 256), dim3(256), 0, c->stream, g, (uint32_t)algo,
-                           (const uint32_t *)a.st_start, (const uint32_t *)a.st_final, words, c->d_list, c->d_scalars + SC_NLIST);
-        HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, SC_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        const uint32_t n = c->h_scalars[SC_NLIST];
-        if (n == 0) break;
-        if (round > g.nseg[algo] + 1) return fail(c, WMBUS_EDEVICE, "segment verification did not converge");
-        *reruns += n;
-        launch(c->d_list, n);
-    }
-    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-    HIPCHK(c, hipEventSynchronize(c->ev[1]));
-    HIPCHK(c, hipEventElapsedTime(ms, c->ev[0], c->ev[1]));
-    /* carry the exact end state into the next push */
-    const uint32_t rows = 2u * g.S;
-    hipLaunchKernelGGL(k_carry, dim3((rows + 255) / 256), dim3(256), 0, c->stream, (const uint32_t *)a.st_final,
-                       (uint32_t *)a.st_carry, words, rows, g.nseg_cap[algo], g.nseg[algo]);
-    HIPCHK(c, hipGetLastError());
-    return 0;
+    const size_t w = algo == WMBUS_ALGO_RLA ? sizeof(WmRlaState) : sizeof(WmClkState);
+    return (char *)c->d_st_carry[algo] + (size_t)(c->carry_in ^ (out ? 1u : 0u)) * 2 * c->S * w;
 }
 
-/* Both framers when the slicer words do not depend on filter state (no DC remover): the clock
- * kernel's first pass, then launches that carry the clock re-run lanes AND the run-length framer
- * (main pass first, its own re-run lists afterwards) until both have converged. */
-static int run_framers_fused(wmbus_ctx *c, K2Args clk, K2Args rla)
+static int launch_k1_any(wmbus_ctx *c, const K1Args &k1, dim3 grid)
 {
-    const WmPush &g = clk.g;
-    const uint32_t lanes_c = 2u * g.nseg[1] * g.S, lanes_r = 2u * g.nseg[0] * g.S;
-    const uint32_t wc = sizeof(WmClkState) / 4, wr = sizeof(WmRlaState) / 4, B = 64 * WM_CLK_WPB, Br = 64 * WM_RLA_WPB;
-    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-    clk.list = nullptr; clk.n_lanes = lanes_c;
-    hipLaunchKernelGGL(k2_clock<false>, dim3((lanes_c + B - 1) / B), dim3(B), 0, c->stream, clk);
-    bool clk_done = false, rla_started = false, rla_done = false;
-    for (unsigned round = 0;; round++) {
-        HIPCHK(c, hipMemsetAsync(c->d_scalars + SC_NLIST, 0, sizeof(uint32_t), c->stream));
-        HIPCHK(c, hipMemsetAsync(c->d_scalars + SC_NLIST2, 0, sizeof(uint32_t), c->stream));
-        if (!clk_done)
-            hipLaunchKernelGGL(k2_verify, dim3((lanes_c + 255) / 256), dim3(256), 0, c->stream, g, (uint32_t)WMBUS_ALGO_T2A,
-                               (const uint32_t *)clk.st_start, (const uint32_t *)clk.st_final, wc, c->d_list, c->d_scalars + SC_NLIST);
-        if (rla_started && !rla_done)
-            hipLaunchKernelGGL(k2_verify, dim3((lanes_r + 255) / 256), dim3(256), 0, c->stream, g, (uint32_t)WMBUS_ALGO_RLA,
-                               (const uint32_t *)rla.st_start, (const uint32_t *)rla.st_final, wr, c->d_list2, c->d_scalars + SC_NLIST2);
-        HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, SC_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        const uint32_t n_c = clk_done ? 0u : c->h_scalars[SC_NLIST], n_r = c->h_scalars[SC_NLIST2];
-        if (!clk_done && n_c == 0) { clk_done = true; HIPCHK(c, hipEventRecord(c->ev[8], c->stream)); }
-        if (rla_started && n_r == 0) rla_done = true;
-        if (clk_done && rla_done) break;
-        if (round > std::max(g.nseg[0], g.nseg[1]) + 2) return fail(c, WMBUS_EDEVICE, "segment verification did not converge");
-        K2Args ca = clk, ra = rla;
-        ca.list = c->d_list; ca.n_lanes = n_c;
-        c->tim.clock_reruns += n_c;
-        if (!rla_started) { ra.list = nullptr; ra.n_lanes = lanes_r; rla_started = true; }
-        else { ra.list = c->d_list2; ra.n_lanes = n_r; c->tim.rla_reruns += n_r; }
-        const uint32_t cb = (n_c + 63u) / 64u, rb = (ra.n_lanes + Br - 1) / Br;     /* one clock wave per block here */
-        hipLaunchKernelGGL(k2_clock_rla, dim3(cb + rb), dim3(Br), 0, c->stream, ca, ra, cb);
+    const bool sh = c->flags & WM_F_SHIFT;
+    if (c->cfg.prefilter == WMBUS_PREFILTER_POLYPHASE) return launch_k1_ppf(c, k1, grid);
+    if (c->d == 2) return sh ? launch_k1v2<2, true>(c, k1, grid) : launch_k1v2<2, false>(c, k1, grid);
+    if (c->d == 3) return sh ? launch_k1v2<3, true>(c, k1, grid) : launch_k1v2<3, false>(c, k1, grid);
+    if (c->d == 4) return sh ? launch_k1v2<4, true>(c, k1, grid) : launch_k1v2<4, false>(c, k1, grid);
+    if (c->d == 5) return sh ? launch_k1v2<5, true>(c, k1, grid) : launch_k1v2<5, false>(c, k1, grid);
+    return sh ? launch_k1v2<0, true>(c, k1, grid) : launch_k1v2<0, false>(c, k1, grid);      /* any other rate */
+}
+
+/* EMA hand-offs between tiles (k1_verify), the first uncertified tile of every row into the repair list (k1_collect),
+ * its length into scalar `cnt`.  A listed tile is re-run sequentially from its predecessor's exact tail, which may
+ * uncover the next one: exact by construction. */
+static void ema_verify(wmbus_ctx *c, uint32_t cnt)
+{
+    const uint32_t rows = 2 * c->S, ntiles = c->ntiles;
+    hipLaunchKernelGGL(k1_verify, dim3((rows + 63) / 64, ntiles), dim3(64), 0, c->stream, c->d_ema_head, c->d_ema_tail, ema_carry(c, false), ntiles, rows, c->d_first_bad);
+    hipLaunchKernelGGL(k1_collect, dim3((rows + 63) / 64), dim3(64), 0, c->stream, c->d_first_bad, ntiles, rows, c->S, c->d_list, c->d_scalars + cnt);
+}
+
+static int ema_repair(wmbus_ctx *c, uint32_t cnt)          /* list launch: a fixed grid walks d_list[0 .. scalar cnt) */
+{
+    K1Args k1 = c->k1a;
+    k1.relist = c->d_list; k1.n_relist = c->d_scalars + cnt;
+    return launch_k1_any(c, k1, dim3(16, 1));
+}
+
+static void ema_commit(wmbus_ctx *c)
+{
+    hipLaunchKernelGGL(k1_commit, dim3((2 * c->S + 63) / 64), dim3(64), 0, c->stream, c->d_ema_tail, ema_carry(c, true), c->ntiles, 2 * c->S);
+}
+
+static void fr_verify(wmbus_ctx *c, int algo, uint32_t cnt)
+{
+    const K2Args &a = algo == WMBUS_ALGO_RLA ? c->k2rla : c->k2clk;
+    const uint32_t lanes = 2u * a.g.nseg[algo] * a.g.S, words = (algo == WMBUS_ALGO_RLA ? sizeof(WmRlaState) : sizeof(WmClkState)) / 4;
+    hipLaunchKernelGGL(k2_verify, dim3((lanes + 255) / 256), dim3(256), 0, c->stream, a.g, (uint32_t)algo, (const uint32_t *)a.st_start,
+                       (const uint32_t *)a.st_final, words, algo == WMBUS_ALGO_RLA ? c->d_list2 : c->d_list, c->d_scalars + cnt);
+}
+
+/* one framer's kernel alone: every lane (cnt == ~0) or the re-run list whose length is scalar `cnt` */
+static void fr_launch(wmbus_ctx *c, int algo, uint32_t cnt)
+{
+    K2Args a = algo == WMBUS_ALGO_RLA ? c->k2rla : c->k2clk;
+    const uint32_t lanes = 2u * a.g.nseg[algo] * a.g.S;
+    const bool all = cnt == 0xFFFFFFFFu;
+    a.list = all ? nullptr : (algo == WMBUS_ALGO_RLA ? c->d_list2 : c->d_list);
+    a.n_lanes = lanes; a.n_ptr = all ? nullptr : c->d_scalars + cnt;
+    const uint32_t B = 64 * (algo == WMBUS_ALGO_RLA ? WM_RLA_WPB : WM_CLK_WPB), grid = all ? (lanes + B - 1) / B : 16u;
+    if (algo == WMBUS_ALGO_RLA) hipLaunchKernelGGL(k2_rla, dim3(grid), dim3(B), 0, c->stream, a);
+    else if (c->flags & WM_F_DC) hipLaunchKernelGGL(k2_clock<true>, dim3(grid), dim3(B), 0, c->stream, a);
+    else hipLaunchKernelGGL(k2_clock<false>, dim3(grid), dim3(B), 0, c->stream, a);
+}
+
+/* the fused launch: clock re-run list (scalar cnt_c) + run-length framer, all lanes (cnt_r == ~0) or its list */
+static void fr_launch_fused(wmbus_ctx *c, uint32_t cnt_c, uint32_t cnt_r)
+{
+    K2Args ca = c->k2clk, ra = c->k2rla;
+    ca.list = c->d_list; ca.n_ptr = c->d_scalars + cnt_c; ca.n_lanes = 0;
+    const uint32_t lanes_r = 2u * ra.g.nseg[0] * ra.g.S, Br = 64 * WM_RLA_WPB;
+    const bool all = cnt_r == 0xFFFFFFFFu;
+    ra.list = all ? nullptr : c->d_list2; ra.n_lanes = lanes_r; ra.n_ptr = all ? nullptr : c->d_scalars + cnt_r;
+    const uint32_t cb = 32u, rb = all ? (lanes_r + Br - 1) / Br : 16u;      /* one clock wave per block here */
+    hipLaunchKernelGGL(k2_clock_rla, dim3(cb + rb), dim3(Br), 0, c->stream, ca, ra, cb);
+}
+
+static void fr_carry(wmbus_ctx *c)
+{
+    const uint32_t rows = 2u * c->S;
+    const WmPush &g = c->k2clk.g;
+    hipLaunchKernelGGL(k_carry, dim3((rows + 255) / 256), dim3(256), 0, c->stream, (const uint32_t *)c->k2clk.st_final,
+                       (uint32_t *)st_carry(c, 1, true), (uint32_t)(sizeof(WmClkState) / 4), rows, g.nseg_cap[1], g.nseg[1]);
+    if (c->flags & WM_F_RLA)
+        hipLaunchKernelGGL(k_carry, dim3((rows + 255) / 256), dim3(256), 0, c->stream, (const uint32_t *)c->k2rla.st_final,
+                           (uint32_t *)st_carry(c, 0, true), (uint32_t)(sizeof(WmRlaState) / 4), rows, g.nseg_cap[0], g.nseg[0]);
+    else   /* a disabled run-length framer keeps its state */
+        hipMemcpyAsync(st_carry(c, 0, true), st_carry(c, 0, false), (size_t)rows * sizeof(WmRlaState), hipMemcpyDeviceToDevice, c->stream);
+}
+
+/* K3 on the settled chip streams: chips-per-framer sums, access-code hits, bursts (decoded on the GPU where they are
+ * complete), then the scalars for the host.  Nothing here needs a number from the host. */
+static int launch_k3(wmbus_ctx *c)
+{
+    const WmPush &g = c->last;
+    HIPCHK(c, hipMemsetAsync(c->d_scalars + SC_NHITS, 0, 5 * sizeof(uint32_t), c->stream));          /* NHITS .. NBYTES */
+    HIPCHK(c, hipMemsetAsync(c->d_scalars + SC_CHIPS, 0, 4 * sizeof(uint32_t), c->stream));
+    hipLaunchKernelGGL(k_sum_counts, dim3(std::min(64u, (2u * (c->nseg_cap[0] + c->nseg_cap[1]) * c->S + 255u) / 256u)), dim3(256), 0, c->stream, g,
+                       c->d_counts[0], c->d_counts[1], c->d_scalars + SC_CHIPS);
+    hipLaunchKernelGGL(k3_scan, dim3((2u * (g.nseg[0] + g.nseg[1]) * g.S + 255u) / 256u), dim3(256), 0, c->stream, g, c->d_chips[0], c->d_chips[1],
+                       c->d_counts[0], c->d_counts[1], c->d_sync_seen[0], c->d_sync_seen[1], c->d_hits, c->d_scalars + SC_NHITS,
+                       c->hits_cap, c->d_scalars + SC_ERR);
+    K3Args k3{};
+    k3.g = g; k3.rssi = c->d_rssi;
+    k3.chips[0] = c->d_chips[0]; k3.chips[1] = c->d_chips[1]; k3.counts[0] = c->d_counts[0]; k3.counts[1] = c->d_counts[1];
+    k3.hits = c->d_hits; k3.n_hits = c->d_scalars + SC_NHITS; k3.hits_cap = c->hits_cap; k3.pending = c->d_pending;
+    k3.hdr = (WmBurstHdr *)c->dv_hdr; k3.hdr_cap = c->hdr_cap; k3.words = (uint32_t *)c->dv_words; k3.words_cap = c->words_cap;
+    k3.n_hdr = c->d_scalars + SC_NHDR; k3.n_words = c->d_scalars + SC_NWORDS; k3.err = c->d_scalars + SC_ERR;
+    if (c->gpu_decode) {
+        k3.pkts = (WmPkt *)c->dv_pkts; k3.pkts_cap = c->pkts_cap; k3.bytes = (uint8_t *)c->dv_bytes; k3.bytes_cap = c->bytes_cap;
+        k3.n_pkts = c->d_scalars + SC_NPKTS; k3.n_bytes = c->d_scalars + SC_NBYTES;
     }
-    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-    HIPCHK(c, hipEventSynchronize(c->ev[1]));
-    HIPCHK(c, hipEventElapsedTime(&c->tim.clock_ms, c->ev[0], c->ev[8]));      /* until the clock kernel had converged */
-    HIPCHK(c, hipEventElapsedTime(&c->tim.rla_ms, c->ev[8], c->ev[1]));        /* what the run-length framer added   */
-    const uint32_t rows = 2u * g.S;
-    hipLaunchKernelGGL(k_carry, dim3((rows + 255) / 256), dim3(256), 0, c->stream, (const uint32_t *)clk.st_final,
-                       (uint32_t *)clk.st_carry, wc, rows, g.nseg_cap[1], g.nseg[1]);
-    hipLaunchKernelGGL(k_carry, dim3((rows + 255) / 256), dim3(256), 0, c->stream, (const uint32_t *)rla.st_final,
-                       (uint32_t *)rla.st_carry, wr, rows, g.nseg_cap[0], g.nseg[0]);
+    static const uint32_t max_blocks = getenv("WMBUS_K3_BLOCKS") ? (uint32_t)atoi(getenv("WMBUS_K3_BLOCKS")) : 256u;   /* tuning aid; 128 ... 512 are within 2 % of each other */
+    const uint32_t most = 4 * c->S + c->hits_cap;
+    hipLaunchKernelGGL(k3_bursts, dim3(std::max(1u, std::min((most + 3u) / 4u, max_blocks))), dim3(256), 0, c->stream, k3, 0xFFFFFFFFu);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -538,9 +638,11 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
     if (c->in_flight) return fail(c, WMBUS_EINVAL, "process: previous push not collected");
     if (c->poisoned) return fail(c, WMBUS_EDEVICE, "process: an earlier internal error left this context unusable; close it");
     c->tim = wmbus_timing{};
+    if (c->committed) { c->carry_in ^= 1u; c->committed = false; }     /* the previous push's end state is this one's start state */
     const uint32_t n_new = (uint32_t)(nbytes / 2);
+    uint8_t *win = c->d_in + (size_t)c->fill * c->S * c->in_stride;      /* the window wmbus_stage has been filling */
     WmPush g{};
-    g.in = c->d_in; g.in_stride = c->in_stride; g.n0 = c->n0; g.m0 = c->n0 / c->d;
+    g.in = win; g.in_stride = c->in_stride; g.n0 = c->n0; g.m0 = c->n0 / c->d;
     g.n_new = n_new; g.M = (uint32_t)((c->n0 + n_new) / c->d - g.m0);
     g.Mcap = c->Mcap; g.d = c->d; g.S = c->S; g.lut_n = 32 * c->d;
     g.lut_phase0 = (uint32_t)((13ull * (c->n0 % g.lut_n)) % g.lut_n);
@@ -552,63 +654,52 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
     g.sp.arena = c->d_spill; g.sp.arena_words = c->spill_words; g.sp.chain = c->d_chain; g.sp.nchain = c->d_nchain;
     g.sp.used = c->d_nchain + (size_t)2 * c->S * c->nseg_cap[0];
     c->last = g; c->have_last = true;
-    c->n_hdr = c->n_words = 0;
+    c->n_hdr = c->n_words = c->n_pkts = 0;
 
+    /* the staged bytes arrive on the copy stream */
+    if (c->copy_stream != c->stream) {
+        HIPCHK(c, hipEventRecord(c->ev_staged, c->copy_stream));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_staged, 0));
+    }
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     if (g.M > 0) {
         HIPCHK(c, hipMemsetAsync(c->d_scalars, 0, SC_COUNT * sizeof(uint32_t), c->stream));
+        /* chips the decoders of half-received telegrams still want: known since the previous collect */
+        for (uint32_t s = 0; s < c->S; s++)
+            for (int ch = 0; ch < 2; ch++)
+                for (int al = 0; al < 2; al++)
+                    c->h_pending[(al * 2 + ch) * c->S + s] = c->decs[((size_t)s * 2 + ch) * 2 + al].owed;
+        HIPCHK(c, hipMemcpyAsync(c->d_pending, c->h_pending, 4 * c->S * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         /* K1 */
         const uint32_t T = c->T, ntiles = (g.M + T - 1) / T;
-        K1Args k1{g, c->d_dphi, c->d_rssi, c->d_lut, c->d_lut + 32 * WM_MAX_DECIM, c->d_ema_head, c->d_ema_tail, ntiles, c->d_scalars + SC_ERR,
-                  nullptr, c->d_ema_carry};
-        /* Contexts of one process take turns in the demodulation kernel: it fills the GPU on its own
-         * (VALU bound), so two of them side by side only time-slice, while one of them beside the
-         * other contexts' latency- and memory-bound framer kernels is complementary.  The turn also
-         * makes the event pair below measure the kernel rather than its share of the GPU. */
-        static std::mutex k1_turn[16];
-        std::unique_lock<std::mutex> turn(k1_turn[c->cfg.device & 15], std::defer_lock);
-        static const bool take_turns = !(getenv("WMBUS_K1_TURNS") && atoi(getenv("WMBUS_K1_TURNS")) == 0);
-        if (take_turns) {
-            const auto t_wait = std::chrono::steady_clock::now();
-            turn.lock();
-            c->tim.turn_wait_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_wait).count();
-        }
-        HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-        auto launch = [&](uint32_t n_list) -> int {                  /* n_list = 0: all tiles; else the repair list */
-            const bool sh = c->flags & WM_F_SHIFT;
-            k1.relist = n_list ? c->d_list : nullptr;
-            const dim3 grid = n_list ? dim3(n_list, 1) : dim3(ntiles, c->S);
-            if (c->cfg.prefilter == WMBUS_PREFILTER_POLYPHASE) return launch_k1_ppf(c, k1, grid);
-            if (c->d == 2) return sh ? launch_k1v2<2, true>(c, k1, grid) : launch_k1v2<2, false>(c, k1, grid);
-            if (c->d == 3) return sh ? launch_k1v2<3, true>(c, k1, grid) : launch_k1v2<3, false>(c, k1, grid);
-            if (c->d == 4) return sh ? launch_k1v2<4, true>(c, k1, grid) : launch_k1v2<4, false>(c, k1, grid);
-            if (c->d == 5) return sh ? launch_k1v2<5, true>(c, k1, grid) : launch_k1v2<5, false>(c, k1, grid);
-            return sh ? launch_k1v2<0, true>(c, k1, grid) : launch_k1v2<0, false>(c, k1, grid);      /* any other rate */
-        };
-        int rc = launch(0);
-        if (rc) return rc;
-        HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
-        /* the turn ends with the kernel: the step time of n contexts is n times the time the
-         * turn is held */
-        if (take_turns) { HIPCHK(c, hipEventSynchronize(c->ev[4])); turn.unlock(); }
-        /* EMA hand-offs between tiles; an uncertified tile is re-run sequentially from its
-         * predecessor's exact tail (which may uncover the next one): exact by construction */
-        for (unsigned round = 0;; round++) {
-            hipLaunchKernelGGL(k1_verify, dim3((2 * c->S + 63) / 64, ntiles), dim3(64), 0, c->stream, c->d_ema_head, c->d_ema_tail,
-                               c->d_ema_carry, ntiles, 2 * c->S, c->d_first_bad);
-            hipLaunchKernelGGL(k1_collect, dim3((2 * c->S + 63) / 64), dim3(64), 0, c->stream, c->d_first_bad, ntiles, 2 * c->S, c->S,
-                               c->d_list, c->d_scalars + SC_NLIST);
-            HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, SC_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            const uint32_t n = c->h_scalars[SC_NLIST];
-            if (n == 0) break;
-            if (round > ntiles + 1) return fail(c, WMBUS_EDEVICE, "RSSI filter hand-off repair did not converge");
-            c->tim.ema_retries += n;
-            rc = launch(n);
+        c->ntiles = ntiles;
+        c->k1a = K1Args{g, c->d_dphi, c->d_rssi, c->d_lut, c->d_lut + 32 * WM_MAX_DECIM, c->d_ema_head, c->d_ema_tail, ntiles, c->d_scalars + SC_ERR,
+                        nullptr, ema_carry(c, false), nullptr};
+        static const int turns = getenv("WMBUS_K1_TURNS") ? atoi(getenv("WMBUS_K1_TURNS")) : 1;      /* 0: no order (A/B) */
+        int rc;
+        {
+            K1Chain &kc = k1_chain[c->cfg.device & 15];
+            std::unique_lock<std::mutex> lk(kc.m, std::defer_lock);
+            if (turns) {
+                lk.lock();
+                if (kc.last && kc.owner != c) HIPCHK(c, hipStreamWaitEvent(c->stream, kc.last, 0));
+            }
+            HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+            rc = launch_k1_any(c, c->k1a, dim3(ntiles, c->S));
             if (rc) return rc;
-            HIPCHK(c, hipMemsetAsync(c->d_scalars + SC_NLIST, 0, sizeof(uint32_t), c->stream));
+            HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+            if (turns) { kc.last = c->ev[4]; kc.owner = c; }
         }
-        hipLaunchKernelGGL(k1_commit, dim3((2 * c->S + 63) / 64), dim3(64), 0, c->stream, c->d_ema_tail, c->d_ema_carry, ntiles, 2 * c->S);
+        /* Everything behind K1 is enqueued while it runs -- no step of a push waits for the host any more:
+         * hand-off verification makes its first rounds on the device (counters per round), K3 reads its item
+         * count there, the results land in pinned host memory.  wmbus_collect looks at the last counters. */
+        for (unsigned r = 0; r < WM_EMA_ROUNDS && opt_rounds; r++) {
+            ema_verify(c, SC_EMA + r);
+            rc = ema_repair(c, SC_EMA + r);
+            if (rc) return rc;
+        }
+        ema_verify(c, SC_EMA + WM_EMA_ROUNDS);
+        ema_commit(c);
 
         /* K2: clock recovery + time2 framer (also produces the slicer bits the RLA needs) */
         K2Args k2{};
@@ -618,98 +709,173 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
             HIPCHK(c, hipMemsetAsync(c->d_sync_seen[al], 0, (size_t)2 * c->S * c->nseg_cap[al] * sizeof(uint32_t), c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_nchain, 0, ((size_t)2 * c->S * c->nseg_cap[0] + 1) * sizeof(uint32_t), c->stream));   /* spill chains + bump counter */
         k2.ckpt = c->d_ckpt; k2.nck = c->nck;
-        K2Args ka = k2, kr = k2;
+        c->k2clk = k2; c->k2rla = k2;
+        K2Args &ka = c->k2clk, &kr = c->k2rla;
         ka.algo = WMBUS_ALGO_T2A;
         ka.chips = c->d_chips[1]; ka.counts = c->d_counts[1]; ka.sync_seen = c->d_sync_seen[1];
-        ka.st_start = c->d_st_start[1]; ka.st_final = c->d_st_final[1]; ka.st_carry = c->d_st_carry[1];
+        ka.st_start = c->d_st_start[1]; ka.st_final = c->d_st_final[1]; ka.st_carry = st_carry(c, 1, false);
         kr.algo = WMBUS_ALGO_RLA;
         kr.chips = c->d_chips[0]; kr.counts = c->d_counts[0]; kr.sync_seen = c->d_sync_seen[0];
-        kr.st_start = c->d_st_start[0]; kr.st_final = c->d_st_final[0]; kr.st_carry = c->d_st_carry[0];
+        kr.st_start = c->d_st_start[0]; kr.st_final = c->d_st_final[0]; kr.st_carry = st_carry(c, 0, false);
         static const bool fuse = !(getenv("WMBUS_FUSE_FRAMERS") && atoi(getenv("WMBUS_FUSE_FRAMERS")) == 0);   /* tuning aid */
-        if ((c->flags & WM_F_RLA) && !(c->flags & WM_F_DC) && fuse) {
-            rc = run_framers_fused(c, ka, kr);
-            if (rc) return rc;
-        } else {
-            rc = run_segments(c, WMBUS_ALGO_T2A, ka, &c->tim.clock_ms, &c->tim.clock_reruns);
-            if (rc) return rc;
-            if (c->flags & WM_F_RLA) {
-                rc = run_segments(c, WMBUS_ALGO_RLA, kr, &c->tim.rla_ms, &c->tim.rla_reruns);
-                if (rc) return rc;
-            } else {
-                HIPCHK(c, hipMemsetAsync(c->d_counts[0], 0, (size_t)2 * c->S * c->nseg_cap[0] * sizeof(uint32_t), c->stream));
+        const bool rla = c->flags & WM_F_RLA;
+        c->fused = rla && !(c->flags & WM_F_DC) && fuse;
+        HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+        fr_launch(c, WMBUS_ALGO_T2A, 0xFFFFFFFFu);                 /* the clock kernel's first pass */
+        if (c->fused) {
+            /* Without the DC remover the slicer words are final after the clock kernel's FIRST pass, so the run-length
+             * framer (main pass, then its own re-run lists) rides in the launches that carry the clock re-run lanes. */
+            for (unsigned r = 0; r < (opt_rounds ? (unsigned)WM_FR_ROUNDS : 1u); r++) {     /* round 0 carries the run-length framer's main pass */
+                fr_verify(c, WMBUS_ALGO_T2A, SC_CLK + r);
+                if (r) fr_verify(c, WMBUS_ALGO_RLA, SC_RLA + r);
+                fr_launch_fused(c, SC_CLK + r, r ? SC_RLA + r : 0xFFFFFFFFu);
             }
+            HIPCHK(c, hipEventRecord(c->ev[8], c->stream));
+        } else {
+            for (unsigned r = 0; r < WM_FR_ROUNDS && opt_rounds; r++) { fr_verify(c, WMBUS_ALGO_T2A, SC_CLK + r); fr_launch(c, WMBUS_ALGO_T2A, SC_CLK + r); }
+            HIPCHK(c, hipEventRecord(c->ev[8], c->stream));
+            if (rla) {
+                fr_launch(c, WMBUS_ALGO_RLA, 0xFFFFFFFFu);
+                for (unsigned r = 1; r < WM_FR_ROUNDS && opt_rounds; r++) { fr_verify(c, WMBUS_ALGO_RLA, SC_RLA + r); fr_launch(c, WMBUS_ALGO_RLA, SC_RLA + r); }
+            } else HIPCHK(c, hipMemsetAsync(c->d_counts[0], 0, (size_t)2 * c->S * c->nseg_cap[0] * sizeof(uint32_t), c->stream));
         }
+        fr_verify(c, WMBUS_ALGO_T2A, SC_CLK + WM_FR_ROUNDS);
+        if (rla) fr_verify(c, WMBUS_ALGO_RLA, SC_RLA + WM_FR_ROUNDS);
+        HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+        fr_carry(c);
+        c->committed = true;
 
-        /* K3: access-code hits of the settled chip streams, then bursts */
         HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
-        hipLaunchKernelGGL(k_sum_counts, dim3(std::min(64u, (2u * (c->nseg_cap[0] + c->nseg_cap[1]) * c->S + 255u) / 256u)), dim3(256), 0, c->stream, g,
-                           c->d_counts[0], c->d_counts[1], c->d_scalars + SC_CHIPS);
-        hipLaunchKernelGGL(k3_scan, dim3((2u * (g.nseg[0] + g.nseg[1]) * g.S + 255u) / 256u), dim3(256), 0, c->stream, g, c->d_chips[0], c->d_chips[1],
-                           c->d_counts[0], c->d_counts[1], c->d_sync_seen[0], c->d_sync_seen[1], c->d_hits, c->d_scalars + SC_NHITS,
-                           c->hits_cap, c->d_scalars + SC_ERR);
-        HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, SC_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        const uint32_t n_hits = std::min(c->h_scalars[SC_NHITS], c->hits_cap);
-        for (uint32_t s = 0; s < c->S; s++)
-            for (int ch = 0; ch < 2; ch++)
-                for (int al = 0; al < 2; al++)
-                    c->h_pending[(al * 2 + ch) * c->S + s] = c->decs[((size_t)s * 2 + ch) * 2 + al].owed;
-        HIPCHK(c, hipMemcpyAsync(c->d_pending, c->h_pending, 4 * c->S * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-        K3Args k3{};
-        k3.g = g; k3.rssi = c->d_rssi;
-        k3.chips[0] = c->d_chips[0]; k3.chips[1] = c->d_chips[1]; k3.counts[0] = c->d_counts[0]; k3.counts[1] = c->d_counts[1];
-        k3.hits = c->d_hits; k3.n_hits = c->d_scalars + SC_NHITS; k3.hits_cap = c->hits_cap; k3.pending = c->d_pending;
-        k3.hdr = c->d_hdr; k3.hdr_cap = c->hdr_cap; k3.words = c->d_words; k3.words_cap = c->words_cap;
-        k3.n_hdr = c->d_scalars + SC_NHDR; k3.n_words = c->d_scalars + SC_NWORDS; k3.err = c->d_scalars + SC_ERR;
-        {
-            static const uint32_t max_blocks = getenv("WMBUS_K3_BLOCKS") ? (uint32_t)atoi(getenv("WMBUS_K3_BLOCKS")) : 256u;   /* tuning aid; 128 ... 512 are within 2 % of each other */
-            const uint32_t n_items = 4 * c->S + n_hits;
-            hipLaunchKernelGGL(k3_bursts, dim3(std::max(1u, std::min((n_items + 3u) / 4u, max_blocks))), dim3(256), 0, c->stream, k3, n_items);
-        }
+        rc = launch_k3(c);
+        if (rc) return rc;
         HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
         HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, SC_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        const uint32_t err = c->h_scalars[SC_ERR];
-        if (err & WM_ERR_CHIP_OVERFLOW) {            /* a time2 region over its proven bound: a defect, not an input property */
-            c->poisoned = true;
-            return fail(c, WMBUS_EDEVICE, "internal error: time2 chip region overflow (err=%u)", err);
-        }
-        /* storage exhausted (spill arena / burst arena): chips or candidate bursts were dropped; every carried state
-         * is exact, so the stream goes on -- reported, never fatal (the reference never gives up either) */
-        c->tim.warnings = ((err & WM_ERR_CHIP_TRUNC) ? WMBUS_WARN_CHIPS_DROPPED : 0u) | ((err & WM_ERR_BURST_OVERFLOW) ? WMBUS_WARN_BURSTS_DROPPED : 0u);
-        c->n_hdr = c->h_scalars[SC_NHDR]; c->n_words = c->h_scalars[SC_NWORDS];
-        for (int al = 0; al < 2; al++) for (int ch = 0; ch < 2; ch++) c->tim.chips[ch][al] = c->h_scalars[SC_CHIPS + al * 2 + ch];
-        if (c->n_hdr) HIPCHK(c, hipMemcpyAsync(c->h_hdr, c->d_hdr, (size_t)c->n_hdr * sizeof(WmBurstHdr), hipMemcpyDeviceToHost, c->stream));
-        if (c->n_words) HIPCHK(c, hipMemcpyAsync(c->h_words, c->d_words, (size_t)c->n_words * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
+        /* slide the input history: the next push sees the last 4096 staged bytes in front of it */
+        uint8_t *next = c->d_in + (size_t)((c->fill + 1) % c->n_win) * c->S * c->in_stride;
+        hipLaunchKernelGGL(k_roll_history, dim3(c->S), dim3(256), 0, c->stream, win, next, c->in_stride, (uint32_t)nbytes);
+        HIPCHK(c, hipGetLastError());
+    } else {
+        uint8_t *next = c->d_in + (size_t)((c->fill + 1) % c->n_win) * c->S * c->in_stride;
+        hipLaunchKernelGGL(k_roll_history, dim3(c->S), dim3(256), 0, c->stream, win, next, c->in_stride, (uint32_t)nbytes);
+        HIPCHK(c, hipGetLastError());
     }
-    /* slide the input history: the next push sees the last 4096 staged bytes in front of it */
-    hipLaunchKernelGGL(k_roll_history, dim3(c->S), dim3(256), 0, c->stream, c->d_in, c->in_stride, (uint32_t)nbytes);
-    HIPCHK(c, hipGetLastError());
+    c->fill = (c->fill + 1) % c->n_win;
     c->n0 += n_new;
     c->in_flight = true;
     return WMBUS_OK;
 }
 
-/* Run the persistent packet decoders of the (stream, chain, framer) groups in order[lo, hi). */
-static void decode_stream_range(wmbus_ctx *c, const std::vector<uint32_t> &order, size_t lo, size_t hi,
+/* The optimistic rounds of wmbus_process left work: finish it round by round with the host in the loop (rare: a
+ * cascade of hand-off failures longer than the rounds enqueued), then redo what depended on it. */
+static int finish_slowly(wmbus_ctx *c, bool ema_left, bool clk_left, bool rla_left)
+{
+    auto leftovers = [&](uint32_t *n) -> int {
+        HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, SC_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        *n = c->h_scalars[SC_SLOW];
+        return 0;
+    };
+    const uint32_t max_rounds = std::max({c->ntiles, c->last.nseg[0], c->last.nseg[1]}) + 4;
+    if (ema_left) {
+        uint32_t cnt = SC_EMA + WM_EMA_ROUNDS, n = 0;          /* the list of the last verify is still in d_list */
+        for (uint32_t round = 0;; round++) {
+            c->tim.ema_retries += c->h_scalars[cnt];
+            int rc = ema_repair(c, cnt);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_copy_word, dim3(1), dim3(1), 0, c->stream, c->d_scalars + SC_SLOW, 0u);    /* after the repair has read it */
+            ema_verify(c, SC_SLOW);
+            if ((rc = leftovers(&n))) return rc;
+            if (n == 0) break;
+            if (round > max_rounds) return fail(c, WMBUS_EDEVICE, "RSSI filter hand-off repair did not converge");
+            cnt = SC_SLOW;
+        }
+        ema_commit(c);
+    }
+    for (int algo = 1; algo >= 0; algo--) {                    /* clock first: with -o the slicer words depend on it */
+        if (!(algo ? clk_left : rla_left)) continue;
+        uint32_t cnt = (algo ? SC_CLK : SC_RLA) + WM_FR_ROUNDS, n = 0;
+        for (uint32_t round = 0;; round++) {
+            (algo ? c->tim.clock_reruns : c->tim.rla_reruns) += c->h_scalars[cnt];
+            fr_launch(c, algo, cnt);
+            hipLaunchKernelGGL(k_copy_word, dim3(1), dim3(1), 0, c->stream, c->d_scalars + SC_SLOW, 0u);
+            fr_verify(c, algo, SC_SLOW);
+            int rc = leftovers(&n);
+            if (rc) return rc;
+            if (n == 0) break;
+            if (round > max_rounds) return fail(c, WMBUS_EDEVICE, "segment verification did not converge");
+            cnt = SC_SLOW;
+        }
+        if (algo == 1 && (c->flags & WM_F_DC) && (c->flags & WM_F_RLA)) {
+            /* the run-length framer ran on slicer words that the clock re-runs have just replaced: all of it again */
+            fr_launch(c, WMBUS_ALGO_RLA, 0xFFFFFFFFu);
+            hipLaunchKernelGGL(k_copy_word, dim3(1), dim3(1), 0, c->stream, c->d_scalars + SC_RLA + WM_FR_ROUNDS, 0u);
+            fr_verify(c, WMBUS_ALGO_RLA, SC_RLA + WM_FR_ROUNDS);
+            HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, SC_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            rla_left = c->h_scalars[SC_RLA + WM_FR_ROUNDS] != 0;
+        }
+    }
+    fr_carry(c);
+    int rc = launch_k3(c);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, SC_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+namespace {
+struct Entry { uint32_t idx; uint8_t raw; };          /* one candidate telegram of a push: a WmPkt (decoded on the GPU) or a WmBurstHdr (chips) */
+struct EntryKey { uint32_t stream, chip0; uint8_t chain, algo, cont; };
+}
+
+static EntryKey entry_key(const wmbus_ctx *c, const Entry &e)
+{
+    if (e.raw) { const WmBurstHdr &h = c->h_hdr[e.idx]; return EntryKey{h.stream, h.chip0, h.chain, h.algo, (uint8_t)(h.flags & 1u)}; }
+    const WmPkt &p = c->h_pkts[e.idx];
+    return EntryKey{p.stream, p.chip0, p.chain, p.algo, 0};
+}
+
+/* Candidate telegrams of the (stream, chain, framer) groups in order[lo, hi), each group in chip order: what the
+ * reference's decoder would do with them -- an access code that passes while the decoder is busy is ignored
+ * (t1_c1_packet_decoder.h:272-278), a telegram the GPU has assembled is stripped and formatted, a burst cut by the end
+ * of the push goes chip by chip through the persistent host decoder. */
+static void decode_stream_range(wmbus_ctx *c, const std::vector<Entry> &order, size_t lo, size_t hi,
                                 std::vector<LineRec> &out, const char *ts_fixed)
 {
     char line[1024], ts[64];
+    uint8_t pkt[WM_PKT_MAXBYTES + 4];
     uint32_t seq = 0;
     size_t i = lo;
     while (i < hi) {
-        const WmBurstHdr &h0 = c->h_hdr[order[i]];
-        HostDecoder &hd = c->decs[((size_t)h0.stream * 2 + h0.chain) * 2 + h0.algo];
-        const char *tag = c->cfg.show_algorithm ? (h0.algo == WMBUS_ALGO_RLA ? "rla;" : "t2a;") : "";
+        const EntryKey k0 = entry_key(c, order[i]);
+        HostDecoder &hd = c->decs[((size_t)k0.stream * 2 + k0.chain) * 2 + k0.algo];
+        const char *tag = c->cfg.show_algorithm ? (k0.algo == WMBUS_ALGO_RLA ? "rla;" : "t2a;") : "";
         uint64_t next_free = 0;                         /* first chip the decoder has not consumed */
-        bool cut = false;
         size_t j = i;
         for (; j < hi; j++) {
-            const WmBurstHdr &h = c->h_hdr[order[j]];
-            if (h.stream != h0.stream || h.chain != h0.chain || h.algo != h0.algo) break;
+            const EntryKey kj = entry_key(c, order[j]);
+            if (kj.stream != k0.stream || kj.chain != k0.chain || kj.algo != k0.algo) break;
+            if (!order[j].raw) {
+                /* ---- the whole burst was inside the push: the GPU has run the decoder over it ---- */
+                const WmPkt &p = c->h_pkts[order[j].idx];
+                if (hd.owed != 0 || p.chip0 < next_free) continue;     /* the access code passed while the decoder was busy */
+                next_free = (uint64_t)p.chip0 + p.consumed;
+                if (p.status != WM_PKT_DONE) continue;
+                const unsigned nb = std::min<unsigned>(std::max<unsigned>(p.L, 2u), WM_PKT_MAXBYTES);
+                memcpy(pkt, c->h_bytes + p.off, nb);
+                if (ts_fixed) snprintf(ts, sizeof ts, "%s", ts_fixed); else wm_timestamp(ts, sizeof ts);
+                const int ok = (p.flags & WM_PKTF_CRC_OK) != 0;
+                const size_t n = wm_packet_format(p.chain ? WM_MODE_S1 : WM_MODE_T1C1, (p.flags & WM_PKTF_C1) != 0, (p.flags & WM_PKTF_FRAME_B) != 0,
+                                                  (p.flags & WM_PKTF_ERR3OF6) != 0, ok, p.L, pkt, p.pkt_rssi, p.rssi_now, tag, ts, line, sizeof line);
+                LineRec r; r.sample = p.sample; r.stream = p.stream; r.chain = p.chain; r.algo = p.algo;
+                r.crc_ok = (uint8_t)ok; r.seq = seq++; r.text.assign(line, n);
+                out.push_back(std::move(r));
+                continue;
+            }
+            const WmBurstHdr &h = c->h_hdr[order[j].idx];
             const bool cont = h.flags & 1u;
-            if (cont ? hd.owed == 0 : h.chip0 < next_free) continue;   /* the access code passed while the decoder was busy */
+            if (cont ? hd.owed == 0 : (hd.owed != 0 || h.chip0 < next_free)) continue;   /* the access code passed while the decoder was busy */
             const uint32_t *w = c->h_words + h.word_off;
             int st = cont ? WM_DEC_RECEIVING : WM_DEC_IDLE;
             uint32_t k = 0;
@@ -734,10 +900,10 @@ static void decode_stream_range(wmbus_ctx *c, const std::vector<uint32_t> &order
                 if (st == WM_DEC_IDLE) { k++; break; }
             }
             next_free = (uint64_t)h.chip0 + k;
-            cut = st == WM_DEC_RECEIVING;
+            const bool cut = st == WM_DEC_RECEIVING;
             if (cut && h.n_chips != h.avail) {                 /* device under-estimated the burst: a bug */
                 uint32_t none = 0;
-                c->short_burst.compare_exchange_strong(none, 1u + order[j]);
+                c->short_burst.compare_exchange_strong(none, 1u + order[j].idx);
             }
             hd.owed = cut ? std::max(1u, wm_decoder_chips_owed(&hd.dec)) : 0u;
         }
@@ -756,28 +922,46 @@ int wmbus_collect(wmbus_ctx *c)
     if (c->last.M > 0) {
         float ms = 0;
         hipEventElapsedTime(&ms, c->ev[3], c->ev[4]); c->tim.demod_ms = ms;
+        hipEventElapsedTime(&ms, c->ev[2], c->ev[3]); c->tim.turn_wait_ms = ms;  /* on the GPU: behind the other contexts' demodulation kernels */
+        hipEventElapsedTime(&ms, c->ev[0], c->ev[8]); c->tim.clock_ms = ms;      /* fused: every framer launch; else the clock kernel's */
+        hipEventElapsedTime(&ms, c->ev[8], c->ev[1]); c->tim.rla_ms = ms;        /* un-fused: the run-length framer's launches */
         hipEventElapsedTime(&ms, c->ev[5], c->ev[6]); c->tim.gather_ms = ms;
         hipEventElapsedTime(&ms, c->ev[6], c->ev[7]); c->tim.d2h_ms = ms;
         hipEventElapsedTime(&ms, c->ev[2], c->ev[7]); c->tim.gpu_total_ms = ms;
+        const uint32_t *hs = c->h_scalars;
+        for (unsigned r = 0; r < WM_EMA_ROUNDS; r++) c->tim.ema_retries += hs[SC_EMA + r];
+        for (unsigned r = 0; r < WM_FR_ROUNDS; r++) { c->tim.clock_reruns += hs[SC_CLK + r]; c->tim.rla_reruns += hs[SC_RLA + r]; }
+        const bool ema_left = hs[SC_EMA + WM_EMA_ROUNDS], clk_left = hs[SC_CLK + WM_FR_ROUNDS], rla_left = hs[SC_RLA + WM_FR_ROUNDS];
+        if (ema_left || clk_left || rla_left) {
+            const int rc = finish_slowly(c, ema_left, clk_left, rla_left);
+            if (rc) { c->poisoned = true; return rc; }
+            c->tim.slow_path = 1;
+        }
+        const uint32_t err = hs[SC_ERR];
+        if (err & WM_ERR_CHIP_OVERFLOW) {            /* a time2 region over its proven bound: a defect, not an input property */
+            c->poisoned = true;
+            return fail(c, WMBUS_EDEVICE, "internal error: time2 chip region overflow (err=%u)", err);
+        }
+        /* storage exhausted (spill arena / burst arena): chips or candidate bursts were dropped; every carried state
+         * is exact, so the stream goes on -- reported, never fatal (the reference never gives up either) */
+        c->tim.warnings = ((err & WM_ERR_CHIP_TRUNC) ? WMBUS_WARN_CHIPS_DROPPED : 0u) | ((err & WM_ERR_BURST_OVERFLOW) ? WMBUS_WARN_BURSTS_DROPPED : 0u);
+        c->n_hdr = std::min(hs[SC_NHDR], c->hdr_cap); c->n_words = hs[SC_NWORDS]; c->n_pkts = std::min(hs[SC_NPKTS], c->pkts_cap);
+        for (int al = 0; al < 2; al++) for (int ch = 0; ch < 2; ch++) c->tim.chips[ch][al] = hs[SC_CHIPS + al * 2 + ch];
     }
-    c->tim.bursts = c->n_hdr;
+    c->tim.bursts = c->n_hdr + c->n_pkts;
     const double t0 = now_ms();
 
-    std::vector<uint32_t> order(c->n_hdr);
-    for (uint32_t i = 0; i < c->n_hdr; i++) order[i] = i;
-    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-        const WmBurstHdr &a = c->h_hdr[x], &b = c->h_hdr[y];
+    std::vector<Entry> order(c->n_hdr + c->n_pkts);
+    for (uint32_t i = 0; i < c->n_hdr; i++) order[i] = Entry{i, 1};
+    for (uint32_t i = 0; i < c->n_pkts; i++) order[c->n_hdr + i] = Entry{i, 0};
+    std::sort(order.begin(), order.end(), [&](const Entry &x, const Entry &y) {
+        const EntryKey a = entry_key(c, x), b = entry_key(c, y);
         if (a.stream != b.stream) return a.stream < b.stream;
         if (a.chain != b.chain) return a.chain < b.chain;
         if (a.algo != b.algo) return a.algo < b.algo;
-        if ((a.flags & 1u) != (b.flags & 1u)) return (a.flags & 1u) > (b.flags & 1u);   /* continuation first */
+        if (a.cont != b.cont) return a.cont > b.cont;                                   /* continuation first */
         return a.chip0 < b.chip0;
     });
-    /* drop exact duplicates (a re-run segment may have re-recorded a hit) */
-    order.erase(std::unique(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-        const WmBurstHdr &a = c->h_hdr[x], &b = c->h_hdr[y];
-        return a.stream == b.stream && a.chain == b.chain && a.algo == b.algo && a.flags == b.flags && a.chip0 == b.chip0;
-    }), order.end());
     unsigned nt = c->cfg.host_threads ? c->cfg.host_threads : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     if (order.size() < 4096) nt = 1;
     const char *tsf = c->cfg.fixed_timestamp ? "TS" : nullptr;
@@ -790,7 +974,7 @@ int wmbus_collect(wmbus_ctx *c)
         cut[0] = 0;
         for (unsigned t = 1; t < np; t++) {
             size_t p = order.size() * t / np;
-            while (p < order.size() && p > 0 && c->h_hdr[order[p]].stream == c->h_hdr[order[p - 1]].stream) p++;
+            while (p < order.size() && p > 0 && entry_key(c, order[p]).stream == entry_key(c, order[p - 1]).stream) p++;
             cut[t] = std::max(p, cut[t - 1]);
         }
         if (!c->pool || c->pool->size() + 1 != nt) c->pool.reset(new WorkerPool(nt - 1));

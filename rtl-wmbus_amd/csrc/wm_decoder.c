@@ -231,28 +231,39 @@ static unsigned strip_crc(uint8_t *p, unsigned n, int frame_b)
     return out;
 }
 
-size_t wm_decoder_format(wm_decoder *d, const char *algo_tag, const char *timestamp,
-                         unsigned rssi_now, char *out, size_t cap, int *crc_ok)
+int wm_packet_crc_ok(const uint8_t *packet, unsigned L, int frame_b)
 {
-    const int fb = d->frame_b;
-    const int ok = fb ? crc_ok_blocks(d->packet, d->L, 128u, 128u) : crc_ok_blocks(d->packet, d->L, 12u, 18u);
-    if (crc_ok) *crc_ok = ok;
-    const uint32_t ident = (uint32_t)d->packet[4] | ((uint32_t)d->packet[5] << 8) |
-                           ((uint32_t)d->packet[6] << 16) | ((uint32_t)d->packet[7] << 24);
-    const char *mode = d->mode == WM_MODE_S1 ? "S1" : d->c1 ? "C1" : "T1";
-    const unsigned ok3 = d->mode == WM_MODE_S1 ? 1u : (unsigned)(d->err3of6 ^ 1u);
-    int n = snprintf(out, cap, "%s%s;%u;%u;%s;%u;%u;%08X;0x", algo_tag ? algo_tag : "", mode, (unsigned)ok, ok3,
-                     timestamp, (unsigned)d->pkt_rssi, rssi_now, (unsigned)ident);
+    return frame_b ? crc_ok_blocks(packet, L, 128u, 128u) : crc_ok_blocks(packet, L, 12u, 18u);
+}
+
+size_t wm_packet_format(int mode, int c1, int frame_b, int err3of6, int crc_ok, unsigned L, uint8_t *packet, unsigned pkt_rssi,
+                        unsigned rssi_now, const char *algo_tag, const char *timestamp, char *out, size_t cap)
+{
+    const uint32_t ident = (uint32_t)packet[4] | ((uint32_t)packet[5] << 8) | ((uint32_t)packet[6] << 16) | ((uint32_t)packet[7] << 24);
+    const char *mname = mode == WM_MODE_S1 ? "S1" : c1 ? "C1" : "T1";
+    const unsigned ok3 = mode == WM_MODE_S1 ? 1u : (unsigned)(err3of6 ^ 1);
+    int n = snprintf(out, cap, "%s%s;%u;%u;%s;%u;%u;%08X;0x", algo_tag ? algo_tag : "", mname, (unsigned)crc_ok, ok3,
+                     timestamp, pkt_rssi, rssi_now, (unsigned)ident);
     if (n < 0 || (size_t)n >= cap) n = 0;
     size_t w = (size_t)n;
-    const unsigned len = strip_crc(d->packet, d->L, fb);
+    const unsigned len = strip_crc(packet, L, frame_b);
     static const char hexd[] = "0123456789abcdef";
     for (unsigned k = 0; k < len && w + 3 < cap; k++) {
-        out[w++] = hexd[d->packet[k] >> 4];
-        out[w++] = hexd[d->packet[k] & 15u];
+        out[w++] = hexd[packet[k] >> 4];
+        out[w++] = hexd[packet[k] & 15u];
     }
     if (w + 1 < cap) out[w++] = '\n';
     out[w] = 0;
+    return w;
+}
+
+size_t wm_decoder_format(wm_decoder *d, const char *algo_tag, const char *timestamp,
+                         unsigned rssi_now, char *out, size_t cap, int *crc_ok)
+{
+    const int ok = wm_packet_crc_ok(d->packet, d->L, d->frame_b);
+    if (crc_ok) *crc_ok = ok;
+    const size_t w = wm_packet_format(d->mode, d->c1, d->frame_b, d->err3of6, ok, d->L, d->packet, d->pkt_rssi, rssi_now,
+                                      algo_tag, timestamp, out, cap);
     d->step = 0;
     return w;
 }

@@ -51,6 +51,15 @@ unsigned wm_decoder_chips_owed(const wm_decoder *d);
 size_t wm_decoder_format(wm_decoder *d, const char *algo_tag, const char *timestamp,
                          unsigned rssi_now, char *out, size_t cap, int *crc_ok);
 
+/* The same line from a telegram that arrives already assembled (the GPU's k3_bursts decodes complete bursts: 3-out-of-6
+ * / NRZ / Manchester symbols, CRC verdict): packet[0 .. stored bytes) with its CRC bytes, L = expected length with CRC
+ * bytes (what the decoder's d->L holds).  Strips the CRC bytes in place and formats (t1_c1_packet_decoder.h:551-636,
+ * 671-699). */
+size_t wm_packet_format(int mode, int c1, int frame_b, int err3of6, int crc_ok, unsigned L, uint8_t *packet, unsigned pkt_rssi,
+                        unsigned rssi_now, const char *algo_tag, const char *timestamp, char *out, size_t cap);
+/* CRC verdict of an assembled telegram (t1_c1_packet_decoder.h:471-536). */
+int wm_packet_crc_ok(const uint8_t *packet, unsigned L, int frame_b);
+
 /* Wall-clock timestamp in the reference's format (rtl_wmbus_util.h:10-39). */
 void wm_timestamp(char *dst, size_t cap);
 

@@ -128,4 +128,23 @@ struct WmBurstHdr {
 };
 /* burst chip word: [31:11] sample delta from pos0, [10:3] rssi, [2:0] value */
 
+/* A burst that lies entirely inside the push is decoded on the GPU (k3_bursts): the host gets the assembled telegram
+ * instead of its chips.  `consumed` = chips the reference's decoder takes from the access-code chip on (that chip
+ * included) before it is idle again -- the host needs it to skip access codes that pass meanwhile. */
+struct WmPkt {
+    uint32_t stream;
+    uint8_t  chain, algo;
+    uint8_t  status;         /* WM_PKT_DONE: telegram assembled; WM_PKT_ABORT: the decoder gave up after `consumed` chips */
+    uint8_t  flags;          /* WM_PKTF_* */
+    uint32_t chip0;          /* index of the access-code chip in this push's chip stream */
+    uint32_t consumed;
+    uint64_t sample;         /* global decimated index of the completing chip (DONE)     */
+    uint32_t off;            /* byte offset of the telegram in the byte arena            */
+    uint16_t L;              /* expected length with CRC bytes (the decoder's L)         */
+    uint8_t  pkt_rssi, rssi_now;
+};
+enum { WM_PKT_DONE = 1, WM_PKT_ABORT = 2 };
+enum { WM_PKTF_C1 = 1, WM_PKTF_FRAME_B = 2, WM_PKTF_ERR3OF6 = 4, WM_PKTF_CRC_OK = 8 };
+#define WM_PKT_MAXBYTES 292u
+
 #endif

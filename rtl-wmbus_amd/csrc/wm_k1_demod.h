@@ -40,6 +40,7 @@ struct K1Args {
      * the tile's EMA is then run sequentially from its predecessor's exact tail */
     const uint32_t *relist;
     const float *ema_carry;  /* [2][S] exact EMA carried in from the previous push */
+    const uint32_t *n_relist;/* repair launches: entries in `relist` (on the device: k1_collect has just written it) */
 };
 
 /* =============================================================================================
@@ -253,8 +254,8 @@ __device__ __forceinline__ void k1_stage_b(const K1Args &a, const int tid, const
 /* GEN = false: the kernel of the DEFAULT switches (both chains, cargf arctangent, first pass): the switch tests, the
  * -a / -A / -p paths and the RSSI repair walk are not compiled in, so the default path carries no cost for the options
  * (any other configuration, and every repair launch, runs the GEN = true kernel: same arithmetic, same results). */
-template <int D, bool SHIFT, bool GEN = true>
-__global__ __launch_bounds__(256) void k1_demod2(K1Args a)
+template <int D, bool SHIFT, bool GEN>
+__device__ __forceinline__ void k1_tile(const K1Args &a, const int tile, const int stream)
 {
     using G = K1Geo;
     constexpr int T = G::T, NA = G::NA, YD = G::YD, YM = G::YM;
@@ -269,9 +270,6 @@ __global__ __launch_bounds__(256) void k1_demod2(K1Args a)
     float *sFin = yDrS + YD, *sHead = sFin + 128, *tab = sHead + 128;
 
     const int tid = threadIdx.x;
-    const bool listed = GEN && a.relist != nullptr;
-    const int tile = listed ? (int)(a.relist[blockIdx.x] % a.ntiles) : (int)blockIdx.x;
-    const int stream = listed ? (int)(a.relist[blockIdx.x] / a.ntiles) : (int)blockIdx.y;
     const int ts = tile * T;
     const int tn = min(T, (int)g.M - ts);
     const bool chT = !GEN || (g.flags & WM_F_T1C1), chS = !GEN || (g.flags & WM_F_S1);
@@ -395,6 +393,18 @@ __global__ __launch_bounds__(256) void k1_demod2(K1Args a)
     k1_stage_b<GEN>(a, tid, tile, stream, ts, tn, chT, chS, yDrT, yDrS, yMgT, yMgS, sFin, sHead);
 }
 
+template <int D, bool SHIFT, bool GEN = true>
+__global__ __launch_bounds__(256) void k1_demod2(K1Args a)
+{
+    if (!GEN || a.relist == nullptr) { k1_tile<D, SHIFT, GEN>(a, (int)blockIdx.x, (int)blockIdx.y); return; }
+    /* repair launch: a fixed grid walks the list k1_collect has just written (no host round trip in between) */
+    const uint32_t n = *a.n_relist;
+    for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
+        k1_tile<D, SHIFT, GEN>(a, (int)(a.relist[e] % a.ntiles), (int)(a.relist[e] / a.ntiles));
+        __syncthreads();                                      /* the tile's LDS is reused by the next entry */
+    }
+}
+
 /* =============================================================================================
  * K1 with the POLYPHASE pre-filter: ppf.h:46-59 driven as the reference's
  * lp_ppf_butter_1600kHz_160kHz_200kHz does (rtl_wmbus.c:258-294): even input samples through the
@@ -419,7 +429,7 @@ struct K1PpfGeo {
     static constexpr size_t smem() { return (size_t)(NSTG + YD + 256) * 4; }
 };
 
-__global__ __launch_bounds__(256) void k1_demod_ppf(K1Args a)
+__device__ __forceinline__ void k1_tile_ppf(const K1Args &a, const int tile, const int stream)
 {
     using G = K1PpfGeo;
     constexpr int T = G::T, NA = G::NA;
@@ -431,8 +441,6 @@ __global__ __launch_bounds__(256) void k1_demod_ppf(K1Args a)
 
     const WmPush &g = a.g;
     const int tid = threadIdx.x;
-    const int tile = a.relist ? (int)(a.relist[blockIdx.x] % a.ntiles) : (int)blockIdx.x;
-    const int stream = a.relist ? (int)(a.relist[blockIdx.x] / a.ntiles) : (int)blockIdx.y;
     const int ts = tile * T;
     const int tn = min(T, (int)g.M - ts);
     const bool chT = g.flags & WM_F_T1C1, chS = g.flags & WM_F_S1;
@@ -502,6 +510,16 @@ __global__ __launch_bounds__(256) void k1_demod_ppf(K1Args a)
         for (int j = 0; j < 4; j++) yMg[qb + j] = mg[j];
     }
     k1_stage_b<true>(a, tid, tile, stream, ts, tn, chT, chS, yDr, yDr, yMg, yMg, sFin, sHead);
+}
+
+__global__ __launch_bounds__(256) void k1_demod_ppf(K1Args a)
+{
+    if (a.relist == nullptr) { k1_tile_ppf(a, (int)blockIdx.x, (int)blockIdx.y); return; }
+    const uint32_t n = *a.n_relist;
+    for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
+        k1_tile_ppf(a, (int)(a.relist[e] % a.ntiles), (int)(a.relist[e] / a.ntiles));
+        __syncthreads();
+    }
 }
 
 /* head[tile] must equal tail[tile-1] (or the value carried from the previous push).  One thread

@@ -191,7 +191,7 @@ __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t bloc
     const bool rerun = a.list != nullptr;
     const WmPush &g = a.g;
     const bool coop = !rerun && (g.S % 64u) == 0u;         /* wave = 64 consecutive streams, lock step */
-    if (lane >= a.n_lanes) return;
+    if (lane >= k2_lane_count(a)) return;
     if (rerun) lane = a.list[lane];
     uint32_t ch, stream, seg;
     lane_decode(g, 1, lane, ch, stream, seg);
@@ -425,7 +425,8 @@ template <bool DC>
 __global__ __launch_bounds__(64 * WM_CLK_WPB) void k2_clock(K2Args a)
 {
     __shared__ __attribute__((aligned(16))) ClkLds<WM_CLK_WPB> lds;
-    clock_lanes<DC, WM_CLK_WPB>(a, blockIdx.x, lds);
+    const uint32_t n = k2_lane_count(a);                  /* a list launch has a fixed grid: its blocks walk the list */
+    for (uint32_t b = blockIdx.x; (uint64_t)b * (64u * WM_CLK_WPB) < n; b += gridDim.x) clock_lanes<DC, WM_CLK_WPB>(a, b, lds);
 }
 
 #endif /* WM_K2_CLOCK_H */

@@ -18,6 +18,8 @@ struct K2Args {
     void *st_carry;            /* [2][S] exact state carried from the previous push         */
     const uint32_t *list;      /* re-run list of lane ids, or nullptr                       */
     uint32_t n_lanes;
+    const uint32_t *n_ptr;     /* if set: the lane count lives on the device (a re-run list k2_verify has just written;
+                                  the launch then has a fixed grid whose blocks walk the list) */
     uint32_t algo;             /* WMBUS_ALGO_* of this launch                              */
     uint32_t *err;
     uint32_t *sync_seen;       /* [2][S][nseg_cap]: set when a pass emitted an access-code chip into the region */
@@ -26,6 +28,8 @@ struct K2Args {
      * speculative pass had already been on the exact trajectory. */
     uint32_t *ckpt; uint32_t nck;
 };
+
+__device__ __forceinline__ uint32_t k2_lane_count(const K2Args &a) { return a.n_ptr ? *a.n_ptr : a.n_lanes; }
 
 __device__ __forceinline__ void lane_decode(const WmPush &g, uint32_t algo, uint32_t lane, uint32_t &ch, uint32_t &stream, uint32_t &seg)
 {

@@ -62,7 +62,7 @@ __device__ __forceinline__ void rla_lanes(const K2Args &a, const uint32_t block_
 {
     uint32_t *s_chip = lds.chip;
     uint32_t lane = block_id * (64 * WM_RLA_WPB) + threadIdx.x;
-    if (lane >= a.n_lanes) return;
+    if (lane >= k2_lane_count(a)) return;
     const bool rerun = a.list != nullptr;
     if (rerun) lane = a.list[lane];
     const WmPush &g = a.g;
@@ -232,7 +232,8 @@ __device__ __forceinline__ void rla_lanes(const K2Args &a, const uint32_t block_
 __global__ __launch_bounds__(64 * WM_RLA_WPB) void k2_rla(K2Args a)
 {
     __shared__ RlaLds lds;
-    rla_lanes(a, blockIdx.x, lds);
+    const uint32_t n = k2_lane_count(a);
+    for (uint32_t b = blockIdx.x; (uint64_t)b * (64u * WM_RLA_WPB) < n; b += gridDim.x) rla_lanes(a, b, lds);
 }
 
 #endif /* WM_K2_RLA_H */

@@ -13,9 +13,12 @@ struct K3Args {
     const uint32_t *counts[2];   /* per algo: [2][S][nseg_cap]                               */
     const uint2 *hits; const uint32_t *n_hits; uint32_t hits_cap;
     const uint32_t *pending;     /* [2 algo][2 chain][S]: chips still owed to a busy decoder  */
-    WmBurstHdr *hdr; uint32_t hdr_cap;
+    WmBurstHdr *hdr; uint32_t hdr_cap;     /* bursts that go to the host decoders as chips: cut by the end of the push, or continuing */
     uint32_t *words; uint32_t words_cap;
     uint32_t *n_hdr, *n_words;
+    WmPkt *pkts; uint32_t pkts_cap;        /* bursts decoded here (nullptr: every burst goes to the host as chips) */
+    uint8_t *bytes; uint32_t bytes_cap;
+    uint32_t *n_pkts, *n_bytes;
     uint32_t *err;
 };
 
@@ -25,34 +28,55 @@ __device__ static const uint8_t D3OF6[64] = {
 
 __device__ __forceinline__ uint32_t full_len_a(uint32_t L) { return 1u + L + 2u * (1u + (L > 9u ? (L - 9u + 15u) / 16u : 0u)); }
 
-/* Chips after the access-code chip that a decoder consumes before it returns to idle, ignoring
- * RSSI aborts and framer resets (those only shorten it).  hb = the next 24 chips, first chip in
- * bit 23; nb = how many of them exist.  Mirrors the length logic of
- * t1_c1_packet_decoder.h:298-349,399-438 and s1_packet_decoder.h:152-197. */
-__device__ uint32_t burst_need(uint32_t chain, uint32_t hb, uint32_t nb)
+/* What a decoder does after an access code, read off the next 24 chips (hb: first chip in bit 23; nb: how many of
+ * them exist), ignoring RSSI aborts, framer resets and Manchester errors in the data (those only shorten it):
+ * `need` chips after the access-code chip, then either the telegram is complete (`done`) or the decoder has given up.
+ * Mirrors the length logic of t1_c1_packet_decoder.h:298-349,399-438 and s1_packet_decoder.h:152-197. */
+struct WmPlan {
+    uint32_t need;
+    uint8_t done;            /* 1: `need` chips complete a telegram; 0: they end in an abort (or the length is not known yet) */
+    uint8_t mode;            /* 0 T1 (3-out-of-6), 1 C1 (NRZ), 2 S1 (Manchester) */
+    uint8_t frame_b;
+    uint16_t L;              /* expected length with CRC bytes (the decoder's L) */
+    uint16_t nbytes;         /* bytes the decoder stores, L-field included */
+};
+
+__device__ WmPlan burst_plan(uint32_t chain, uint32_t hb, uint32_t nb)
 {
+    WmPlan p = {};
     if (chain == 0) {
-        if (nb < 12) return WM_MAXCHIPS_T1C1;
+        p.need = WM_MAXCHIPS_T1C1;
+        if (nb < 12) return p;
         const uint32_t hi = D3OF6[(hb >> 18) & 63u], lo = D3OF6[(hb >> 12) & 63u];
-        if (hi != 255u && lo != 255u) return 12u * full_len_a((hi << 4) | lo);
+        if (hi != 255u && lo != 255u) {
+            p.L = (uint16_t)full_len_a((hi << 4) | lo); p.nbytes = p.L; p.need = 12u * p.L; p.done = 1;
+            return p;
+        }
         const uint32_t mode = hb >> 12;
-        if (mode != 0x54Cu && mode != 0x543u) return 12u;
-        if (nb < 24) return WM_MAXCHIPS_T1C1;
-        if (((hb >> 8) & 15u) != 0xDu) return 16u;
-        const uint32_t L = hb & 255u, total = mode == 0x543u ? 1u + L : full_len_a(L);
+        if (mode != 0x54Cu && mode != 0x543u) { p.need = 12u; return p; }
+        p.mode = 1; p.frame_b = mode == 0x543u;
+        if (nb < 24) return p;
+        if (((hb >> 8) & 15u) != 0xDu) { p.need = 16u; return p; }
+        const uint32_t L = hb & 255u, total = p.frame_b ? 1u + L : full_len_a(L);
         /* the decoder looks at the length only after storing a byte: a frame B that claims L = 0 still
          * takes one byte after its L-field (found by tests/test_burst_need.py) */
-        return 24u + 8u * (total > 2u ? total - 1u : 1u);
+        p.L = (uint16_t)total; p.nbytes = (uint16_t)(total > 2u ? total : 2u);
+        p.need = 24u + 8u * (p.nbytes - 1u); p.done = 1;
+        return p;
     }
-    if (nb < 16) return WM_MAXCHIPS_S1;
+    p.mode = 2; p.need = WM_MAXCHIPS_S1;
+    if (nb < 16) return p;
     uint32_t L = 0;
     for (int j = 0; j < 8; j++) {
         const uint32_t pair = (hb >> (22 - 2 * j)) & 3u;
-        if (pair == 0u || pair == 3u) return 2u * (uint32_t)j + 2u;
+        if (pair == 0u || pair == 3u) { p.need = 2u * (uint32_t)j + 2u; return p; }
         L = (L << 1) | (pair == 1u ? 1u : 0u);
     }
-    return 16u * full_len_a(L);
+    p.L = (uint16_t)full_len_a(L); p.nbytes = p.L; p.need = 16u * p.L; p.done = 1;
+    return p;
 }
+
+__device__ uint32_t burst_need(uint32_t chain, uint32_t hb, uint32_t nb) { return burst_plan(chain, hb, nb).need; }
 
 /* Access-code hits = chips with the sync flag, collected AFTER both framers have settled (re-runs
  * included).  (The framer kernels used to append hits as they went; every re-run then left stale
@@ -105,8 +129,52 @@ __global__ __launch_bounds__(256) void k3_scan(WmPush g, const uint32_t *chips0,
     }
 }
 
-/* One access-code hit (or pending continuation), handled by one wave. */
-__device__ void burst_item(const K3Args &a, const uint32_t item, const uint32_t ln)
+/* Per-wave scratch of k3_bursts: the burst's chips as a bit string (chip j = bit j % 64 of word j / 64) and the
+ * telegram's bytes. */
+#define WM_K3_BITWORDS 76          /* >= (WM_MAXCHIPS_S1 + 1 + 63) / 64 + 1 */
+struct K3Lds { unsigned long long bits[4][WM_K3_BITWORDS]; uint8_t bytes[4][WM_PKT_MAXBYTES + 4]; };
+
+#ifndef WM_WAVE_SYNC
+#define WM_WAVE_SYNC() __builtin_amdgcn_wave_barrier()       /* LDS hand-over inside one wave (DS operations of a wave are in order) */
+#endif
+
+/* `n` chips (n <= 32) of the burst starting at chip j0, first chip in the most significant bit. */
+__device__ __forceinline__ uint32_t k3_field(const unsigned long long *bits, uint32_t j0, uint32_t n)
+{
+    const uint32_t w = j0 >> 6, o = j0 & 63u;
+    unsigned long long v = bits[w] >> o;
+    if (o) v |= bits[w + 1] << (64u - o);
+    return __brev((uint32_t)v) >> (32u - n);
+}
+
+/* EN 13757 CRC-16 of `n` bytes (poly 0x3D65, init 0, complemented), t1_c1_packet_decoder.h:463-469. */
+__device__ __forceinline__ uint32_t k3_crc16(const uint8_t *p, uint32_t n)
+{
+    uint32_t crc = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        crc ^= (uint32_t)p[i] << 8;
+#pragma unroll
+        for (int k = 0; k < 8; k++) crc = (crc & 0x8000u) ? ((crc << 1) ^ 0x3D65u) : (crc << 1);
+        crc &= 0xFFFFu;
+    }
+    return (~crc) & 0xFFFFu;
+}
+
+/* One access-code hit (or pending continuation), handled by one wave.
+ *
+ * A burst that ends inside the push is DECODED here, chip for chip what the reference's state machines do
+ * (t1_c1_packet_decoder.h:649-712, s1_packet_decoder.h:233-282; the host's wm_decoder.c is the same logic and the
+ * tests hold the two against each other): the chips the decoder would take are loaded once (value, framer-reset
+ * marker, RSSI byte), the first chip at which it would stop early is found by a wave-wide minimum --
+ *     the access-code chip itself with RSSI < 5: not armed, 1 chip consumed              (:705-710 gate at idle)
+ *     a framer-reset marker on chip j >= 1: aborted BEFORE chip j, j consumed           (rtl_wmbus.c:636,725)
+ *     RSSI < 5 on a chip that does not complete the telegram: aborted, j + 1 consumed   (:705-710)
+ *     an invalid Manchester pair completed by chip j (S1): j + 1 consumed              (s1_packet_decoder.h:152-168)
+ *     an invalid L-field / mode / trailer: the plan's own end                          (:313-349, 399-415)
+ * -- and if none precedes the last chip, lanes assemble the bytes (3-out-of-6 with the error flag, NRZ, Manchester)
+ * and check the block CRCs.  The host gets {consumed, flags, RSSI pair, completing sample} and the bytes.  A burst
+ * cut by the end of the push, and its continuation in the next one, still travel as chips to the host decoder. */
+__device__ void burst_item(const K3Args &a, const uint32_t item, const uint32_t ln, unsigned long long *s_bits, uint8_t *s_bytes)
 {
     const WmPush &g = a.g;
     const uint32_t n_hits = min(*a.n_hits, a.hits_cap);
@@ -147,6 +215,7 @@ __device__ void burst_item(const K3Args &a, const uint32_t item, const uint32_t 
     };
 
     uint32_t n;
+    WmPlan plan = {};
     if (cont) n = min(want, avail);
     else {
         uint32_t bit = 0;
@@ -154,8 +223,95 @@ __device__ void burst_item(const K3Args &a, const uint32_t item, const uint32_t 
         const unsigned long long m = __ballot(bit);
         uint32_t hb = 0;
         for (int j = 0; j < 24; j++) hb |= (uint32_t)((m >> j) & 1ull) << (23 - j);
-        n = min(burst_need(ch, hb, min(24u, avail - 1u)) + 1u, avail);
+        plan = burst_plan(ch, hb, min(24u, avail - 1u));
+        n = min(plan.need + 1u, avail);
     }
+
+    if (!cont && a.pkts != nullptr && plan.need + 1u <= avail) {
+        /* ---- the whole burst is here: decode it -------------------------------------------------- */
+        uint32_t ev = n;                         /* chips consumed if nothing stops the decoder early */
+        uint32_t r_first = 0, r_last = 0, pm_last = 0;
+        for (uint32_t j0 = 0; j0 < n; j0 += 64u) {
+            const uint32_t j = j0 + ln;
+            uint32_t w = 0, pm = 0, rs = 255u;
+            if (j < n) {
+                uint32_t sg, kk; locate(j, sg, kk);
+                w = chip(sg, kk);
+                pm = sg * seg_len + WM_CHIP_POS(w);
+                rs = a.rssi[row * g.Mcap + pm];
+                if (j >= 1u && (w & 4u)) ev = min(ev, j);                                  /* framer reset before this chip */
+                else if (rs < 5u && (j == 0u || j + 1u < n || !plan.done)) ev = min(ev, j + 1u);   /* RSSI gate */
+            }
+            const unsigned long long m = __ballot(w & 1u);
+            if (ln == 0) s_bits[j0 >> 6] = m;
+            if (j == 1u) r_first = rs;
+            if (j + 1u == n) { r_last = rs; pm_last = pm; }
+        }
+        if (ln == 0) s_bits[(n + 63u) >> 6] = 0ull;          /* k3_field may look one word ahead */
+        WM_WAVE_SYNC();
+        const uint32_t nb = plan.done ? plan.nbytes : 0u;
+        uint32_t err36 = 0;
+        /* bytes: lane b assembles byte b, b + 64, ... */
+        for (uint32_t b0 = 0; b0 < nb; b0 += 64u) {
+            const uint32_t b = b0 + ln;
+            if (b < nb) {
+                uint32_t v;
+                if (plan.mode == 0u) {
+                    const uint32_t hi = D3OF6[k3_field(s_bits, 1u + 12u * b, 6)], lo = D3OF6[k3_field(s_bits, 7u + 12u * b, 6)];
+                    err36 |= (hi == 255u || lo == 255u);
+                    v = ((hi == 255u ? 255u : hi << 4) | lo) & 255u;
+                } else if (plan.mode == 1u) v = k3_field(s_bits, 17u + 8u * b, 8);
+                else {
+                    const uint32_t sym = k3_field(s_bits, 1u + 16u * b, 16);
+                    v = 0;
+#pragma unroll
+                    for (int q = 7; q >= 0; q--) {           /* pair q: 01 -> 1, 10 -> 0 (s1_packet_decoder.h:35-37) */
+                        const uint32_t pair = (sym >> (2 * q)) & 3u;
+                        if (pair == 0u || pair == 3u) ev = min(ev, 1u + 16u * b + 2u * (7u - (uint32_t)q) + 2u);   /* chip completing the pair, + 1 */
+                        v = (v << 1) | (pair == 1u);
+                    }
+                }
+                s_bytes[b] = (uint8_t)v;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) ev = min(ev, __shfl_xor(ev, off));
+        err36 = __ballot(err36) != 0ull;
+        r_first = __shfl(r_first, 1); r_last = __shfl(r_last, (int)((n - 1u) & 63u)); pm_last = __shfl(pm_last, (int)((n - 1u) & 63u));
+        const bool done = plan.done && ev == n;
+        WM_WAVE_SYNC();
+        /* block CRCs (t1_c1_packet_decoder.h:471-536): frame A 12 bytes then 18s, frame B 128s, the last block may be short */
+        uint32_t crc_bad = 0;
+        if (done) {
+            const uint32_t L = plan.L, first = plan.frame_b ? 128u : 12u, next = plan.frame_b ? 128u : 18u;
+            const uint32_t start = ln == 0 ? 0u : first + (ln - 1u) * next;
+            if (L < 12u) crc_bad = 1;
+            else if (start < L) {
+                const uint32_t blk = min(ln == 0 ? first : next, L - start);
+                crc_bad = blk < 2u || k3_crc16(s_bytes + start, blk - 2u) != (((uint32_t)s_bytes[start + blk - 2u] << 8) | s_bytes[start + blk - 1u]);
+            }
+        }
+        crc_bad = __ballot(crc_bad) != 0ull;
+        uint32_t slot = 0, boff = 0;
+        if (ln == 0) { slot = atomicAdd(a.n_pkts, 1u); boff = done ? atomicAdd(a.n_bytes, (nb + 3u) & ~3u) : 0u; }
+        slot = __shfl(slot, 0); boff = __shfl(boff, 0);
+        if (slot >= a.pkts_cap || (done && boff + nb > a.bytes_cap)) { if (ln == 0) atomicOr(a.err, WM_ERR_BURST_OVERFLOW); return; }
+        if (done) for (uint32_t b = ln; b < nb; b += 64u) a.bytes[boff + b] = s_bytes[b];
+        if (ln == 0) {
+            WmPkt p;
+            p.stream = stream; p.chain = (uint8_t)ch; p.algo = (uint8_t)algo;
+            p.status = done ? WM_PKT_DONE : WM_PKT_ABORT;
+            p.flags = (uint8_t)((plan.mode == 1u ? WM_PKTF_C1 : 0u) | (plan.frame_b ? WM_PKTF_FRAME_B : 0u) | (err36 ? WM_PKTF_ERR3OF6 : 0u) |
+                                (done && !crc_bad ? WM_PKTF_CRC_OK : 0u));
+            p.chip0 = chip0; p.consumed = ev; p.sample = g.m0 + pm_last; p.off = boff; p.L = plan.L;
+            p.pkt_rssi = (uint8_t)r_first; p.rssi_now = (uint8_t)r_last;
+            a.pkts[slot] = p;
+        }
+        WM_WAVE_SYNC();                                      /* the scratch is reused by the wave's next item */
+        return;
+    }
+
+    /* ---- cut by the end of the push, or the rest of such a burst: chips for the host decoder ---- */
     uint32_t hslot = 0, woff = 0;
     if (ln == 0) { hslot = atomicAdd(a.n_hdr, 1u); woff = atomicAdd(a.n_words, n); }
     hslot = __shfl(hslot, 0); woff = __shfl(woff, 0);
@@ -184,10 +340,13 @@ __device__ void burst_item(const K3Args &a, const uint32_t item, const uint32_t 
  * -- 14 000 single-wave blocks per 128 captures, each a chain of dependent loads -- took every wave
  * slot of the chip for the kernel's duration and stalled the demodulation kernel of the next
  * context (measured: K1 ran at a quarter of its speed while this kernel was resident). */
-__global__ __launch_bounds__(256) void k3_bursts(K3Args a, uint32_t n_items)
+__global__ __launch_bounds__(256) void k3_bursts(K3Args a, uint32_t n_items_host)
 {
-    const uint32_t ln = threadIdx.x & 63u;
-    for (uint32_t item = blockIdx.x * 4u + (threadIdx.x >> 6); item < n_items; item += gridDim.x * 4u) burst_item(a, item, ln);
+    __shared__ K3Lds lds;
+    const uint32_t ln = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    /* the host may not know the number of hits yet (no round trip between k3_scan and this kernel): ~0 = read it here */
+    const uint32_t n_items = n_items_host != 0xFFFFFFFFu ? n_items_host : 4u * a.g.S + min(*a.n_hits, a.hits_cap);
+    for (uint32_t item = blockIdx.x * 4u + wv; item < n_items; item += gridDim.x * 4u) burst_item(a, item, ln, lds.bits[wv], lds.bytes[wv]);
 }
 
 /* Debug/parity helper: flatten one (chain, algo, stream) chip stream. */

@@ -55,8 +55,14 @@
 __global__ __launch_bounds__(64 * WM_RLA_WPB, WM_FUSED_WAVES_PER_SIMD) void k2_clock_rla(K2Args clk, K2Args rla, uint32_t clk_blocks)
 {
     __shared__ __attribute__((aligned(16))) union { ClkLds<1> c; RlaLds r; } lds;
-    if (blockIdx.x < clk_blocks) clock_lanes<false, 1, WM_FUSED_LEAN_CLOCK != 0>(clk, blockIdx.x, lds.c);
-    else rla_lanes(rla, blockIdx.x - clk_blocks, lds.r);
+    /* both parts walk their lane lists with the blocks they were given (the counts may live on the device) */
+    if (blockIdx.x < clk_blocks) {
+        const uint32_t n = k2_lane_count(clk);
+        for (uint32_t b = blockIdx.x; (uint64_t)b * 64u < n; b += clk_blocks) clock_lanes<false, 1, WM_FUSED_LEAN_CLOCK != 0>(clk, b, lds.c);
+    } else {
+        const uint32_t n = k2_lane_count(rla), nb = gridDim.x - clk_blocks;
+        for (uint32_t b = blockIdx.x - clk_blocks; (uint64_t)b * (64u * WM_RLA_WPB) < n; b += nb) rla_lanes(rla, b, lds.r);
+    }
 }
 
 /* start[seg] must equal final[seg-1]; mismatching lanes are appended to `list`. */

@@ -93,7 +93,9 @@ long wm_emu_k1(const uint8_t *in, uint64_t in_stride, uint32_t S, uint32_t d, ui
     const bool sh = flags & WM_F_SHIFT;
     auto launch = [&](uint32_t n_list) {
         a.relist = n_list ? relist.data() : nullptr;
-        const uint32_t gx = n_list ? n_list : ntiles, gy = n_list ? 1 : S;
+        a.n_relist = &n_relist;                                             /* repair launches: a fixed grid walks the list (3 blocks here) */
+        const uint32_t gx = n_list ? 3u : ntiles, gy = n_list ? 1 : S;
+        gridDim = {gx, gy, 1};
         if (polyphase) {                                                    /* ppf.h pre-filter (d = 2, no shift) */
             for (uint32_t y = 0; y < gy; y++)
                 for (uint32_t x = 0; x < gx; x++) { blockIdx = {x, y, 0}; block_emu::run_block(256, [&] { k1_demod_ppf(a); }); }

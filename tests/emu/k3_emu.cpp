@@ -12,13 +12,15 @@
 #define __global__
 #define __forceinline__ inline
 #define __launch_bounds__(...)
-#define __shared__
+#define __shared__ static                  /* one block runs at a time: block-shared = static */
+#define WM_WAVE_SYNC() emu_wave_barrier()
 struct uint2 { uint32_t x, y; };
 struct uint4 { uint32_t x, y, z, w; };
 static inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
 using std::max;
 using std::min;
 static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+static inline uint32_t __brev(uint32_t v) { uint32_t r = 0; for (int i = 0; i < 32; i++) r |= ((v >> i) & 1u) << (31 - i); return r; }
 static inline uint32_t atomicAdd(uint32_t *p, uint32_t v) { const uint32_t o = *p; *p += v; return o; }
 static inline uint32_t atomicOr(uint32_t *p, uint32_t v) { const uint32_t o = *p; *p |= v; return o; }
 
@@ -37,6 +39,14 @@ void wm_emu_k3_set_spill(uint32_t *arena, uint32_t arena_words, uint32_t *chain,
 }
 
 /* geo: M, Mcap, flags, m0, seg_len[2], nseg[2], cap[2] (S = 1).  Returns the number of bursts, or -1 on overflow. */
+/* optional: where the bursts decoded by the kernel go (WmPkt array, byte arena); unset = every burst as chips */
+static WmPkt *emu_pkts = nullptr; static uint32_t emu_pkts_cap = 0, *emu_n_pkts = nullptr; static uint8_t *emu_bytes = nullptr; static uint32_t emu_bytes_cap = 0;
+void wm_emu_k3_set_decode(void *pkts, uint32_t pkts_cap, uint32_t *n_pkts, uint8_t *bytes, uint32_t bytes_cap)
+{
+    emu_pkts = (WmPkt *)pkts; emu_pkts_cap = pkts_cap; emu_n_pkts = n_pkts; emu_bytes = bytes; emu_bytes_cap = bytes_cap;
+}
+unsigned wm_emu_pkt_bytes(void) { return sizeof(WmPkt); }
+
 long wm_emu_k3(const uint64_t *geo, const uint32_t *chips0, const uint32_t *chips1, const uint32_t *counts0, const uint32_t *counts1,
                const uint32_t *seen0, const uint32_t *seen1, const uint8_t *rssi, const uint32_t *pending, void *hdr_out, uint32_t hdr_cap,
                uint32_t *words_out, uint32_t words_cap, uint32_t *n_words_out, uint32_t max_blocks)
@@ -60,8 +70,11 @@ long wm_emu_k3(const uint64_t *geo, const uint32_t *chips0, const uint32_t *chip
     k3.hits = hits.data(); k3.n_hits = &n_hits; k3.hits_cap = hdr_cap; k3.pending = pending;
     k3.hdr = (WmBurstHdr *)hdr_out; k3.hdr_cap = hdr_cap; k3.words = words_out; k3.words_cap = words_cap;
     k3.n_hdr = &n_hdr; k3.n_words = &n_words; k3.err = &err;
-    const uint32_t n_items = 4 * g.S + std::min(n_hits, hdr_cap);
-    gridDim = {std::max(1u, std::min((n_items + 3u) / 4u, max_blocks)), 1, 1};
+    uint32_t n_bytes = 0;
+    if (emu_pkts) { *emu_n_pkts = 0; k3.pkts = emu_pkts; k3.pkts_cap = emu_pkts_cap; k3.n_pkts = emu_n_pkts; k3.bytes = emu_bytes; k3.bytes_cap = emu_bytes_cap; k3.n_bytes = &n_bytes; }
+    const uint32_t n_items = 0xFFFFFFFFu;                  /* the kernel reads the hit count itself, as in the product */
+    const uint32_t n_items_host = 4 * g.S + std::min(n_hits, hdr_cap);
+    gridDim = {std::max(1u, std::min((n_items_host + 3u) / 4u, max_blocks)), 1, 1};
     for (uint32_t b = 0; b < gridDim.x; b++) {
         blockIdx = {b, 0, 0};
         block_emu::run_block(256, [&] { k3_bursts(k3, n_items); });

@@ -17,6 +17,8 @@ static inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
 struct Idx3 { uint32_t x, y, z; };
 static Idx3 threadIdx, blockIdx, gridDim;
 static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+static inline uint32_t __brev(uint32_t v) { uint32_t r = 0; for (int i = 0; i < 32; i++) r |= ((v >> i) & 1u) << (31 - i); return r; }
+#define WM_WAVE_SYNC() ((void)0)
 static inline unsigned long long __ballot(int p) { return p ? 1ull : 0ull; }       /* one-lane "wave": only to let the header compile */
 template <typename T> static inline T __shfl(T v, int) { return v; }
 template <typename T> static inline T __shfl_xor(T v, int) { return v; }

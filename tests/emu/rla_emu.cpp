@@ -19,7 +19,7 @@
 struct uint4 { uint32_t x, y, z, w; };
 static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
 struct Idx3 { uint32_t x, y, z; };
-static Idx3 threadIdx, blockIdx;
+static Idx3 threadIdx, blockIdx, gridDim;
 static inline int __ffs(int v) { return __builtin_ffs(v); }
 static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 static inline float __frcp_rn(float x) { return 1.0f / x; }          /* correctly rounded on both sides */

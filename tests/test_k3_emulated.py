@@ -22,6 +22,8 @@ SRC = os.path.join(HERE, "emu", "k3_emu.cpp")
 CLANG = shutil.which("clang++") or "/opt/rocm/lib/llvm/bin/clang++"
 HDR = np.dtype([("stream", "<u4"), ("chain", "u1"), ("algo", "u1"), ("flags", "<u2"), ("chip0", "<u4"), ("n_chips", "<u4"),
                 ("pos0", "<u8"), ("word_off", "<u4"), ("avail", "<u4")])
+PKT = np.dtype([("stream", "<u4"), ("chain", "u1"), ("algo", "u1"), ("status", "u1"), ("flags", "u1"), ("chip0", "<u4"), ("consumed", "<u4"),
+                ("sample", "<u8"), ("off", "<u4"), ("L", "<u2"), ("pkt_rssi", "u1"), ("rssi_now", "u1")])
 F_T1C1, F_S1, F_RLA, F_T2A = 8, 16, 32, 64
 
 emu_clock = CE.emu
@@ -40,7 +42,9 @@ def emu_k3():
     L = ctypes.CDLL(SO)
     L.wm_emu_k3.restype = ctypes.c_long
     L.wm_emu_k3.argtypes = [ctypes.c_void_p] * 10 + [ctypes.c_uint, ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p, ctypes.c_uint]
-    assert L.wm_emu_hdr_bytes() == HDR.itemsize
+    L.wm_emu_k3_set_decode.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint]
+    L.wm_emu_k3_set_spill.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    assert L.wm_emu_hdr_bytes() == HDR.itemsize and L.wm_emu_pkt_bytes() == PKT.itemsize
     return L
 
 
@@ -67,6 +71,7 @@ def framers_on_host(emu_clock, emu_rla, ref, seg1=32768, seg0=8192):
     for rr in range(2):
         emu_rla.wm_emu_rla_reset_state(carry0[rr * sb:].ctypes.data)
     ctypes.c_void_p.in_dll(emu_rla, "wm_emu_seen_out").value = seen0.ctypes.data
+    emu_rla.wm_emu_rla_set_spill(None, 0, None, None, None)             # roomy primary regions here
     r = emu_rla.wm_emu_rla(bits.ctypes.data, 1, M, Mcap, F_T1C1 | F_S1, seg0, 1024, cap0, carry0.ctypes.data, chips0.ctypes.data, counts0.ctypes.data,
                            ctypes.byref(err))
     ctypes.c_void_p.in_dll(emu_rla, "wm_emu_seen_out").value = None
@@ -75,13 +80,24 @@ def framers_on_host(emu_clock, emu_rla, ref, seg1=32768, seg0=8192):
     return dict(geo=geo, chips=(chips0, chips1), counts=(counts0, counts1), seen=(seen0, seen1), Mcap=Mcap)
 
 
-def bursts_on_host(emu_k3, fr, rssi_rows, pending=None, max_blocks=256):
+def bursts_on_host(emu_k3, fr, rssi_rows, pending=None, max_blocks=256, decode=False):
+    """decode=False: every burst as chips for the host decoders (hdr, words).  decode=True: as the product runs it --
+    bursts that end inside the push are decoded by the kernel: (hdr, words, pkts, bytes)."""
     pend = np.zeros(4, np.uint32) if pending is None else np.asarray(pending, np.uint32)
     hdr = np.zeros(1 << 16, HDR); words = np.zeros(1 << 24, np.uint32); nw = ctypes.c_uint(0)
+    emu_k3.wm_emu_k3_set_spill(*fr.get("spill", (None, 0, None, None, None)))
+    pkts = np.zeros(1 << 16, PKT); pbytes = np.zeros(1 << 22, np.uint8); npk = ctypes.c_uint(0)
+    if decode:
+        emu_k3.wm_emu_k3_set_decode(pkts.ctypes.data, pkts.size, ctypes.addressof(npk), pbytes.ctypes.data, pbytes.size)
+    else:
+        emu_k3.wm_emu_k3_set_decode(None, 0, None, None, 0)
     n = emu_k3.wm_emu_k3(fr["geo"].ctypes.data, fr["chips"][0].ctypes.data, fr["chips"][1].ctypes.data, fr["counts"][0].ctypes.data,
                          fr["counts"][1].ctypes.data, fr["seen"][0].ctypes.data, fr["seen"][1].ctypes.data, rssi_rows.ctypes.data,
                          pend.ctypes.data, hdr.ctypes.data, hdr.size, words.ctypes.data, words.size, ctypes.byref(nw), max_blocks)
     assert n >= 0
+    emu_k3.wm_emu_k3_set_decode(None, 0, None, None, 0)
+    if decode:
+        return hdr[:n], words[:nw.value], pkts[:npk.value], pbytes
     return hdr[:n], words[:nw.value]
 
 
@@ -147,3 +163,81 @@ def test_continuation_slots_deliver_what_a_busy_decoder_is_owed(emu_k3, emu_cloc
         w = words[h["word_off"]:h["word_off"] + h["n_chips"]]
         assert np.array_equal(w & 7, oc["value"][:h["n_chips"]] & 7)
         assert np.array_equal(h["pos0"] + (w >> 11), oc["sample"][:h["n_chips"]])
+
+
+def host_decoder_on_every_access_code(dec, ref, ch, al):
+    """What the product's host decoder (wm_decoder.c = the reference's state machines, held against them in
+    test_host_decoder.py / test_oracle_units.py) does from EVERY access-code chip of a chip stream on:
+    {chip index: (consumed, done, packet bytes, L, flags, pkt_rssi, rssi_now, completing sample)}; None if the
+    burst runs into the end of the stream."""
+    oc = ref["chips"][(ref["chips"]["chain"] == ch) & (ref["chips"]["algo"] == al)]
+    val, rssi, pos = oc["value"].astype(np.uint32), oc["rssi"].astype(np.uint32), oc["sample"].astype(np.int64)
+    db = dec.wm_emu_decoder_bytes()
+    dec.wm_decoder_init.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    dec.wm_decoder_chip.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint]
+    out = {}
+    for i in np.nonzero(val & 2)[0]:
+        buf = ctypes.create_string_buffer(db)
+        dec.wm_decoder_init(buf, ch)
+        st, k, res = 0, 0, None
+        for j in range(i, len(val)):
+            v = int(val[j])
+            if (v & 4) and st == 1:
+                res = (k, False); break
+            st = dec.wm_decoder_chip(buf, v & 3, int(rssi[j]))
+            k += 1
+            if st == 2:
+                res = (k, True); break
+            if st == 0:
+                res = (k, False); break
+        if res is None:
+            out[int(i)] = None
+            continue
+        d = np.frombuffer(buf.raw, np.uint8)
+        # wm_decoder layout (wm_decoder.h): step u16, mode u8, err3of6 u8, c1 u8, frame_b u8, l u16, L u16, [pad], sym u32, mode_bits u32, pkt_rssi u32, packet[292]
+        err36, c1, fb = int(d[3]), int(d[4]), int(d[5])
+        l_, L = int(d[6]) | int(d[7]) << 8, int(d[8]) | int(d[9]) << 8
+        pkt_rssi = int(np.frombuffer(buf.raw[20:24], "<u4")[0])
+        out[int(i)] = dict(consumed=res[0], done=res[1], L=L, nbytes=l_, bytes=bytes(d[24:24 + l_]), c1=c1, fb=fb, err36=err36, pkt_rssi=pkt_rssi,
+                           rssi_now=int(rssi[i + res[0] - 1]), sample=int(pos[i + res[0] - 1]))
+    return out
+
+
+@pytest.mark.parametrize("seed,amp,kinds,noise", [(1, 60.0, 15, 3.0), (2, 9.0, 15, 3.0), (3, 25.0, 15, 10.0), (4, 60.0, 6, 0.5)])
+def test_bursts_inside_the_push_are_decoded_like_the_host_decoder_would(emu_k3, emu_clock, emu_rla, emu_need, oracle, wm, seed, amp, kinds, noise):
+    """3-out-of-6 / NRZ / Manchester decode, RSSI gate, framer-reset aborts and the block CRCs on the GPU.
+    Every access-code hit whose burst ends inside the push must come back as a WmPkt with exactly the chips-consumed
+    count, verdicts, RSSI pair, completing sample and bytes the host decoder produces from the same chips; the rest
+    (cut by the end of the push) still arrive as chips."""
+    cu8 = wm.synth_capture(seed=5200 + seed, n_samples=1 << 19, kinds=kinds, frames_per_s=150.0, amplitude=amp, noise_sigma=noise)[0]
+    if seed == 3:
+        cu8[cu8.size // 3 & ~1: cu8.size // 3 + 40000] = 128                # a silent stretch: RSSI gate and framer resets inside bursts
+    ref = oracle.run(cu8, flags_to_oracle_opts(oracle, ["-v"]), taps=True, chips=True)
+    fr = framers_on_host(emu_clock, emu_rla, ref)
+    rssi = np.zeros((2, fr["Mcap"]), np.uint8)
+    for ch in range(2):
+        rssi[ch, :ref["m"]] = ref["rssi"][ch].astype(np.uint32).astype(np.uint8)
+    hdr, words, pkts, pbytes = bursts_on_host(emu_k3, fr, rssi, decode=True)
+    n_done = n_abort = n_raw = 0
+    for ch in (0, 1):
+        for al in (0, 1):
+            want = host_decoder_on_every_access_code(emu_need, ref, ch, al)
+            got_p = {int(p["chip0"]): p for p in pkts[(pkts["chain"] == ch) & (pkts["algo"] == al)]}
+            got_h = {int(h["chip0"]) for h in hdr[(hdr["chain"] == ch) & (hdr["algo"] == al)]}
+            assert sorted(list(got_p) + list(got_h)) == sorted(want), (ch, al)     # every hit exactly once
+            for i, w in want.items():
+                if i in got_h:
+                    n_raw += 1                                   # shipped as chips: the plan reaches past the push (w may even be known)
+                    continue
+                p = got_p[i]
+                assert w is not None, (ch, al, i)
+                assert int(p["consumed"]) == w["consumed"] and (p["status"] == 1) == w["done"], (ch, al, i, p, w)
+                if w["done"]:
+                    fl = int(p["flags"])
+                    assert (int(p["L"]), bool(fl & 1), bool(fl & 2), bool(fl & 4)) == (w["L"], bool(w["c1"]), bool(w["fb"]), bool(w["err36"])), (ch, al, i)
+                    assert bytes(pbytes[int(p["off"]):int(p["off"]) + w["nbytes"]]) == w["bytes"], (ch, al, i)
+                    assert (int(p["pkt_rssi"]), int(p["rssi_now"]), int(p["sample"])) == (w["pkt_rssi"] & 0xFF, w["rssi_now"], w["sample"]), (ch, al, i)
+                    n_done += 1
+                else:
+                    n_abort += 1
+    assert n_done > 10 and n_abort > 0 and n_raw <= 8

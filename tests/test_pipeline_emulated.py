@@ -22,8 +22,9 @@ F_SHIFT, F_ACCURATE, F_DC, F_T1C1, F_S1, F_RLA, F_T2A = 1, 2, 4, 8, 16, 32, 64
 
 class HostPipeline:
     def __init__(self, libs, d=2, flags=F_ACCURATE | F_T1C1 | F_S1 | F_RLA | F_T2A, seg1=32768, seg0=8192, warm=(12288, 24576), lookback=1024,
-                 max_push=1 << 20, polyphase=0):
+                 max_push=1 << 20, polyphase=0, gpu_decode=True):
         self.polyphase = polyphase
+        self.gpu_decode = gpu_decode                              # as the product: bursts inside the push are decoded by k3_bursts
         self.k1, self.clk, self.rla, self.k3, self.dec = libs
         self.d, self.flags, self.seg1, self.seg0, self.warm, self.lookback = d, flags, seg1, seg0, warm, lookback
         self.stride = (K1.HIST + max_push + K1.SLACK + 255) // 256 * 256
@@ -43,6 +44,10 @@ class HostPipeline:
         self.dec.wm_decoder_chips_owed.argtypes = [ctypes.c_void_p]; self.dec.wm_decoder_chips_owed.restype = ctypes.c_uint
         self.dec.wm_decoder_format.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p]
         self.dec.wm_decoder_format.restype = ctypes.c_size_t
+        self.dec.wm_packet_format.argtypes = [ctypes.c_int] * 5 + [ctypes.c_uint, ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint, ctypes.c_char_p, ctypes.c_char_p,
+                                              ctypes.c_char_p, ctypes.c_size_t]
+        self.dec.wm_packet_format.restype = ctypes.c_size_t
+        self.dec.wm_packet_crc_ok.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_int]
         for ch in range(2):
             for al in range(2):
                 buf = ctypes.create_string_buffer(db)
@@ -70,8 +75,12 @@ class HostPipeline:
                                       self.clk_carry.ctypes.data, bits.ctypes.data, chips1.ctypes.data, counts1.ctypes.data, ctypes.byref(err), None)
             ctypes.c_void_p.in_dll(self.clk, "wm_emu_seen_out").value = None
             assert r >= 0 and err.value == 0
-            nseg0, cap0 = (M + self.seg0 - 1) // self.seg0, 4 * self.seg0 + 8 + 8192      # wm_api.hip: cap[0]
+            # the product's layout (wm_api.hip): a primary region of half a chip per sample, then the segment's spill chain
+            nseg0, cap0 = (M + self.seg0 - 1) // self.seg0, (self.seg0 // 2 + 8 + 7) // 8 * 8
             chips0 = np.zeros((2, nseg0, cap0), np.uint32); counts0 = np.zeros((2, nseg0), np.uint32); seen0 = np.zeros((2, nseg0), np.uint32)
+            arena = np.zeros(1 << 20, np.uint32); chain = np.zeros((2, nseg0, self.rla.wm_emu_spill_levels()), np.uint32); nchain = np.zeros(2 * nseg0 + 1, np.uint32)
+            spill = (arena.ctypes.data, arena.size, chain.ctypes.data, nchain.ctypes.data, nchain[2 * nseg0:].ctypes.data)
+            self.rla.wm_emu_rla_set_spill(*spill)
             ctypes.c_void_p.in_dll(self.rla, "wm_emu_seen_out").value = seen0.ctypes.data
             r = 0 if not self.flags & F_RLA else self.rla.wm_emu_rla(bits.ctypes.data, 1, M, Mcap, self.flags & (F_T1C1 | F_S1), self.seg0, self.lookback, cap0, self.rla_carry.ctypes.data,
                                     chips0.ctypes.data, counts0.ctypes.data, ctypes.byref(err))
@@ -82,26 +91,50 @@ class HostPipeline:
             fr = dict(geo=np.array([M, Mcap, self.flags, m0, self.seg0, self.seg1, nseg0, nseg1, cap0, cap1], np.uint64), chips=(chips0, chips1),
                       counts=(counts0, counts1), seen=(seen0, seen1))
             pending = [self.decs[(ch, al)][1] for al in range(2) for ch in range(2)]          # [algo][chain]
-            hdr, words = K3.bursts_on_host(self.k3, fr, rssi, pending)
-            lines = self.collect(hdr, words)
+            fr["spill"] = spill
+            self.spilled = getattr(self, "spilled", 0) + int(nchain[:2 * nseg0].sum())
+            if self.gpu_decode:
+                hdr, words, pkts, pbytes = K3.bursts_on_host(self.k3, fr, rssi, pending, decode=True)
+                lines = self.collect(hdr, words, pkts, pbytes)
+            else:
+                hdr, words = K3.bursts_on_host(self.k3, fr, rssi, pending)
+                lines = self.collect(hdr, words)
         self.row[:K1.HIST] = self.row[nb:nb + K1.HIST].copy()
         self.n0 += n_new
         return lines
 
-    def collect(self, hdr, words):
-        """wm_api.hip: wmbus_collect / decode_stream_range for one capture."""
+    def collect(self, hdr, words, pkts=(), pbytes=None):
+        """wm_api.hip: wmbus_collect / decode_stream_range for one capture: candidate telegrams (bursts as chips, and
+        telegrams the kernel has already assembled) per (chain, framer) in chip order."""
         out, seq = [], 0
-        order = sorted(range(len(hdr)), key=lambda i: (hdr[i]["chain"], hdr[i]["algo"], 0 if hdr[i]["flags"] & 1 else 1, hdr[i]["chip0"]))
+        ents = [((int(h["chain"]), int(h["algo"]), 0 if h["flags"] & 1 else 1, int(h["chip0"])), 1, h) for h in hdr] + \
+               [((int(p["chain"]), int(p["algo"]), 1, int(p["chip0"])), 0, p) for p in pkts]
+        ents.sort(key=lambda e: e[0])
         line = ctypes.create_string_buffer(1024); ok = ctypes.c_int(0)
         group, next_free = None, 0
-        for i in order:
-            h = hdr[i]
-            key = (int(h["chain"]), int(h["algo"]))
+        for keyfull, raw, h in ents:
+            key = keyfull[:2]
             if key != group:
                 group, next_free = key, 0
             dec = self.decs[key]
+            tag = b"rla;" if key[1] == 0 else b"t2a;"
+            if not raw:
+                if dec[1] != 0 or h["chip0"] < next_free:
+                    continue                                    # the access code passed while the decoder was busy
+                next_free = int(h["chip0"]) + int(h["consumed"])
+                if h["status"] != 1:
+                    continue
+                fl, L = int(h["flags"]), int(h["L"])
+                buf = (ctypes.c_uint8 * 296)(*pbytes[int(h["off"]):int(h["off"]) + max(L, 2)].tolist())
+                # the kernel's CRC verdict must be the host's (t1_c1_packet_decoder.h:471-536 restated twice)
+                assert bool(fl & 8) == bool(self.dec.wm_packet_crc_ok(buf, L, int(bool(fl & 2)))), "device CRC verdict"
+                n = self.dec.wm_packet_format(key[0], int(bool(fl & 1)), int(bool(fl & 2)), int(bool(fl & 4)), int(bool(fl & 8)), L, buf,
+                                              int(h["pkt_rssi"]), int(h["rssi_now"]), tag, b"TS", line, 1024)
+                out.append((int(h["sample"]), key[0], key[1], seq, line.raw[:n].decode()))
+                seq += 1
+                continue
             cont = bool(h["flags"] & 1)
-            if (dec[1] == 0) if cont else (h["chip0"] < next_free):
+            if (dec[1] == 0) if cont else (dec[1] != 0 or h["chip0"] < next_free):
                 continue                                        # the access code passed while the decoder was busy
             w = words[h["word_off"]:h["word_off"] + h["n_chips"]]
             st, k = (1 if cont else 0), 0
@@ -113,7 +146,7 @@ class HostPipeline:
                     break
                 st = self.dec.wm_decoder_chip(dec[0], val & 3, rs)
                 if st == 2:
-                    n = self.dec.wm_decoder_format(dec[0], b"rla;" if key[1] == 0 else b"t2a;", b"TS", rs, line, 1024, ctypes.byref(ok))
+                    n = self.dec.wm_decoder_format(dec[0], tag, b"TS", rs, line, 1024, ctypes.byref(ok))
                     out.append((int(h["pos0"]) + (int(w[k]) >> 11), key[0], key[1], seq, line.raw[:n].decode()))
                     seq += 1
                     st = 0
@@ -151,6 +184,7 @@ def test_bundled_capture_through_the_emulated_pipeline(libs, oracle, samples, pu
     ref = oracle.run(cu8, flags_to_oracle_opts(oracle, ["-v"]))
     assert len(ref["text"].splitlines()) >= 2
     assert run_capture(libs, cu8, pushes) == ref["text"]
+    assert run_capture(libs, cu8, pushes, gpu_decode=False) == ref["text"]        # every burst through the host decoders (WMBUS_GPU_DECODE=0)
 
 
 def test_synthetic_captures_through_the_emulated_pipeline(libs, oracle, wm):
