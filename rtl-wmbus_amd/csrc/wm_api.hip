@@ -128,7 +128,9 @@ struct wmbus_ctx {
     uint32_t carry_in = 0; bool committed = false;
     uint32_t *d_chips[2] = {}, *d_counts[2] = {};
     void *d_st_start[2] = {}, *d_st_final[2] = {}, *d_st_carry[2] = {};
-    uint32_t *d_list2 = nullptr;                        /* run-length re-run list of the fused framer launches */
+    uint32_t *d_list2 = nullptr;                        /* run-length re-run list */
+    uint32_t *d_list_ema = nullptr;                     /* RSSI repair list (one entry per row at most); every verifier has its own list:
+                                                           collect's slow path starts from what the LAST verify of each kind left */
     uint32_t *d_list = nullptr, *d_scalars = nullptr;   /* scalars: err, n_list, n_hits, n_hdr, n_words */
     uint32_t *d_sync_seen[2] = {};                      /* per framer: [2][S][nseg_cap] access-code chip seen in region */
     uint32_t *d_spill = nullptr, *d_chain = nullptr, *d_nchain = nullptr; uint32_t spill_words = 0;   /* WmSpill (wm_dev.h) */
@@ -314,7 +316,7 @@ void wmbus_close(wmbus_ctx *c)
         std::lock_guard<std::mutex> lk(kc.m);
         if (kc.owner == c) { kc.last = nullptr; kc.owner = nullptr; }      /* nobody may wait on an event that is about to go */
     }
-    void *dev[] = {c->d_spill, c->d_chain, c->d_nchain, c->d_list2, c->d_sync_seen[0], c->d_sync_seen[1], c->d_first_bad, c->d_ckpt, c->d_in, c->d_dphi, c->d_rssi, c->d_bits, c->d_lut, c->d_ema_head, c->d_ema_tail, c->d_ema_carry,
+    void *dev[] = {c->d_list_ema, c->d_spill, c->d_chain, c->d_nchain, c->d_list2, c->d_sync_seen[0], c->d_sync_seen[1], c->d_first_bad, c->d_ckpt, c->d_in, c->d_dphi, c->d_rssi, c->d_bits, c->d_lut, c->d_ema_head, c->d_ema_tail, c->d_ema_carry,
                    c->d_chips[0], c->d_chips[1], c->d_counts[0], c->d_counts[1], c->d_st_start[0], c->d_st_start[1],
                    c->d_st_final[0], c->d_st_final[1], c->d_st_carry[0], c->d_st_carry[1], c->d_list, c->d_scalars,
                    c->d_hits, c->d_pending};
@@ -418,6 +420,7 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
     }
     A(dalloc(&c->d_list, (size_t)rows * std::max(c->nseg_cap[0], c->nseg_cap[1])));
     A(dalloc(&c->d_list2, (size_t)rows * c->nseg_cap[0]));
+    A(dalloc(&c->d_list_ema, (size_t)rows));
     c->nck = c->C[1] / WM_CK_SAMPLES ? c->C[1] / WM_CK_SAMPLES - 1 : 0;
     A(dalloc(&c->d_ckpt, std::max<size_t>(16, (size_t)rows * c->nseg_cap[1] * c->nck * 16)));
     A(dalloc(&c->d_scalars, (size_t)SC_COUNT));
@@ -539,13 +542,13 @@ static void ema_verify(wmbus_ctx *c, uint32_t cnt)
 {
     const uint32_t rows = 2 * c->S, ntiles = c->ntiles;
     hipLaunchKernelGGL(k1_verify, dim3((rows + 63) / 64, ntiles), dim3(64), 0, c->stream, c->d_ema_head, c->d_ema_tail, ema_carry(c, false), ntiles, rows, c->d_first_bad);
-    hipLaunchKernelGGL(k1_collect, dim3((rows + 63) / 64), dim3(64), 0, c->stream, c->d_first_bad, ntiles, rows, c->S, c->d_list, c->d_scalars + cnt);
+    hipLaunchKernelGGL(k1_collect, dim3((rows + 63) / 64), dim3(64), 0, c->stream, c->d_first_bad, ntiles, rows, c->S, c->d_list_ema, c->d_scalars + cnt);
 }
 
 static int ema_repair(wmbus_ctx *c, uint32_t cnt)          /* list launch: a fixed grid walks d_list[0 .. scalar cnt) */
 {
     K1Args k1 = c->k1a;
-    k1.relist = c->d_list; k1.n_relist = c->d_scalars + cnt;
+    k1.relist = c->d_list_ema; k1.n_relist = c->d_scalars + cnt;
     return launch_k1_any(c, k1, dim3(16, 1));
 }
 
@@ -778,7 +781,7 @@ static int finish_slowly(wmbus_ctx *c, bool ema_left, bool clk_left, bool rla_le
     };
     const uint32_t max_rounds = std::max({c->ntiles, c->last.nseg[0], c->last.nseg[1]}) + 4;
     if (ema_left) {
-        uint32_t cnt = SC_EMA + WM_EMA_ROUNDS, n = 0;          /* the list of the last verify is still in d_list */
+        uint32_t cnt = SC_EMA + WM_EMA_ROUNDS, n = 0;          /* the list of the last verify is still in d_list_ema */
         for (uint32_t round = 0;; round++) {
             c->tim.ema_retries += c->h_scalars[cnt];
             int rc = ema_repair(c, cnt);
