@@ -118,6 +118,7 @@ struct wmbus_ctx {
     size_t staged = 0;
     /* device buffers */
     uint8_t *d_in = nullptr;                           /* [n_win][S][in_stride] */
+    uint8_t *d_hist = nullptr;                         /* [S][4096] the input history of the next push (see k_copy_hist) */
     float *d_dphi = nullptr; uint8_t *d_rssi = nullptr; uint32_t *d_bits = nullptr;
     float *d_lut = nullptr;
     float *d_ema_head = nullptr, *d_ema_tail = nullptr, *d_ema_carry = nullptr;   /* carry: [2][rows], see carry_in */
@@ -181,13 +182,14 @@ static const bool opt_rounds = !(getenv("WMBUS_OPT_ROUNDS") && atoi(getenv("WMBU
 enum { SC_ERR = 0, SC_NHITS = 1, SC_NHDR = 2, SC_NWORDS = 3, SC_NPKTS = 4, SC_NBYTES = 5, SC_SLOW = 6, SC_CHIPS = 8 /* [algo][chain] */,
        SC_EMA = 16 /* [WM_EMA_ROUNDS + 1] */, SC_CLK = 24 /* [WM_FR_ROUNDS + 1] */, SC_RLA = 32 /* [WM_FR_ROUNDS + 1] */, SC_COUNT = 40 };
 
-__global__ void k_roll_history(const uint8_t *in, uint8_t *next, uint64_t stride, uint32_t nbytes)
+/* 4096 bytes per capture from src + row * sstride + soff to dst + row * dstride (256 threads x 16 bytes).  The input
+ * history: the last 4096 staged bytes of a push are put aside (d_hist) when the push is enqueued and placed in front of
+ * the window the next push is staged into when THAT push is enqueued -- in between the window stays as it was, so
+ * that wmbus_collect's slow path can still re-run the first tile of a capture. */
+__global__ void k_copy_hist(const uint8_t *src, uint64_t sstride, uint64_t soff, uint8_t *dst, uint64_t dstride)
 {
-    /* history of the next push (front of the window it will be staged into; the same window when there is only
-     * one) = the 4096 bytes that end at the end of the staged data */
-    const uint4 v = *(const uint4 *)(in + (uint64_t)blockIdx.x * stride + nbytes + 16u * threadIdx.x);
-    __syncthreads();
-    *(uint4 *)(next + (uint64_t)blockIdx.x * stride + 16u * threadIdx.x) = v;
+    const uint4 v = *(const uint4 *)(src + (uint64_t)blockIdx.x * sstride + soff + 16u * threadIdx.x);
+    *(uint4 *)(dst + (uint64_t)blockIdx.x * dstride + 16u * threadIdx.x) = v;
 }
 
 __global__ void k_copy_word(uint32_t *dst, uint32_t v) { *dst = v; }
@@ -316,7 +318,7 @@ void wmbus_close(wmbus_ctx *c)
         std::lock_guard<std::mutex> lk(kc.m);
         if (kc.owner == c) { kc.last = nullptr; kc.owner = nullptr; }      /* nobody may wait on an event that is about to go */
     }
-    void *dev[] = {c->d_list_ema, c->d_spill, c->d_chain, c->d_nchain, c->d_list2, c->d_sync_seen[0], c->d_sync_seen[1], c->d_first_bad, c->d_ckpt, c->d_in, c->d_dphi, c->d_rssi, c->d_bits, c->d_lut, c->d_ema_head, c->d_ema_tail, c->d_ema_carry,
+    void *dev[] = {c->d_hist, c->d_list_ema, c->d_spill, c->d_chain, c->d_nchain, c->d_list2, c->d_sync_seen[0], c->d_sync_seen[1], c->d_first_bad, c->d_ckpt, c->d_in, c->d_dphi, c->d_rssi, c->d_bits, c->d_lut, c->d_ema_head, c->d_ema_tail, c->d_ema_carry,
                    c->d_chips[0], c->d_chips[1], c->d_counts[0], c->d_counts[1], c->d_st_start[0], c->d_st_start[1],
                    c->d_st_final[0], c->d_st_final[1], c->d_st_carry[0], c->d_st_carry[1], c->d_list, c->d_scalars,
                    c->d_hits, c->d_pending};
@@ -393,6 +395,7 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
     for (auto &ev : c->ev) A(hipEventCreate(&ev));
     A(hipEventCreateWithFlags(&c->ev_staged, hipEventDisableTiming));
     A(dalloc(&c->d_in, (size_t)c->in_stride * c->S * c->n_win));
+    A(dalloc(&c->d_hist, (size_t)WM_HIST_BYTES * c->S));
     A(dalloc(&c->d_dphi, (size_t)rows * c->Mcap));
     A(dalloc(&c->d_rssi, (size_t)rows * c->Mcap));
     A(dalloc(&c->d_bits, (size_t)rows * (c->Mcap / 32)));
@@ -464,6 +467,7 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
     A(hipMemsetAsync(c->d_scalars, 0, SC_COUNT * sizeof(uint32_t), c->stream));
     A(hipMemsetAsync(c->d_pending, 0, 4 * c->S * sizeof(uint32_t), c->stream));
     hipLaunchKernelGGL(k_fill, dim3(c->S * c->n_win), dim3(256), 0, c->stream, c->d_in, c->in_stride, (uint32_t)c->in_stride, (uint8_t)128);
+    hipLaunchKernelGGL(k_fill, dim3(c->S), dim3(256), 0, c->stream, c->d_hist, (uint64_t)WM_HIST_BYTES, (uint32_t)WM_HIST_BYTES, (uint8_t)128);
     /* frequency-translation LUT, built with the host libm exactly like rtl_wmbus.c:974-993 */
     {
         const int fs_khz = (int)c->d * 800;
@@ -665,6 +669,7 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_staged, 0));
     }
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    hipLaunchKernelGGL(k_copy_hist, dim3(c->S), dim3(256), 0, c->stream, c->d_hist, (uint64_t)WM_HIST_BYTES, (uint64_t)0, win, c->in_stride);
     if (g.M > 0) {
         HIPCHK(c, hipMemsetAsync(c->d_scalars, 0, SC_COUNT * sizeof(uint32_t), c->stream));
         /* chips the decoders of half-received telegrams still want: known since the previous collect */
@@ -754,15 +759,10 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
         HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
         HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, SC_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
-        /* slide the input history: the next push sees the last 4096 staged bytes in front of it */
-        uint8_t *next = c->d_in + (size_t)((c->fill + 1) % c->n_win) * c->S * c->in_stride;
-        hipLaunchKernelGGL(k_roll_history, dim3(c->S), dim3(256), 0, c->stream, win, next, c->in_stride, (uint32_t)nbytes);
-        HIPCHK(c, hipGetLastError());
-    } else {
-        uint8_t *next = c->d_in + (size_t)((c->fill + 1) % c->n_win) * c->S * c->in_stride;
-        hipLaunchKernelGGL(k_roll_history, dim3(c->S), dim3(256), 0, c->stream, win, next, c->in_stride, (uint32_t)nbytes);
-        HIPCHK(c, hipGetLastError());
     }
+    /* the next push sees the last 4096 staged bytes in front of it */
+    hipLaunchKernelGGL(k_copy_hist, dim3(c->S), dim3(256), 0, c->stream, win, c->in_stride, (uint64_t)nbytes, c->d_hist, (uint64_t)WM_HIST_BYTES);
+    HIPCHK(c, hipGetLastError());
     c->fill = (c->fill + 1) % c->n_win;
     c->n0 += n_new;
     c->in_flight = true;
