@@ -28,7 +28,10 @@ import os
 # One HIP stream per receiver context; ROCm maps streams onto 4 hardware queues by default and streams
 # that share a queue serialise against each other (8 contexts on 4 queues: -25 %).  Must be set
 # before the HIP runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+import sys as _sys
+# (--from-host gives every context a second stream for its staging copies: 16 queues, or two contexts' compute streams
+# share one)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16" if "--from-host" in _sys.argv else "8")
 
 import argparse
 import collections
@@ -172,7 +175,7 @@ def main():
         host_threads = a.host_threads or max(4, min(32, 2 * (os.cpu_count() or 16) // max(1, world * nctx)))
         rx = wm.Receiver(n_streams=per_ctx[i], max_push_bytes=push_bytes, device=local, seg_len=a.seg_len, rla_seg_len=a.rla_seg_len,
                          warmup_s1=a.warmup_s1, warmup_t1c1=a.warmup_t1c1, show_algorithm=True, fixed_timestamp=True,
-                         host_threads=host_threads)
+                         host_threads=host_threads, input_windows=2 if a.from_host else 1)
         for s in range(per_ctx[i]):
             rx.stage(s, caps[base + s])
         rxs.append(rx)
@@ -197,13 +200,17 @@ def main():
         rx, lines, tims = rxs[i], 0, []
         if stagger_s > 0 and i:
             time.sleep(stagger_s * i)
-        for _ in range(k_steps):
-            if a.from_host:
-                for s_ in range(per_ctx[i]):
-                    rx.stage(s_, host_caps[i][s_])
+        def stage_all():                                      # pinned host memory -> the window the next push reads (copy stream)
+            for s_ in range(per_ctx[i]):
+                rx.stage(s_, host_caps[i][s_])
+        if a.from_host:
+            stage_all()
+        for k in range(k_steps):
             t_a = time.perf_counter()
             rx.process(push_bytes)
             t_b = time.perf_counter()
+            if a.from_host and k + 1 < k_steps:
+                stage_all()                                   # the next push's bytes cross PCIe while this one is in flight (second input window)
             rx.collect()
             lines += rx.lines_count()
             tm = rx.timing()

@@ -72,6 +72,11 @@ typedef struct wmbus_cfg {
      * the alternatives its source keeps behind `#elif 0` / `#else`: extensions, ignored with -a. */
     int atan_mode;
     unsigned spill_words;       /* tuning: run-length chip spill arena, 32-bit words (0 = default) */
+    /* Downstream conveniences, OFF by default (the drop-in prints exactly what the reference prints).  The two
+     * framers work on every burst, so a clean telegram is printed twice (README.md:105-108): dedup_twins drops the
+     * later of two lines of one capture and mode with the same payload from different framers that complete within one
+     * longest-telegram time; only_crc_ok prints CRC-clean telegrams only (what e.g. wmbusmeters keeps). */
+    int dedup_twins, only_crc_ok;
     unsigned input_windows;     /* 1 (default, also for 0): one device input window per stream; 2: two, used alternately, so
                                    that wmbus_stage() for the next push may run while the previous one is in flight (the
                                    copies run on their own HIP stream).  wmbus_device_input() names the window the next

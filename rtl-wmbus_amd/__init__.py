@@ -42,7 +42,8 @@ class Cfg(ctypes.Structure):
                 ("max_push_bytes", ctypes.c_size_t), ("seg_len", ctypes.c_uint), ("rla_seg_len", ctypes.c_uint),
                 ("warmup_t1c1", ctypes.c_uint),
                 ("warmup_s1", ctypes.c_uint), ("rla_lookback", ctypes.c_uint), ("host_threads", ctypes.c_uint),
-                ("keep_taps", ctypes.c_int), ("prefilter", ctypes.c_int), ("atan_mode", ctypes.c_int), ("spill_words", ctypes.c_uint), ("input_windows", ctypes.c_uint)]
+                ("keep_taps", ctypes.c_int), ("prefilter", ctypes.c_int), ("atan_mode", ctypes.c_int), ("spill_words", ctypes.c_uint), ("dedup_twins", ctypes.c_int), ("only_crc_ok", ctypes.c_int),
+                ("input_windows", ctypes.c_uint)]
 
 
 class Line(ctypes.Structure):
@@ -140,7 +141,7 @@ class Receiver:
     def __init__(self, n_streams=1, max_push_bytes=4 << 20, decimation=2, simultaneous=False, accurate_atan=True,
                  remove_dc=False, t1c1=True, s1=True, rla=True, time2=True, show_algorithm=True, device=0,
                  seg_len=0, rla_seg_len=0, warmup_t1c1=0, warmup_s1=0, rla_lookback=0, host_threads=0, fixed_timestamp=True,
-                 prefilter=0, atan_mode=0, keep_taps=True, spill_words=0, input_windows=1):
+                 prefilter=0, atan_mode=0, keep_taps=True, spill_words=0, input_windows=1, dedup_twins=False, only_crc_ok=False):
         L = lib()
         c = Cfg()
         L.wmbus_default_cfg(ctypes.byref(c))
@@ -155,6 +156,7 @@ class Receiver:
         c.atan_mode = atan_mode
         c.spill_words = spill_words
         c.input_windows = input_windows
+        c.dedup_twins, c.only_crc_ok = int(dedup_twins), int(only_crc_ok)
         self.cfg = c
         self.n_streams = n_streams
         self._h = ctypes.c_void_p()

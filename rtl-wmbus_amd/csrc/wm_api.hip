@@ -153,6 +153,7 @@ struct wmbus_ctx {
     uint32_t n_hdr = 0, n_words = 0, n_pkts = 0;
     K1Args k1a{}; K2Args k2clk{}, k2rla{}; uint32_t ntiles = 0; bool fused = false;    /* this push's launch arguments (collect's slow path re-uses them) */
     std::vector<HostDecoder> decs;                      /* [stream][chain][algo] */
+    std::vector<wm_twin> twins;                         /* [stream][chain][2]: the last lines printed (cfg.dedup_twins) */
     std::unique_ptr<WorkerPool> pool;                   /* packet-decoder workers, created on first use */
     std::vector<wmbus_line> lines; std::string text;
     WmPush last{}; bool have_last = false, in_flight = false;
@@ -1005,6 +1006,22 @@ int wmbus_collect(wmbus_ctx *c)
         if (a.algo != b.algo) return a.algo < b.algo;
         return a.seq < b.seq;
     });
+    /* Options (off by default: the drop-in prints what the reference prints).  Both framers work on every burst, so a
+     * clean telegram is printed twice, once per framer (README.md:105-108 "You will eventually get two identical
+     * datagrams"): dedup_twins drops the later of two lines of one capture and mode that carry the same payload, come
+     * from different framers and complete within one longest-telegram time of each other.  only_crc_ok drops what a
+     * consumer like wmbusmeters would discard anyway. */
+    if (c->cfg.dedup_twins || c->cfg.only_crc_ok) {
+        if (c->twins.empty()) c->twins.assign((size_t)c->S * 2 * 2, wm_twin{0, 0, 0, 0});
+        std::vector<LineRec> kept;
+        kept.reserve(all.size());
+        for (auto &r : all) {
+            if (c->cfg.only_crc_ok && !r.crc_ok) continue;
+            if (c->cfg.dedup_twins && wm_twin_check(&c->twins[((size_t)r.stream * 2 + r.chain) * 2], r.chain, r.algo, r.sample, r.text.data(), r.text.size())) continue;
+            kept.push_back(std::move(r));
+        }
+        all.swap(kept);
+    }
     for (auto &r : all) {
         wmbus_line l{};
         l.stream = r.stream; l.chain = r.chain; l.algo = r.algo; l.crc_ok = r.crc_ok; l.sample = r.sample;

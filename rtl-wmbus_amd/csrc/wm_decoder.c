@@ -268,6 +268,24 @@ size_t wm_decoder_format(wm_decoder *d, const char *algo_tag, const char *timest
     return w;
 }
 
+int wm_twin_check(wm_twin state[2], int chain, int algo, uint64_t sample, const char *text, size_t len)
+{
+    size_t x = len;
+    while (x >= 3 && !(text[x - 3] == ';' && text[x - 2] == '0' && text[x - 1] == 'x')) x--;
+    x = x >= 3 ? x - 3 : 0;                                   /* from ";0x" on: the payload */
+    uint64_t h = 1469598103934665603ull;                     /* FNV-1a */
+    for (size_t i = x; i < len; i++) h = (h ^ (uint8_t)text[i]) * 1099511628211ull;
+    /* decimated samples (800 kS/s) of the longest telegram: 290 bytes x 12 chips x 8 samples (T1), x 16 x 24 (S1) */
+    const uint64_t window = chain ? 16ull * 290 * 24 + 1024 : 12ull * 290 * 8 + 1024;
+    int twin = 0;
+    for (int k = 0; k < 2; k++)
+        if (state[k].valid && state[k].algo != algo && state[k].hash == h && sample - state[k].sample <= window) { twin = 1; state[k].valid = 0; }
+    if (twin) return 1;
+    const int slot = (!state[0].valid || (state[1].valid && state[0].sample <= state[1].sample)) ? 0 : 1;
+    state[slot].sample = sample; state[slot].hash = h; state[slot].algo = (uint8_t)algo; state[slot].valid = 1;
+    return 0;
+}
+
 void wm_timestamp(char *dst, size_t cap)
 {
     struct timeval tv;

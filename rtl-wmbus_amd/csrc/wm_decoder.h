@@ -60,6 +60,13 @@ size_t wm_packet_format(int mode, int c1, int frame_b, int err3of6, int crc_ok, 
 /* CRC verdict of an assembled telegram (t1_c1_packet_decoder.h:471-536). */
 int wm_packet_crc_ok(const uint8_t *packet, unsigned L, int frame_b);
 
+/* Twin filter (option cfg.dedup_twins; off by default).  Both framers work on every burst, so a clean telegram is
+ * printed twice (README.md:105-108: "You will eventually get two identical datagrams").  state: two records per
+ * (capture, chain), zero-initialised.  Returns 1 if this line is the later of two lines with the same payload (text
+ * from ";0x" on) from DIFFERENT framers whose completing samples lie within one longest-telegram time: drop it. */
+typedef struct wm_twin { uint64_t sample, hash; uint8_t algo, valid; } wm_twin;
+int wm_twin_check(wm_twin state[2], int chain, int algo, uint64_t sample, const char *text, size_t len);
+
 /* Wall-clock timestamp in the reference's format (rtl_wmbus_util.h:10-39). */
 void wm_timestamp(char *dst, size_t cap);
 

@@ -47,6 +47,8 @@ static void print_usage(const char *prog)
     fprintf(stdout, "\t-B bytes per GPU push (multiple of 4096, default 1048576)\n");
     fprintf(stdout, "\t-G HIP device ordinal (default 0); batch mode: 'all' or a list '0,2,5' shards the files, file i on device list[i mod n]\n");
     fprintf(stdout, "\t-M batch mode: print the file -> device map and exit\n");
+    fprintf(stdout, "\t-U unique: print a datagram that both the time2 and the run length method decoded only once\n");
+    fprintf(stdout, "\t-W like -U, and only datagrams with a correct CRC (what wmbusmeters keeps)\n");
     fprintf(stdout, "\t-A 1|2 atan2_approximation / atan2_approximation2 (atan2.h) instead of cargf in the discriminator\n");
     fprintf(stdout, "\t-P polyphase low-pass (ppf.h) instead of the moving average before decimation (1.6 MS/s, -d 2, no -s)\n");
     fprintf(stdout, "\t-T host:port read the cu8 stream from a TCP server instead of stdin\n");
@@ -254,7 +256,7 @@ int main(int argc, char **argv)
     cfg.max_push_bytes = 1u << 20;
     int check_flow = 0, opt, map_only = 0, devs[64], n_devs = 0;
     const char *tcp = NULL;
-    while ((opt = getopt(argc, argv, "ofad:p:r:vVst:B:G:PT:A:M")) != -1) {
+    while ((opt = getopt(argc, argv, "ofad:p:r:vVst:B:G:PT:A:MUW")) != -1) {
         switch (opt) {
         case 'o': cfg.remove_dc = 1; break;
         case 'f': check_flow = 1; break;
@@ -278,6 +280,8 @@ int main(int argc, char **argv)
             cfg.device = devs[0];
             break;
         case 'M': map_only = 1; break;
+        case 'U': cfg.dedup_twins = 1; break;
+        case 'W': cfg.dedup_twins = 1; cfg.only_crc_ok = 1; break;
         case 'P': cfg.prefilter = WMBUS_PREFILTER_POLYPHASE; break;
         case 'A': cfg.atan_mode = atoi(optarg); break;
         case 'T': tcp = optarg; break;

@@ -344,24 +344,81 @@ def test_cli_batch_mode_and_tcp_input(wm, oracle, samples, tmp_path):
     assert p.stdout.decode() == want["a.cu8"]
 
 
-def test_full_size_batch_properties(wm):
-    """BASELINE-size streams (2^22 samples) x 32: every complete strong burst comes out CRC-ok, nothing
-    CRC-ok comes out that was not sent, and the result does not depend on the segmentation."""
-    n_streams, n = 32, 1 << 22
+def test_full_size_batch_matches_the_oracle(wm, oracle):
+    """BASELINE configs[3] shape at an eighth of its width: 128 captures (two waves of 64: the clock kernel's cooperative
+    path, exactly one of bench.py's eight contexts) x 2^22 IQ samples, one push.  EVERY capture's text against the oracle
+    (farmed over the host's cores), plus the properties the synthetic recipe offers: every complete strong burst comes
+    out CRC-ok, nothing CRC-ok comes out that was not sent, and the result does not depend on the segmentation."""
+    n_streams, n = 128, 1 << 22
     caps, sent = [], []
     for s in range(n_streams):
         c, fr = wm.synth_capture(seed=0xC0FFEE + s, n_samples=n, kinds=7, frames_per_s=20.0)
         caps.append(c); sent.append(fr)
-    outs = []
-    for seg in (65536, 16384):
-        with wm.Receiver(n_streams=n_streams, max_push_bytes=2 * n, seg_len=seg, rla_seg_len=seg // 8) as rx:
-            outs.append(rx.run(caps))
-    assert outs[0] == outs[1]
+    want = oracle.run_many(caps, oracle.make_opts())
+    with wm.Receiver(n_streams=n_streams, max_push_bytes=2 * n) as rx:          # the default tuning, as bench.py runs it
+        got = rx.run(caps)
+        tim = rx.timing()
+    assert got == want
+    assert tim["slow_path"] == 0 and tim["warnings"] == 0
+    with wm.Receiver(n_streams=32, max_push_bytes=2 * n, seg_len=16384, rla_seg_len=2048) as rx:
+        assert rx.run(caps[:32]) == want[:32]
+    n_good = 0
     for s in range(n_streams):
-        good = {l.split(";")[-1][2:] for l in outs[0][s].splitlines() if l.split(";")[2] == "1"}
+        good = {l.split(";")[-1][2:] for l in got[s].splitlines() if l.split(";")[2] == "1"}
         tx = {f["telegram"].hex() for f in sent[s]}
         assert good <= tx
         assert all(f["telegram"].hex() in good for f in sent[s] if f["complete"])
+        n_good += len(good)
+    assert n_good > 20 * n_streams
+
+
+def test_c3_configuration_at_its_survey_size(wm, oracle):
+    """BASELINE configs[2] / SURVEY 8 C3: 4.0 MS/s, -d 5 -s, S1 + T1 + C1 chains concurrently, 2^22 IQ samples, all
+    four frame kinds placed at +-325 kHz; text, soft symbols, RSSI, slicer bits and every chip against the oracle."""
+    flags = ["-d", "5", "-s", "-v"]
+    cu8 = wm.synth_capture(seed=20260, n_samples=1 << 22, fs_khz=4000, kinds=15, frames_per_s=60.0, amplitude=60.0,
+                           t1c1_center_khz=325.0, s1_center_khz=-325.0)[0]
+    ref = oracle.run(cu8, flags_to_oracle_opts(oracle, flags), taps=True, chips=True)
+    modes = {l.split(";")[1] for l in ref["text"].splitlines() if l.split(";")[2] == "1"}
+    assert modes == {"T1", "C1", "S1"} and len(ref["text"].splitlines()) > 60
+    with wm.Receiver(n_streams=1, max_push_bytes=cu8.size, **flags_to_kwargs(flags)) as rx:
+        assert rx.run(cu8)[0] == ref["text"]
+        compare_taps(rx, ref)
+        compare_chips(rx, ref)
+    with wm.Receiver(n_streams=1, max_push_bytes=1 << 20, **flags_to_kwargs(flags)) as rx:
+        assert rx.run(cu8, push_bytes=1 << 20)[0] == ref["text"]           # eight pushes: 104 857.6 decimated samples each, ragged
+
+
+def test_cli_unique_and_crc_only_options(wm, samples):
+    """-U (twin de-duplication) and -W (that plus CRC-clean telegrams only): extensions, off by default."""
+    env = dict(os.environ, WMBUS_FIXED_TS="1")
+    cu8 = samples["samples2"].tobytes()
+    base = BUNDLED[f"{S2_NAME}|-v"].splitlines(True)
+    out = {}
+    for opt in ("-U", "-W"):
+        p = subprocess.run([wm.CLI_PATH, "-v", opt], input=cu8, capture_output=True, env=env)
+        assert p.returncode == 0, p.stderr
+        out[opt] = p.stdout.decode().splitlines(True)
+    assert out["-U"] == [base[0], base[2], base[3]]          # the 71200023 pair is identical: its run-length copy goes
+    assert out["-W"] == [base[0]]                             # the 64700082 lines fail their CRC
+
+
+def test_bench_runs_two_ranks_through_the_hip_library(wm, tmp_path):
+    """The N > 1 path of bench.py with the REAL back end (tests/gloo_worker.py, CPU-only, can only stand in the oracle):
+    `python bench.py --gpus 2` spawns its two ranks itself; on this one-GPU box both are pointed at device 0 and use
+    gloo for the barrier / reductions.  Rank r owns its own captures (seed offset), the JSON line reports n_gpus = 2 and
+    the whole-job rate, and the per-rank parity checks (every capture of the first pass) are reduced over the ranks."""
+    import json, sys
+    from conftest import ROOT
+    env = dict(os.environ, WMBUS_BENCH_BACKEND="gloo", WMBUS_BENCH_DEVICE="0")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--streams", "128",
+                        "--samples", str(1 << 20), "--contexts", "2", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["parity"]["ok"] and line["parity"]["ranks"] == 2 and line["parity"]["first_pass"]["captures_compared"] == 128
+    assert line["datagrams_per_step"] > 100
 
 
 @pytest.mark.gpu

@@ -55,3 +55,26 @@ def test_crc16_known_answer(wm):
     L.wm_crc16.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
     # first block of the samples2 telegram: CRC-16/EN-13757 check value
     assert L.wm_crc16(b"123456789", 9) == 0xC2B7
+
+
+def test_twin_filter_drops_the_second_of_a_pair(wm):
+    """cfg.dedup_twins / CLI -U (README.md:105-108): the later of two lines with the same payload from
+    different framers within one telegram time goes; different payloads, the same framer, or a long gap stay."""
+    import ctypes, json, os
+    from conftest import GOLDEN
+    L = wm.lib()
+
+    class Twin(ctypes.Structure):
+        _fields_ = [("sample", ctypes.c_uint64), ("hash", ctypes.c_uint64), ("algo", ctypes.c_uint8), ("valid", ctypes.c_uint8)]
+    L.wm_twin_check.argtypes = [ctypes.POINTER(Twin), ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_size_t]
+    lines = json.load(open(os.path.join(GOLDEN, "bundled.json")))["rtlsdr_868.950M_1M6_samples2.cu8|-v"].splitlines(True)
+    assert len(lines) == 4 and lines[0].split(";")[-1] == lines[1].split(";")[-1] and lines[2].split(";")[-1] != lines[3].split(";")[-1]
+    st = (Twin * 2)()
+    drop = [L.wm_twin_check(st, 0, 1 if ln.startswith("t2a") else 0, 1000 + 10 * k, ln.encode(), len(ln)) for k, ln in enumerate(lines)]
+    assert drop == [0, 1, 0, 0]                               # the 71200023 twin goes; the 64700082 pair differs in its last bytes
+    st = (Twin * 2)()
+    a, b = lines[0].encode(), lines[1].encode()
+    assert L.wm_twin_check(st, 0, 1, 10, a, len(a)) == 0
+    assert L.wm_twin_check(st, 0, 1, 20, a, len(a)) == 0      # the same framer again: a repeated transmission, kept
+    assert L.wm_twin_check(st, 0, 0, 10 + 12 * 290 * 8 + 5000, b, len(b)) == 0     # the other framer, but a telegram time later: kept
+    assert L.wm_twin_check(st, 0, 1, 10 + 12 * 290 * 8 + 5100, a, len(a)) == 1     # ... and ITS twin goes
