@@ -311,6 +311,26 @@ def main():
         parity["ranks"] = world
         parity["ok"] = n_bad == 0
 
+    # VALU roofline (BASELINE.md section 3 asks for it next to the HBM one; it is the roof that binds): wave-instructions per
+    # input sample from the committed SQ_INSTS_VALU pass (profiles/valu.json) x the samples of a launch / the HIP-event
+    # duration measured live above; peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction.
+    valu = None
+    vf = os.path.join(ROOT, "profiles", "valu.json")
+    if os.path.exists(vf) and k1_avg_s > 0:
+        try:
+            vj = json.load(open(vf))
+            peak = float(vj["peak_T_wave_instr_per_s"])
+            wi = vj["k1_valu_wave_instr_per_input_sample"] * samples_per_launch
+            wj = vj["job_valu_wave_instr_per_input_sample"] * S * n
+            valu = {"kernel": "k1_demod2", "wave_instr_per_launch": int(wi), "achieved_T_per_s": round(wi / k1_avg_s / 1e12, 4), "peak": peak,
+                    "frac": round(wi / k1_avg_s / 1e12 / peak, 4),
+                    "whole_job": {"wave_instr_per_step": int(wj), "achieved_T_per_s": round(wj / (elapsed / a.steps) / 1e12, 4),
+                                  "frac": round(wj / (elapsed / a.steps) / 1e12 / peak, 4)},
+                    "how": "SQ_INSTS_VALU per launch from the committed rocprofv3 --pmc pass (profiles/valu.json, profiles/*_pmc_sq_counters.csv) / "
+                           "the HIP-event duration of this run; peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction"}
+        except Exception:
+            valu = None
+
     if rank == 0:
         last = tim_acc[-1]
         out = {
@@ -332,6 +352,11 @@ def main():
                          "in_timed_region": {"avg_launch_ms": round(k1_concurrent_ms, 3), "launches": k1_launches,
                                              "achieved": round(BYTES_PER_SAMPLE * samples_per_launch / max(k1_concurrent_ms, 1e-9) / 1e6, 1),
                                              "frac": round(BYTES_PER_SAMPLE * samples_per_launch / max(k1_concurrent_ms, 1e-9) / 1e6 / HBM_PEAK_GBPS, 4)},
+                         "valu": valu,
+                         "dominant": "k1_demod2 is the largest kernel of the job by work (two thirds of its VALU instructions; 20 of the 45 ms the "
+                                     "kernels take one after the other, profiles/*_single_context_kernel_stats.csv) and the one the roofline is quoted "
+                                     "for; in this 8-context configuration the framer kernels (k2_clock, k2_clock_rla) are RESIDENT longer (about 60 % of "
+                                     "the summed kernel durations, profiles/*_bench_kernel_stats.csv) because they are latency-bound and overlap it",
                          "how": "HIP events around k1_demod2 on the library's stream, one context at a time after the timed "
                                 "region (inside it a launch runs beside the other contexts' kernels: avg %.3f ms each)" % k1_concurrent_ms},
             "stage_ms_last_step": [{k: round(v, 3) if isinstance(v, float) else v for k, v in t.items()} for t in last],

@@ -642,7 +642,9 @@ static int launch_k3(wmbus_ctx *c, bool again)
         k3.pkts = (WmPkt *)c->dv_pkts; k3.pkts_cap = c->pkts_cap; k3.bytes = (uint8_t *)c->dv_bytes; k3.bytes_cap = c->bytes_cap;
         k3.n_pkts = c->d_scalars + SC_NPKTS; k3.n_bytes = c->d_scalars + SC_NBYTES;
     }
-    static const uint32_t max_blocks = getenv("WMBUS_K3_BLOCKS") ? (uint32_t)atoi(getenv("WMBUS_K3_BLOCKS")) : 256u;   /* tuning aid; 128 ... 512 are within 2 % of each other */
+    /* Few blocks: a latency-bound wave parked on a SIMD costs the demodulation kernel one of its eight wave slots there
+     * for as long as it lives; 256 blocks put one on every SIMD of the chip (r02 sweep: 256 -> 64 blocks + 6 %, 16 blocks - 9 %: then the kernel itself becomes the longest link of the chain) */
+    static const uint32_t max_blocks = getenv("WMBUS_K3_BLOCKS") ? (uint32_t)atoi(getenv("WMBUS_K3_BLOCKS")) : 64u;
     const uint32_t most = 4 * c->S + c->hits_cap;
     hipLaunchKernelGGL(k3_bursts, dim3(std::max(1u, std::min((most + 3u) / 4u, max_blocks))), dim3(256), 0, c->stream, k3, 0xFFFFFFFFu);
     HIPCHK(c, hipGetLastError());
@@ -734,7 +736,10 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
         kr.algo = WMBUS_ALGO_RLA;
         kr.chips = c->d_chips[0]; kr.counts = c->d_counts[0]; kr.sync_seen = c->d_sync_seen[0];
         kr.st_start = c->d_st_start[0]; kr.st_final = c->d_st_final[0]; kr.st_carry = st_carry(c, 0, false);
-        static const bool fuse = !(getenv("WMBUS_FUSE_FRAMERS") && atoi(getenv("WMBUS_FUSE_FRAMERS")) == 0);   /* tuning aid */
+        /* fused framer launches (clock re-run lanes + run-length framer in one launch) were worth 4 ms of a context's
+         * dependent chain while every round cost a host round trip; with the rounds enqueued unattended the plain
+         * sequence is 6 % faster for the whole job (r02 sweep: 144.6 / 140.8 against 135.2 / 133.6 Gsamples/s) */
+        static const bool fuse = getenv("WMBUS_FUSE_FRAMERS") && atoi(getenv("WMBUS_FUSE_FRAMERS")) != 0;   /* tuning aid */
         const bool rla = c->flags & WM_F_RLA;
         c->fused = rla && !(c->flags & WM_F_DC) && fuse;
         HIPCHK(c, hipEventRecord(c->ev[0], c->stream));

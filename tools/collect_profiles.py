@@ -10,7 +10,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
 COPIES = [("trace/bench_kernel_stats.csv", "bench_kernel_stats.csv"),
           ("trace/bench_domain_stats.csv", "bench_domain_stats.csv"),
@@ -18,7 +18,8 @@ COPIES = [("trace/bench_kernel_stats.csv", "bench_kernel_stats.csv"),
           ("trace1/single_kernel_stats.csv", "single_context_kernel_stats.csv"),
           ("single_context_under_rocprof.json", "single_context_under_rocprof.json"),
           ("pmc_fetch_size.csv", "pmc_fetch_size.csv"),
-          ("pmc_write_size.csv", "pmc_write_size.csv")]
+          ("pmc_write_size.csv", "pmc_write_size.csv"),
+          ("pmc_sq.csv", "pmc_sq_counters.csv")]
 for src, dst in COPIES:
     p = os.path.join(SRC, src)
     if os.path.exists(p):
@@ -63,6 +64,37 @@ def pick(d, prefix):
             s += kb
     return n, s
 
+
+# ---- VALU roofline inputs: wave-instructions per launch from the SQ counter pass (single context: 1024 captures per launch)
+sqp = os.path.join(SRC, "pmc_sq.csv")
+if os.path.exists(sqp):
+    S, N = 1024, 1 << 22
+    per = {}
+    for r in csv.DictReader(open(sqp)):
+        base = r["kernel"].split("<")[0]
+        d = per.setdefault(base, {"launches": 0, "avg_ms_under_pmc": 0.0})
+        d[r["counter"]] = d.get(r["counter"], 0.0) + float(r["sum"])
+        if r["counter"] == "SQ_INSTS_VALU":
+            d["launches"] += int(r["launches"]); d["avg_ms_under_pmc"] = max(d["avg_ms_under_pmc"], float(r["avg_ms_under_pmc"]))
+    steps = 2                                  # bench.py --steps 1 --warmup 0: the timed step + the un-overlapped calibration pass
+    valu = {"run": f"bench.py --contexts 1 --steps 1 --warmup 0: {S} captures x 2^22 IQ samples per launch, {steps} passes",
+            "peak_T_wave_instr_per_s": 1.2288,
+            "peak_how": "1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md: SIMD-32, v_fma_f32 2 cyc)",
+            "kernels": {}}
+    for k, d in per.items():
+        if not any(k.startswith(x) for x in ("k1_demod2", "k2_clock", "k2_rla", "k3_", "k2_verify")):
+            continue
+        valu["kernels"][k] = {"valu_wave_instr_per_step": d.get("SQ_INSTS_VALU", 0) / steps, "salu_per_step": d.get("SQ_INSTS_SALU", 0) / steps,
+                              "lds_instr_per_step": d.get("SQ_INSTS_LDS", 0) / steps, "waves_per_step": d.get("SQ_WAVES", 0) / steps,
+                              "wave_quad_cycles_per_step": d.get("SQ_WAVE_CYCLES", 0) / steps,
+                              "active_valu_quad_cycles_per_step": d.get("SQ_ACTIVE_INST_VALU", 0) / steps,
+                              "wait_inst_any_quad_cycles_per_step": d.get("SQ_WAIT_INST_ANY", 0) / steps,
+                              "wait_any_quad_cycles_per_step": d.get("SQ_WAIT_ANY", 0) / steps}
+    k1 = valu["kernels"].get("k1_demod2", {})
+    valu["k1_valu_wave_instr_per_input_sample"] = k1.get("valu_wave_instr_per_step", 0) / (S * N)
+    valu["job_valu_wave_instr_per_input_sample"] = sum(v["valu_wave_instr_per_step"] for v in valu["kernels"].values()) / (S * N)
+    json.dump(valu, open(os.path.join(DST, "valu.json"), "w"), indent=1)
+    print(json.dumps({k: v for k, v in valu.items() if k != "kernels"}, indent=1))
 
 n_k1, f_k1 = pick(fetch, "k1_demod2")
 _, w_k1 = pick(write, "k1_demod2")

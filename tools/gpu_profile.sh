@@ -12,10 +12,34 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $ctr --kernel-trace --stats -d $R/gpurun_out/prof/pmc_$ctr -o pmc --output-format csv -- python $R/bench.py --steps 1 --warmup 0 --contexts 1 --no-cpu-baseline --no-check > $R/gpurun_out/prof/pmc_$ctr.log 2>&1
   echo "$ctr rc=$?"
 done
+# (3) SQ counters of the same single-context run (1024 captures per launch), each group in its own pass: what the VALU
+# roofline of the bench line is computed from (instruction counts) and what the waves spend their time on
+i=0
+for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC" ; do
+  i=$((i+1))
+  timeout 600 rocprofv3 --pmc $grp --kernel-trace --stats -d $R/gpurun_out/prof/pmc_sq$i -o pmc --output-format csv -- python $R/bench.py --steps 1 --warmup 0 --contexts 1 --no-cpu-baseline --no-check > $R/gpurun_out/prof/pmc_sq$i.log 2>&1
+  echo "SQ group $i rc=$?"
+done
 python3 - <<'PY'
 import csv,os,collections,json
 R=os.environ['GRAFT_REPO_ROOT']+'/gpurun_out/prof'
 out={}
+sq=collections.defaultdict(lambda: collections.defaultdict(list)); durs=collections.defaultdict(list)
+for i in (1,2):
+    p=f'{R}/pmc_sq{i}/pmc_counter_collection.csv'
+    if not os.path.exists(p): continue
+    seen=set()
+    for r in csv.DictReader(open(p)):
+        k=r['Kernel_Name'].split('(')[0].replace('void ','')
+        sq[k][r['Counter_Name']].append(float(r['Counter_Value']))
+        if i==1 and r['Dispatch_Id'] not in seen:
+            seen.add(r['Dispatch_Id']); durs[k].append((int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e6)
+with open(f'{R}/pmc_sq.csv','w') as f:
+    f.write('kernel,launches,avg_ms_under_pmc,counter,sum,avg_per_launch\n')
+    for k,d in sorted(sq.items()):
+        for c,v in sorted(d.items()):
+            f.write(f'"{k}",{len(v)},{(sum(durs[k])/max(1,len(durs[k]))):.4f},{c},{sum(v):.0f},{sum(v)/len(v):.0f}\n')
 for ctr in ('FETCH_SIZE','WRITE_SIZE'):
     agg=collections.defaultdict(list)
     for r in csv.DictReader(open(f'{R}/pmc_{ctr}/pmc_counter_collection.csv')):
