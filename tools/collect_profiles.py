@@ -59,6 +59,8 @@ def pick(d, prefix):
     n = s = 0
     for k, (ln, kb) in d.items():
         base = k.replace("void ", "").split("(")[0].split("<")[0]
+        if prefix == "k1_demod2" and k.rstrip().endswith("true>"):
+            continue                                   # the option / repair variant of the kernel (empty list launches here)
         if base == prefix:
             n += ln
             s += kb
@@ -71,6 +73,8 @@ if os.path.exists(sqp):
     S, N = 1024, 1 << 22
     per = {}
     for r in csv.DictReader(open(sqp)):
+        if r["kernel"].rstrip().endswith("true>") and r["kernel"].startswith("k1_demod2"):
+            continue                                   # repair / option variant: empty list launches
         base = r["kernel"].split("<")[0]
         d = per.setdefault(base, {"launches": 0, "avg_ms_under_pmc": 0.0})
         d[r["counter"]] = d.get(r["counter"], 0.0) + float(r["sum"])
