@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--rla-seg-len", type=int, default=0)
     ap.add_argument("--warmup-s1", type=int, default=0)
     ap.add_argument("--warmup-t1c1", type=int, default=0)
+    ap.add_argument("--rla-lookback", type=int, default=0)
     ap.add_argument("--contexts", type=int, default=8, help="receiver contexts per GPU (GPU / host-decode overlap)")
     ap.add_argument("--stagger", type=float, default=0.0, help="seconds between context starts (the contexts' turns in the demodulation kernel stagger them anyway)")
     ap.add_argument("--from-host", action="store_true",
@@ -174,7 +175,7 @@ def main():
         # oversubscribed: the contexts do not decode at the same time)
         host_threads = a.host_threads or max(4, min(32, 2 * (os.cpu_count() or 16) // max(1, world * nctx)))
         rx = wm.Receiver(n_streams=per_ctx[i], max_push_bytes=push_bytes, device=local, seg_len=a.seg_len, rla_seg_len=a.rla_seg_len,
-                         warmup_s1=a.warmup_s1, warmup_t1c1=a.warmup_t1c1, show_algorithm=True, fixed_timestamp=True,
+                         warmup_s1=a.warmup_s1, warmup_t1c1=a.warmup_t1c1, rla_lookback=a.rla_lookback, show_algorithm=True, fixed_timestamp=True,
                          host_threads=host_threads, input_windows=2 if a.from_host else 1)
         for s in range(per_ctx[i]):
             rx.stage(s, caps[base + s])
