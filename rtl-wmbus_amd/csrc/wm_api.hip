@@ -522,6 +522,7 @@ int wmbus_stage(wmbus_ctx *c, unsigned stream, const uint8_t *cu8, size_t nbytes
     if (nbytes > c->cfg.max_push_bytes || nbytes % WMBUS_BLOCK_BYTES) return fail(c, WMBUS_EINVAL, "stage: nbytes must be a multiple of 4096 and <= max_push_bytes");
     /* with one input window the kernels of a push in flight still read it; with two (cfg.input_windows = 2) the next
      * push is staged into the other one while they run */
+    HIPCHK(c, hipSetDevice(c->cfg.device));
     if (c->in_flight && c->n_win == 1) return fail(c, WMBUS_EINVAL, "stage: a push is in flight and the context has one input window (cfg.input_windows = 2 overlaps them)");
     HIPCHK(c, hipMemcpyAsync(wmbus_device_input(c, stream), cu8, nbytes, hipMemcpyHostToDevice, c->copy_stream));
     return WMBUS_OK;
@@ -657,6 +658,7 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
     if (nbytes == 0 || nbytes > c->cfg.max_push_bytes || nbytes % WMBUS_BLOCK_BYTES)
         return fail(c, WMBUS_EINVAL, "process: nbytes must be a positive multiple of 4096 and <= max_push_bytes");
     if (c->in_flight) return fail(c, WMBUS_EINVAL, "process: previous push not collected");
+    HIPCHK(c, hipSetDevice(c->cfg.device));            /* HIP's current device is per host thread; a context may be driven from any */
     if (c->poisoned) return fail(c, WMBUS_EDEVICE, "process: an earlier internal error left this context unusable; close it");
     c->tim = wmbus_timing{};
     if (c->committed) { c->carry_in ^= 1u; c->committed = false; }     /* the previous push's end state is this one's start state */
@@ -934,6 +936,7 @@ int wmbus_collect(wmbus_ctx *c)
     c->lines.clear(); c->text.clear();
     c->short_burst.store(0);
     if (!c->in_flight) return WMBUS_OK;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->in_flight = false;
     if (c->last.M > 0) {

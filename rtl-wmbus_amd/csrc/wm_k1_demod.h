@@ -165,9 +165,14 @@ __device__ __forceinline__ void k1_fir_s(const K1Args &a, const float *yDrS, con
  * rtl_wmbus.c:475-495, + hand-off certification) of a 976-sample tile; shared by the moving-average
  * and the polyphase front ends.  Rows: element a of a discriminator row at word a + 4, of a
  * magnitude row at a + a/16 (the two chains' rows may alias when they carry the same data).
- * Work split: waves 0 and 1 run one chain's EMA each (16 samples per lane behind the warm-up) and
- * the 11-tap FIR of half the tile; waves 2 and 3 the 46-tap FIR of half the tile each -- 630 against
- * 860 instructions, instead of 960 on the EMA waves and 530 on the others. */
+ * Work split (WM_K1_BALANCED, the default): every wave runs ONE quarter of the 46-tap FIR (the largest item: 4 x 92
+ * operations per lane); waves 0 and 1 add one chain's EMA each (16 samples per lane behind the warm-up), waves 2 and 3
+ * half of the 11-tap FIR each -- about 570 against 545 instructions.  (Second generation: EMA + half of the 11-tap
+ * FIR against half of the 46-tap FIR, 380 against 740: the light waves sat at the barrier for a quarter of the
+ * tile's time, holding their wave slots; first generation 960 against 530.) */
+#ifndef WM_K1_BALANCED
+#define WM_K1_BALANCED 1
+#endif
 template <bool GEN>
 __device__ __forceinline__ void k1_stage_b(const K1Args &a, const int tid, const int tile, const int stream, const int ts, const int tn,
                                            const bool chT, const bool chS, const float *yDrT, const float *yDrS,
@@ -235,7 +240,11 @@ __device__ __forceinline__ void k1_stage_b(const K1Args &a, const int tid, const
                 *(uint4 *)(a.rssi + row * g.Mcap + ts + m0l) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
             sFin[rt] = ema; sHead[rt] = head;
         }
-        if (chT) { k1_fir_t(a, yDrT, 128 * wv + e, stream, ts, tn); k1_fir_t(a, yDrT, 128 * wv + 64 + e, stream, ts, tn); }
+        if (WM_K1_BALANCED) { if (chS) k1_fir_s(a, yDrS, 64 * wv + e, stream, ts, tn); }
+        else if (chT) { k1_fir_t(a, yDrT, 128 * wv + e, stream, ts, tn); k1_fir_t(a, yDrT, 128 * wv + 64 + e, stream, ts, tn); }
+    } else if (WM_K1_BALANCED) {
+        if (chS) k1_fir_s(a, yDrS, 64 * wv + e, stream, ts, tn);
+        if (chT) { k1_fir_t(a, yDrT, 128 * (wv - 2) + e, stream, ts, tn); k1_fir_t(a, yDrT, 128 * (wv - 2) + 64 + e, stream, ts, tn); }
     } else if (chS) {
         k1_fir_s(a, yDrS, 128 * (wv - 2) + e, stream, ts, tn);
         k1_fir_s(a, yDrS, 128 * (wv - 2) + 64 + e, stream, ts, tn);
