@@ -674,6 +674,8 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
         g.seg_len[al] = c->C[al]; g.nseg[al] = (g.M + c->C[al] - 1) / c->C[al]; g.nseg_cap[al] = c->nseg_cap[al]; g.cap[al] = c->cap[al];
     }
     g.warm[0] = c->cfg.warmup_t1c1; g.warm[1] = c->cfg.warmup_s1; g.lookback = c->cfg.rla_lookback;
+    static const uint32_t s1_span = getenv("WMBUS_S1_SPAN") ? (uint32_t)atoi(getenv("WMBUS_S1_SPAN")) : 1u;    /* tuning aid, see WmPush.s1_span */
+    g.s1_span = s1_span;
     g.sp.arena = c->d_spill; g.sp.arena_words = c->spill_words; g.sp.chain = c->d_chain; g.sp.nchain = c->d_nchain;
     g.sp.used = c->d_nchain + (size_t)2 * c->S * c->nseg_cap[0];
     c->last = g; c->have_last = true;

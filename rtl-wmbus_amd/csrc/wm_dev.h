@@ -102,6 +102,8 @@ struct WmPush {
     uint32_t cap[2];         /* chips per segment region                              */
     uint32_t warm[2];        /* IIR warm-up per chain                                 */
     uint32_t lookback;       /* RLA speculative lookback                              */
+    uint32_t s1_span;        /* 2: an S1 clock lane covers two consecutive segments (its warm-up is twice T1/C1's, so at the
+                                same segment length it re-reads 75 % instead of 37 %); 0 / 1: one segment per lane */
     WmSpill sp;              /* run-length chips beyond cap[0]                        */
 };
 

@@ -197,10 +197,19 @@ __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t bloc
     lane_decode(g, 1, lane, ch, stream, seg);
     if (!(g.flags & (ch ? WM_F_S1 : WM_F_T1C1))) return;
 
+    /* S1 lanes may span two segments (WmPush.s1_span): the odd segment rides with its even predecessor.  The lane then
+     * owns both segments' chip regions, checkpoint slots and hand-off records (they are adjacent): chips and count go to
+     * the even one (the odd one's count is 0), the end state to the odd one's record, and the pair (final[even],
+     * start[odd]) is set to one constant so that the verifier, which knows nothing of this, sees a certified hand-off. */
+    const uint32_t span = (ch == 1u && g.s1_span == 2u) ? 2u : 1u;
+    if (seg % span) return;
     const uint64_t row = (uint64_t)ch * g.S + stream;
     const uint64_t sidx = row * g.nseg_cap[1] + seg;
-    const uint32_t mb = seg * g.seg_len[1], me = min(g.M, mb + g.seg_len[1]);
-    const uint32_t cap_t2 = g.cap[1];
+    const uint32_t mb = seg * g.seg_len[1], me = min(g.M, mb + span * g.seg_len[1]);
+    const uint32_t covered = (me - mb + g.seg_len[1] - 1u) / g.seg_len[1];          /* segments this lane really covers: 1 or 2 */
+    const uint32_t cap_t2 = covered * g.cap[1];
+    const uint32_t nck = covered == 2u ? 2u * a.nck : a.nck;                          /* checkpoint slots (one interior point of a pair has none) */
+    const uint64_t sidxF = sidx + covered - 1u;                                       /* where the end state goes */
     WmClkState *stS = (WmClkState *)a.st_start, *stF = (WmClkState *)a.st_final, *stC = (WmClkState *)a.st_carry;
 
     WmClkState s;
@@ -220,7 +229,7 @@ __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t bloc
     const float *xc = a.dphi + (row0 + (ln >> 3)) * g.Mcap + 4u * (ln & 7u);
     const uint64_t xc_step = 8ull * g.Mcap;
     const uint32_t syncw = ch ? WM_SYNC_S1 : WM_SYNC_T1C1, syncm = ch ? WM_SYNC_S1_MASK : WM_SYNC_T1C1_MASK;
-    uint32_t *out = a.chips + sidx * cap_t2;
+    uint32_t *out = a.chips + sidx * g.cap[1];            /* region pitch (cap_t2 may be two regions) */
     uint32_t *bw = a.bits + row * (g.Mcap / 32);
     uint32_t n_out = 0, saw_sync = 0;
 
@@ -354,7 +363,7 @@ __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t bloc
             main_block(gxA);
             if (m < stop) main_block(gxB);
         }
-        if (m < me_full && j < a.nck) {                  /* interior checkpoint j */
+        if (m < me_full && j < nck) {                    /* interior checkpoint j */
             uint32_t *q = ck + 16u * j;
             const uint32_t *sw = (const uint32_t *)&s;
             if (!rerun) {
@@ -382,7 +391,7 @@ __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t bloc
                         a.counts[sidx] = n1 + (total0 - n0);
                         /* this and the later checkpoints describe the tail, which has moved: a later
                          * round may re-run this segment again and meet them */
-                        for (uint32_t jj = j; jj < a.nck; jj++) ck[16u * jj + 12u] -= n0 - n1;
+                        for (uint32_t jj = j; jj < nck; jj++) ck[16u * jj + 12u] -= n0 - n1;
                     }
                     if (saw_sync) a.sync_seen[sidx] = 1u;       /* the tail's flag, if any, is already set */
                     return;
@@ -415,7 +424,8 @@ __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t bloc
         bw[m >> 5] = bitw;
         emit_block(m, smask, bitw, true);
     }
-    stF[sidx] = s;
+    stF[sidxF] = s;
+    if (covered == 2u) { const WmClkState none = {}; stF[sidx] = none; stS[sidx + 1u] = none; a.counts[sidx + 1u] = 0u; }
     a.counts[sidx] = min(n_out, cap_t2);
     if (saw_sync) a.sync_seen[sidx] = 1u;
     if (n_out > cap_t2) atomicOr(a.err, WM_ERR_CHIP_OVERFLOW);       /* cannot happen: the lock pattern takes >= 4 samples per chip */

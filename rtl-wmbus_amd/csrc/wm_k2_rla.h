@@ -229,7 +229,10 @@ __device__ __forceinline__ void rla_lanes(const K2Args &a, const uint32_t block_
     if (n_stored < n_out) atomicOr(a.err, WM_ERR_CHIP_TRUNC);     /* a warning: the framer state is exact, some chips of this segment are lost */
 }
 
-__global__ __launch_bounds__(64 * WM_RLA_WPB) void k2_rla(K2Args a)
+#ifndef WM_RLA_WAVES_PER_SIMD
+#define WM_RLA_WAVES_PER_SIMD 1        /* 8: at most 64 VGPRs (build-time experiment) */
+#endif
+__global__ __launch_bounds__(64 * WM_RLA_WPB, WM_RLA_WAVES_PER_SIMD) void k2_rla(K2Args a)
 {
     __shared__ RlaLds lds;
     const uint32_t n = k2_lane_count(a);

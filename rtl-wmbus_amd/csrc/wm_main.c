@@ -11,8 +11,8 @@
  * -G HIP device ordinal, -P polyphase pre-filter, -T host:port (cu8 over TCP, e.g. a raw IQ server;
  * the role of the reference's unused net_support.h:15-44 / rtl_wmbus.c:1281), and
  *   rtl_wmbus_hip [switches] a.cu8 b.cu8 ...      batch mode: one capture per file, all of them in
- * lock step on one GPU, lines prefixed "a.cu8: "; a reader thread fills one pinned slab while the
- * GPU works on the other (double-buffered H2D).  With -G all (or -G 0,2,5) batch mode shards the files over the
+ * lock step on one GPU, lines prefixed "a.cu8: "; while the GPU works on one pinned slab the next one is read and
+ * staged into the context's second input window (double-buffered H2D on the copy stream).  With -G all (or -G 0,2,5) batch mode shards the files over the
  * GPUs of the node, file i on device list[i mod n] (file-per-GPU, no collective): one receiver
  * context and one worker thread per device, each file's lines in its own order.  -M prints that map and exits.
  */
@@ -102,9 +102,6 @@ static void batch_fill(struct batch *b, int k)
     b->filled[k] = most;
 }
 
-struct fill_job { struct batch *b; int k; };
-static void *fill_thread(void *p) { struct fill_job *j = p; batch_fill(j->b, j->k); return NULL; }
-
 static pthread_mutex_t out_lock = PTHREAD_MUTEX_INITIALIZER;      /* one push's lines leave as a unit */
 
 /* The reference never stops on an input; neither do we: exhausted chip / burst storage is reported once and the
@@ -135,6 +132,7 @@ static int run_batch(wmbus_cfg cfg, int n, char **names)
         b.live[s] = 1;
     }
     cfg.n_streams = (unsigned)n;
+    cfg.input_windows = 2;
     wmbus_ctx *ctx = NULL;
     if (wmbus_open(&cfg, &ctx)) {
         fprintf(stderr, "rtl_wmbus_hip: cannot open GPU back end: %s\n", ctx ? wmbus_last_error(ctx) : "out of memory");
@@ -145,15 +143,21 @@ static int run_batch(wmbus_cfg cfg, int n, char **names)
         b.slab[k] = wmbus_alloc_pinned((size_t)n * b.push);
         if (!b.slab[k]) { fprintf(stderr, "rtl_wmbus_hip: cannot allocate pinned staging\n"); return EXIT_FAILURE; }
     }
-    int rc = 0, cur = 0;
+    /* wmbus_process only enqueues: while the GPU works on one slab this thread reads the next one from the files and
+     * stages it into the context's other input window (cfg.input_windows = 2: the copies run on their own stream) */
+    int rc = 0, cur = 0, staged = 0;
     batch_fill(&b, cur);
     while (b.filled[cur] && !rc) {
-        pthread_t th;
-        struct fill_job job = {&b, cur ^ 1};
-        pthread_create(&th, NULL, fill_thread, &job);            /* next slab while the GPU works */
         const size_t nbytes = b.filled[cur];
-        for (int s = 0; s < n && !rc; s++) rc = wmbus_stage(ctx, (unsigned)s, b.slab[cur] + (size_t)s * b.push, nbytes);
+        for (int s = 0; s < n && !rc && !staged; s++) rc = wmbus_stage(ctx, (unsigned)s, b.slab[cur] + (size_t)s * b.push, nbytes);
         if (!rc) rc = wmbus_process(ctx, nbytes);
+        staged = 0;
+        if (!rc) {
+            batch_fill(&b, cur ^ 1);
+            for (int s = 0; s < n && !rc && b.filled[cur ^ 1]; s++)
+                rc = wmbus_stage(ctx, (unsigned)s, b.slab[cur ^ 1] + (size_t)s * b.push, b.filled[cur ^ 1]);
+            staged = b.filled[cur ^ 1] != 0;
+        }
         if (!rc) rc = wmbus_collect(ctx);
         if (rc) fprintf(stderr, "rtl_wmbus_hip: %s\n", wmbus_last_error(ctx));
         else {
@@ -170,7 +174,6 @@ static int run_batch(wmbus_cfg cfg, int n, char **names)
             fflush(stdout);
             pthread_mutex_unlock(&out_lock);
         }
-        pthread_join(th, NULL);
         cur ^= 1;
     }
     for (int k = 0; k < 2; k++) wmbus_free_pinned(b.slab[k]);

@@ -43,6 +43,7 @@ using std::min;
 extern "C" {
 
 int wm_emu_descending = 1;
+int wm_emu_s1_span = 0;                   /* WmPush.s1_span of the next calls */
 uint32_t *wm_emu_seen_out = nullptr;      /* optional: receives the per-region "access-code chip seen" flags */
 int wm_emu_lean_reruns = 0;
 
@@ -56,7 +57,7 @@ long wm_emu_clock(const float *dphi, uint32_t S, uint32_t M, uint32_t Mcap, uint
     WmPush g{};
     g.M = M; g.Mcap = Mcap; g.S = S; g.flags = flags; g.d = 2;
     g.seg_len[1] = seg_len; g.nseg[1] = (M + seg_len - 1) / seg_len; g.nseg_cap[1] = g.nseg[1]; g.cap[1] = cap;
-    g.warm[0] = warm0; g.warm[1] = warm1;
+    g.warm[0] = warm0; g.warm[1] = warm1; g.s1_span = (uint32_t)wm_emu_s1_span;
     const uint32_t rows = 2 * S, nseg = g.nseg[1], lanes = rows * nseg;
     const uint32_t nck = seg_len / WM_CK_SAMPLES ? seg_len / WM_CK_SAMPLES - 1 : 0;
     std::vector<WmClkState> st_start((size_t)rows * nseg), st_final((size_t)rows * nseg);

@@ -31,10 +31,11 @@ def emu():
     return L
 
 
-def run_emulated(emu, soft_rows, pushes, seg_len, warm, dc=False, descending=True, lean_reruns=False):
+def run_emulated(emu, soft_rows, pushes, seg_len, warm, dc=False, descending=True, lean_reruns=False, s1_span=None):
     """soft_rows: [2][M] float32 FIR outputs of one capture; pushes: decimated samples per push."""
     ctypes.c_int.in_dll(emu, "wm_emu_descending").value = int(descending)   # see clock_emu.cpp: launch semantics
     ctypes.c_int.in_dll(emu, "wm_emu_lean_reruns").value = int(lean_reruns)  # per-sample block in re-run launches (WM_FUSED_LEAN_CLOCK)
+    ctypes.c_int.in_dll(emu, "wm_emu_s1_span").value = int(s1_span or 0)     # WmPush.s1_span: S1 lanes cover two segments
     sb = emu.wm_emu_clock_state_bytes()
     carry = np.zeros(2 * sb, np.uint8)                     # a fresh context starts from the all-zero state
     chips_out, bits_out, m0, reruns, max_rounds = [[], []], [[], []], 0, 0, 0
@@ -58,7 +59,7 @@ def run_emulated(emu, soft_rows, pushes, seg_len, warm, dc=False, descending=Tru
         for ch in range(2):
             bits_out[ch].append(np.unpackbits(bits[ch].view(np.uint8), bitorder="little")[:M])
             for s in range(nseg):
-                w = chips[ch, s, :counts[ch, s]]
+                w = chips[ch].reshape(-1)[s * cap: s * cap + counts[ch, s]]       # an S1 lane spanning two segments fills both regions from the first
                 chips_out[ch].append(np.stack([m0 + s * seg_len + (w >> 3), w & 7], axis=1))
         m0 += M
     return ([np.concatenate(o) if o else np.zeros((0, 2), np.uint32) for o in chips_out], [np.concatenate(b) for b in bits_out],
@@ -70,12 +71,13 @@ def oracle_t2a_chips(ref, ch):
     return np.stack([oc["sample"].astype(np.uint32), oc["value"].astype(np.uint32)], axis=1)
 
 
+@pytest.mark.parametrize("s1_span", [1, 2])
 @pytest.mark.parametrize("seg_len,warm,flags", [(32768, (12288, 24576), ["-v"]), (4096, (512, 512), ["-v"]), (8192, (1024, 2048), ["-v", "-o"]),
                                                  (2048, (128, 256), ["-v"])])
-def test_device_source_on_host_matches_oracle_bundled_capture(emu, oracle, samples, seg_len, warm, flags):
+def test_device_source_on_host_matches_oracle_bundled_capture(emu, oracle, samples, seg_len, warm, flags, s1_span):
     cu8 = samples["samples2"]
     ref = oracle.run(cu8, flags_to_oracle_opts(oracle, flags), taps=True, chips=True)
-    chips, bits, reruns, rounds = run_emulated(emu, ref["dphi_fir"], [ref["m"]], seg_len, warm, dc="-o" in flags)
+    chips, bits, reruns, rounds = run_emulated(emu, ref["dphi_fir"], [ref["m"]], seg_len, warm, dc="-o" in flags, s1_span=s1_span)
     for ch in (0, 1):
         assert np.array_equal(bits[ch], ref["bit"][ch]), ("bits", ch)
         assert np.array_equal(chips[ch], oracle_t2a_chips(ref, ch)), ("chips", ch)
@@ -103,7 +105,8 @@ def test_device_source_on_host_matches_oracle_randomised(emu, oracle, wm):
         if os.environ.get("WMBUS_EMU_STRESS"):               # bug hunts: many checkpoints per segment, hopeless warm-ups
             seg_len = int(rng.choice([4096, 8192, 16384]))
             warm = (int(rng.choice([32, 64, 256])), int(rng.choice([32, 64, 256])))
-        chips, bits, reruns, rounds = run_emulated(emu, ref["dphi_fir"], pushes, seg_len, warm, dc=dc, descending=bool(k % 5), lean_reruns=bool(k % 2))
+        chips, bits, reruns, rounds = run_emulated(emu, ref["dphi_fir"], pushes, seg_len, warm, dc=dc, descending=bool(k % 5), lean_reruns=bool(k % 2),
+                                                   s1_span=1 + (k // 2) % 2)
         multi += rounds > 1
         for ch in (0, 1):
             assert np.array_equal(bits[ch], ref["bit"][ch]), (k, "bits", ch)
