@@ -253,6 +253,10 @@ __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t bloc
     const uint32_t me_full = mb + ((me - mb) & ~31u);
     /* Two blocks of loads are kept in flight per lane (register sets A and B, used alternately):
      * with one, the kernel ran at the latency of a single 10 KB request per wave (2.8 TB/s). */
+#ifndef WM_CLK_PREFETCH
+#define WM_CLK_PREFETCH 2          /* blocks of loads in flight per lane; 1 = build-time experiment (32 VGPRs fewer) */
+#endif
+    constexpr uint32_t AHEAD = 32u * WM_CLK_PREFETCH;
     float4 gxA[8], gxB[8];
     auto fetch_x = [&](float4 (&gx)[8], uint32_t mm) {
         if (coop) {
@@ -280,7 +284,7 @@ __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t bloc
      * and stores in one in-order queue) --------------------------------------------------------- */
     auto warm_block = [&](float4 (&gx)[8]) {
         put_x(gx);
-        fetch_x(gx, min(m + 64u, m_last));
+        fetch_x(gx, min(m + AHEAD, m_last));
         uint32_t bitw, smask;
         if (LEAN) clk_block32_lean<DC>(s, c, xrow, bitw, smask); else clk_block32<DC>(s, c, xrow, bitw, smask);
         /* shift-register upkeep, loop-free: at most 8 chips per block, oldest first */
@@ -294,9 +298,10 @@ __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t bloc
         }
         m += 32;
     };
-    if (m < me_full) { fetch_x(gxA, m); fetch_x(gxB, min(m + 32u, m_last)); }
+    if (m < me_full) { fetch_x(gxA, m); if (WM_CLK_PREFETCH == 2) fetch_x(gxB, min(m + 32u, m_last)); }
     while (m < mb) {
         warm_block(gxA);
+        if (WM_CLK_PREFETCH == 1) continue;
         if (m < mb) warm_block(gxB);
         else {                                               /* keep "A = next block" for phase 2 */
 #pragma unroll
@@ -326,7 +331,7 @@ __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t bloc
     uint32_t *my_bits = s_bits + ln * WM_CLK_BROW;
     auto main_block = [&](float4 (&gx)[8]) {
         put_x(gx);
-        fetch_x(gx, min(m + 64u, m_last));
+        fetch_x(gx, min(m + AHEAD, m_last));
         uint32_t bitw, smask;
         if (LEAN) clk_block32_lean<DC>(s, c, xrow, bitw, smask); else clk_block32<DC>(s, c, xrow, bitw, smask);
         uint32_t cnt = 0;
@@ -361,7 +366,7 @@ __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t bloc
         const uint32_t stop = min(me_full, m + (uint32_t)WM_CK_SAMPLES);     /* an even number of blocks, or the end */
         while (m < stop) {
             main_block(gxA);
-            if (m < stop) main_block(gxB);
+            if (WM_CLK_PREFETCH == 2 && m < stop) main_block(gxB);
         }
         if (m < me_full && j < nck) {                    /* interior checkpoint j */
             uint32_t *q = ck + 16u * j;
