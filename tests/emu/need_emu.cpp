@@ -9,7 +9,7 @@
 #define __device__
 #define __global__
 #define __forceinline__ inline
-#define __launch_bounds__(x)
+#define __launch_bounds__(...)
 #define __shared__ static
 struct uint2 { uint32_t x, y; };
 struct uint4 { uint32_t x, y, z, w; };

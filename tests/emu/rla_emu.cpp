@@ -14,7 +14,7 @@
 #define __device__
 #define __global__
 #define __forceinline__ inline
-#define __launch_bounds__(x)
+#define __launch_bounds__(...)
 #define __shared__ static
 struct uint4 { uint32_t x, y, z, w; };
 static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
