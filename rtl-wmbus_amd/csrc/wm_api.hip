@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void k_sum_counts(WmPush g, const uint32_t *co
 template <int D, bool SHIFT, bool GEN> int launch_k1v3(wmbus_ctx *c, const K1Args &a, dim3 grid)
 {
     const size_t sm = K1Geo::smem(D ? D : (int)c->d, SHIFT);
-    static size_t set_for[16] = {};                         /* per device: the attribute call is not free, a push makes several launches */
+    static std::atomic<size_t> set_for[16];                 /* per device: the attribute call is not free, a push makes several launches */
     if (set_for[c->cfg.device & 15] < sm) {
         HIPCHK(c, hipFuncSetAttribute((const void *)k1_demod2<D, SHIFT, GEN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
         set_for[c->cfg.device & 15] = sm;
@@ -255,7 +255,7 @@ template <int D, bool SHIFT> int launch_k1v2(wmbus_ctx *c, const K1Args &a, dim3
 int launch_k1_ppf(wmbus_ctx *c, const K1Args &a, dim3 grid)
 {
     const size_t sm = K1PpfGeo::smem();
-    static size_t set_for[16] = {};
+    static std::atomic<size_t> set_for[16];
     if (set_for[c->cfg.device & 15] < sm) {
         HIPCHK(c, hipFuncSetAttribute((const void *)k1_demod_ppf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
         set_for[c->cfg.device & 15] = sm;
