@@ -85,7 +85,7 @@ def cpu_baseline(caps, n_samples):
     exe, kind = (O.REF_BIN, "reference") if os.path.exists(O.REF_BIN) else (O.ORACLE_CLI, "port")
     if not os.path.exists(exe):
         return None
-    cores = min(os.cpu_count() or 1, 64)
+    cores = min(os.cpu_count() or 1, 256)                  # one reference process per host core (the reference is single-threaded)
     d = tempfile.mkdtemp(prefix="wmbus_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     try:
         files = []
