@@ -85,14 +85,17 @@ def cpu_baseline(caps, n_samples):
     exe, kind = (O.REF_BIN, "reference") if os.path.exists(O.REF_BIN) else (O.ORACLE_CLI, "port")
     if not os.path.exists(exe):
         return None
-    cores = min(os.cpu_count() or 1, 256)                  # one reference process per host core (the reference is single-threaded)
+    # one reference process per core, at most 64: on the 256-thread bench hosts 256 processes deliver LESS in total (162
+    # against 246 Msamples/s, and take 250 s): the aggregate saturates near 64, so that is the baseline's best case
+    cores = min(os.cpu_count() or 1, 64)
     d = tempfile.mkdtemp(prefix="wmbus_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     try:
         files = []
-        for w in range(cores):
+        for w in range(min(cores, 32)):                       # 32 different captures, shared read-only by the processes
             f = os.path.join(d, f"c{w}.cu8")
             caps[w % len(caps)].tofile(f)
             files.append(f)
+        files = [files[w % len(files)] for w in range(cores)]
         t = time.perf_counter()
         subprocess.run(f"{exe} < {files[0]} > /dev/null", shell=True, check=True)
         one = time.perf_counter() - t
@@ -366,7 +369,10 @@ def main():
             "input": "staged from pinned host memory inside every step (PCIe-inclusive, informational)" if a.from_host else "resident in HBM",
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(caps, n)
+            try:
+                out["cpu_baseline"] = cpu_baseline(caps, n)
+            except Exception as e:                            # the baseline must never cost the bench line
+                out["cpu_baseline"] = {"value": None, "unit": "Msamples/s", "cores": 0, "kind": "reference", "sample": f"failed: {e!r}"}
         if parity is not None:
             fp, lp = parity["first_pass"], parity["last_pass"]
             out["parity"] = parity
