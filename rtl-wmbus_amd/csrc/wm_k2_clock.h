@@ -253,6 +253,9 @@ __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t bloc
     const uint32_t me_full = mb + ((me - mb) & ~31u);
     /* Two blocks of loads are kept in flight per lane (register sets A and B, used alternately):
      * with one, the kernel ran at the latency of a single 10 KB request per wave (2.8 TB/s). */
+#ifndef WM_CLK_EARLY_EXIT
+#define WM_CLK_EARLY_EXIT 1        /* 0: always eight trips through the chip loops of a block (the round-1 form; A/B) */
+#endif
 #ifndef WM_CLK_PREFETCH
 #define WM_CLK_PREFETCH 2          /* blocks of loads in flight per lane; 1 = build-time experiment (32 VGPRs fewer) */
 #endif
@@ -287,10 +290,12 @@ __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t bloc
         fetch_x(gx, min(m + AHEAD, m_last));
         uint32_t bitw, smask;
         if (LEAN) clk_block32_lean<DC>(s, c, xrow, bitw, smask); else clk_block32<DC>(s, c, xrow, bitw, smask);
-        /* shift-register upkeep, loop-free: at most 8 chips per block, oldest first */
+        /* shift-register upkeep: at most 8 chips per block, oldest first; the wave stops as soon as none of its lanes
+         * has a chip left (T1/C1 lanes meet 4 per block, S1 lanes 1.3: half the trips of the fixed eight) */
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const bool has = smask != 0u;
+            if (WM_CLK_EARLY_EXIT && __ballot(has) == 0ull) break;
             const uint32_t k = has ? (uint32_t)__ffs((int)smask) - 1u : 0u;
             smask &= smask - 1u;
             const uint32_t sr_new = ((s.sr << 1) | ((bitw >> k) & 1u)) & syncm;
@@ -338,6 +343,7 @@ __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t bloc
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const bool has = smask != 0u;
+            if (WM_CLK_EARLY_EXIT && __ballot(has) == 0ull) break;              /* no lane of the wave has a chip left in this block */
             const uint32_t k = has ? (uint32_t)__ffs((int)smask) - 1u : 0u;
             smask &= smask - 1u;
             const uint32_t bit = (bitw >> k) & 1u;

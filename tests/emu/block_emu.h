@@ -83,6 +83,7 @@ static void run_block(uint32_t nthreads, const std::function<void()> &fn, size_t
 static inline void __syncthreads() { block_emu::yield(block_emu::WAIT_BLOCK); }
 static inline unsigned long long __ballot(int pred)
 {
+    if (block_emu::cur < 0) return pred ? 1ull : 0ull;       /* outside run_block: a lane on its own is a wave of one */
     block_emu::cos[block_emu::cur].pred = pred != 0;
     block_emu::yield(block_emu::WAIT_WAVE);
     return block_emu::cos[block_emu::cur].ballot;
