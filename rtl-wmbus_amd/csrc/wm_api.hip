@@ -99,6 +99,7 @@ private:
 struct HostDecoder {           /* persistent across pushes */
     wm_decoder dec;
     uint32_t owed;             /* chips to request at the start of the next push */
+    uint64_t fed;              /* push in which the decoder last took chips (see the dropped-burst clean-up in wmbus_collect) */
 };
 
 }  // namespace
@@ -157,6 +158,7 @@ struct wmbus_ctx {
     std::unique_ptr<WorkerPool> pool;                   /* packet-decoder workers, created on first use */
     std::vector<wmbus_line> lines; std::string text;
     WmPush last{}; bool have_last = false, in_flight = false;
+    uint64_t push_seq = 0;                              /* pushes enqueued so far */
     std::atomic<uint32_t> short_burst{0};               /* set by the decoder threads of one collect: 1 + header index */
     wmbus_timing tim{};
 };
@@ -197,6 +199,7 @@ __global__ void k_copy_hist(const uint8_t *src, uint64_t sstride, uint64_t soff,
 }
 
 __global__ void k_copy_word(uint32_t *dst, uint32_t v) { *dst = v; }
+__global__ void k_and_word(uint32_t *dst, uint32_t v) { *dst &= v; }
 
 __global__ void k_fill(uint8_t *p, uint64_t stride, uint32_t n, uint8_t v)
 {
@@ -437,10 +440,11 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
     const uint64_t dec_total = (uint64_t)c->S * c->Mcap;
     c->hdr_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(65536, dec_total / 1024), 1u << 24);
     c->hits_cap = c->hdr_cap;
-    /* bursts that still travel as chips are the ones cut by the end of a push (and their continuations): at most one
-     * per (capture, chain, framer) and push, each at most 16 x 290 + 1 chips */
+    /* bursts that still travel as chips are the ones whose plan reaches past the end of the push (every such hit is
+     * shipped with the chips up to the end, at most 16 x 290 + 1 of them) and the continuations of those the decoders
+     * took: room for two longest bursts per (capture, chain, framer); beyond that bursts are dropped with a warning */
     c->gpu_decode = !(getenv("WMBUS_GPU_DECODE") && atoi(getenv("WMBUS_GPU_DECODE")) == 0);    /* 0: every burst to the host decoders as chips (A/B, tests) */
-    c->words_cap = c->gpu_decode ? (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1u << 20, 4ull * c->S * 1024), 1u << 28)
+    c->words_cap = c->gpu_decode ? (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1u << 20, 4ull * c->S * 2 * WM_MAXCHIPS_S1), 1u << 28)
                                  : (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1u << 20, dec_total / 8), 1u << 29);
     c->pkts_cap = c->hdr_cap;
     c->bytes_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1u << 20, dec_total / 64), 1u << 30);
@@ -496,7 +500,7 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
             for (int al = 0; al < 2; al++) {
                 HostDecoder &hd = c->decs[((size_t)s * 2 + ch) * 2 + al];
                 wm_decoder_init(&hd.dec, ch ? WM_MODE_S1 : WM_MODE_T1C1);
-                hd.owed = 0;
+                hd.owed = 0; hd.fed = 0;
             }
     *out = c;
     return WMBUS_OK;
@@ -587,9 +591,15 @@ static void fr_launch(wmbus_ctx *c, int algo, uint32_t cnt)
     a.n_lanes = lanes; a.n_ptr = all ? nullptr : c->d_scalars + cnt;
     /* list launches: blocks for 3/16 of the lanes (a re-run list is a few percent of them; the blocks walk whatever is more) */
     const uint32_t B = 64 * (algo == WMBUS_ALGO_RLA ? WM_RLA_WPB : WM_CLK_WPB), grid = all ? (lanes + B - 1) / B : std::max(16u, (lanes / B) * 3u / 16u);
-    if (algo == WMBUS_ALGO_RLA) hipLaunchKernelGGL(k2_rla, dim3(grid), dim3(B), 0, c->stream, a);
-    else if (c->flags & WM_F_DC) hipLaunchKernelGGL(k2_clock<true>, dim3(grid), dim3(B), 0, c->stream, a);
-    else hipLaunchKernelGGL(k2_clock<false>, dim3(grid), dim3(B), 0, c->stream, a);
+    if (algo == WMBUS_ALGO_RLA) {
+        if (all) hipLaunchKernelGGL(k2_rla, dim3(grid), dim3(B), 0, c->stream, a);
+        else hipLaunchKernelGGL(k2_rla_list, dim3(grid), dim3(B), 0, c->stream, a);
+    }
+    else if (all) {
+        if (c->flags & WM_F_DC) hipLaunchKernelGGL(k2_clock<true>, dim3(grid), dim3(B), 0, c->stream, a);
+        else hipLaunchKernelGGL(k2_clock<false>, dim3(grid), dim3(B), 0, c->stream, a);
+    } else if (c->flags & WM_F_DC) hipLaunchKernelGGL(k2_clock_list<true>, dim3(grid), dim3(B), 0, c->stream, a);
+    else hipLaunchKernelGGL(k2_clock_list<false>, dim3(grid), dim3(B), 0, c->stream, a);
 }
 
 /* the fused launch: clock re-run list (scalar cnt_c) + run-length framer, all lanes (cnt_r == ~0) or its list */
@@ -627,6 +637,8 @@ static int launch_k3(wmbus_ctx *c, bool again)
     if (again) {                                             /* collect's slow path: the counters of the first attempt go */
         HIPCHK(c, hipMemsetAsync(c->d_scalars + SC_NHITS, 0, 5 * sizeof(uint32_t), c->stream));          /* NHITS .. NBYTES */
         HIPCHK(c, hipMemsetAsync(c->d_scalars + SC_CHIPS, 0, 4 * sizeof(uint32_t), c->stream));
+        /* ... and so does its burst-storage warning (chips dropped by the framers stay dropped: that bit is kept) */
+        hipLaunchKernelGGL(k_and_word, dim3(1), dim3(1), 0, c->stream, c->d_scalars + SC_ERR, ~(uint32_t)WM_ERR_BURST_OVERFLOW);
     }
     hipLaunchKernelGGL(k_sum_counts, dim3(std::min(64u, (2u * (c->nseg_cap[0] + c->nseg_cap[1]) * c->S + 255u) / 256u)), dim3(256), 0, c->stream, g,
                        c->d_counts[0], c->d_counts[1], c->d_scalars + SC_CHIPS);
@@ -783,6 +795,7 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
     HIPCHK(c, hipGetLastError());
     c->fill = (c->fill + 1) % c->n_win;
     c->n0 += n_new;
+    c->push_seq++;
     c->in_flight = true;
     return WMBUS_OK;
 }
@@ -884,6 +897,9 @@ static void decode_stream_range(wmbus_ctx *c, const std::vector<Entry> &order, s
                 next_free = (uint64_t)p.chip0 + p.consumed;
                 if (p.status != WM_PKT_DONE) continue;
                 const unsigned nb = std::min<unsigned>(std::max<unsigned>(p.L, 2u), WM_PKT_MAXBYTES);
+                /* the reference's decoder is memset on reset (t1_c1_packet_decoder.h:268,276): bytes a short telegram never
+                 * stored read as zero in the ident field of its line (get_serial looks at bytes 4..7 whatever L is) */
+                memset(pkt, 0, sizeof pkt);
                 memcpy(pkt, c->h_bytes + p.off, nb);
                 if (ts_fixed) snprintf(ts, sizeof ts, "%s", ts_fixed); else wm_timestamp(ts, sizeof ts);
                 const int ok = (p.flags & WM_PKTF_CRC_OK) != 0;
@@ -927,6 +943,7 @@ static void decode_stream_range(wmbus_ctx *c, const std::vector<Entry> &order, s
                 c->short_burst.compare_exchange_strong(none, 1u + order[j].idx);
             }
             hd.owed = cut ? std::max(1u, wm_decoder_chips_owed(&hd.dec)) : 0u;
+            hd.fed = c->push_seq;
         }
         i = j;
     }
@@ -1006,6 +1023,12 @@ int wmbus_collect(wmbus_ctx *c)
         if (!c->pool || c->pool->size() + 1 != nt) c->pool.reset(new WorkerPool(nt - 1));
         c->pool->run(np, [&](unsigned t) { decode_stream_range(c, order, cut[t], cut[t + 1], parts[t], tsf); });
     }
+    /* Burst storage ran out (a warning): a half-received telegram whose continuation was among the dropped bursts would
+     * otherwise wait for it for ever and take the FIRST chips of the next push for its own -- it is lost, like the
+     * bursts that were dropped. */
+    if (c->tim.warnings & WMBUS_WARN_BURSTS_DROPPED)
+        for (auto &hd : c->decs)
+            if (hd.owed != 0 && hd.fed != c->push_seq) { wm_decoder_abort(&hd.dec); hd.owed = 0; }
     /* stdout order of the reference: by completing sample, then T1/C1 before S1, run-length before time2 */
     std::vector<LineRec> all;
     for (auto &p : parts) for (auto &r : p) all.push_back(std::move(r));

@@ -180,7 +180,10 @@ template <int W> struct ClkLds {         /* per block: W independent waves */
  * long-running wave on ONE SIMD slows every 4-wave K1 block of that CU down to the pace of the K1
  * wave that shares the SIMD with it (measured: two clock launches in flight, one wave per CU, cost
  * K1 60 %). */
-template <bool DC, int W, bool LEAN = false>
+/* PASS: 0 = the speculative first pass only (a.list == nullptr), 1 = a re-run list only, 2 = either (host emulation): each kind of launch has its own
+ * kernel, so the first pass carries neither the list walk nor the checkpoint comparison (with both in one kernel behind
+ * a grid-stride loop the first pass needed 254 VGPRs + 16 AGPRs and ran at one wave per SIMD, round 2). */
+template <bool DC, int W, bool LEAN = false, int PASS = 2>
 __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t block, ClkLds<W> &lds)
 {
     const uint32_t ln = threadIdx.x & 63u, wv = threadIdx.x >> 6;
@@ -188,7 +191,7 @@ __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t bloc
     float *s_x = lds.x[wv];
     uint32_t *s_chip = lds.chip[wv], *s_bits = lds.bits[wv];
     uint32_t lane = (block * W + wv) * 64 + ln;
-    const bool rerun = a.list != nullptr;
+    const bool rerun = PASS == 2 ? a.list != nullptr : PASS == 1;
     const WmPush &g = a.g;
     const bool coop = !rerun && (g.S % 64u) == 0u;         /* wave = 64 consecutive streams, lock step */
     if (lane >= k2_lane_count(a)) return;
@@ -443,11 +446,18 @@ __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t bloc
 }
 
 template <bool DC>
-__global__ __launch_bounds__(64 * WM_CLK_WPB) void k2_clock(K2Args a)
+__global__ __launch_bounds__(64 * WM_CLK_WPB) void k2_clock(K2Args a)                 /* first pass: one block per 64 * WM_CLK_WPB lanes */
 {
     __shared__ __attribute__((aligned(16))) ClkLds<WM_CLK_WPB> lds;
-    const uint32_t n = k2_lane_count(a);                  /* a list launch has a fixed grid: its blocks walk the list */
-    for (uint32_t b = blockIdx.x; (uint64_t)b * (64u * WM_CLK_WPB) < n; b += gridDim.x) clock_lanes<DC, WM_CLK_WPB>(a, b, lds);
+    clock_lanes<DC, WM_CLK_WPB, false, 0>(a, blockIdx.x, lds);
+}
+
+template <bool DC>
+__global__ __launch_bounds__(64 * WM_CLK_WPB) void k2_clock_list(K2Args a)            /* re-run list: a fixed grid whose blocks walk the list */
+{
+    __shared__ __attribute__((aligned(16))) ClkLds<WM_CLK_WPB> lds;
+    const uint32_t n = k2_lane_count(a);
+    for (uint32_t b = blockIdx.x; (uint64_t)b * (64u * WM_CLK_WPB) < n; b += gridDim.x) clock_lanes<DC, WM_CLK_WPB, false, 1>(a, b, lds);
 }
 
 #endif /* WM_K2_CLOCK_H */

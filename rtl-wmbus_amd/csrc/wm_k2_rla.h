@@ -58,12 +58,15 @@ __device__ __forceinline__ uint32_t deglitch_word(uint32_t W, bool s1)
  * from the masked history.  WmRlaState.raw keeps the last five raw bits in time order. */
 struct RlaLds { uint32_t chip[64 * WM_RLA_WPB * WM_RLA_CROW]; };     /* lane-private staging; the block's waves are independent */
 
+/* PASS: 0 = first pass only (a.list == nullptr), 1 = re-run list only, 2 = either (the fused launch): like the clock kernel,
+ * each kind of launch has its own kernel (the main pass then carries no list walk: 78 instead of 97 VGPRs). */
+template <int PASS = 2>
 __device__ __forceinline__ void rla_lanes(const K2Args &a, const uint32_t block_id, RlaLds &lds)
 {
     uint32_t *s_chip = lds.chip;
     uint32_t lane = block_id * (64 * WM_RLA_WPB) + threadIdx.x;
     if (lane >= k2_lane_count(a)) return;
-    const bool rerun = a.list != nullptr;
+    const bool rerun = PASS == 2 ? a.list != nullptr : PASS == 1;
     if (rerun) lane = a.list[lane];
     const WmPush &g = a.g;
     uint32_t ch, stream, seg;
@@ -118,7 +121,9 @@ __device__ __forceinline__ void rla_lanes(const K2Args &a, const uint32_t block_
         uint32_t w[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) w[i] = my_chip[i];
-        uint32_t *dst = n_fl + 8u <= cap_rl ? out + n_fl : spill_slot(n_fl - cap_rl);
+        /* once storage is exhausted the lane stops asking: every failed request bumps the 32-bit arena counter, and 2^21
+         * of them in one push would wrap it back into chunks other segments own */
+        uint32_t *dst = n_fl + 8u <= cap_rl ? out + n_fl : n_stored == 0xFFFFFFFFu ? spill_slot(n_fl - cap_rl) : nullptr;
         if (dst != nullptr && n_stored == 0xFFFFFFFFu) {
             *(uint4 *)(dst) = make_uint4(w[0], w[1], w[2], w[3]);
             *(uint4 *)(dst + 4) = make_uint4(w[4], w[5], w[6], w[7]);
@@ -232,11 +237,17 @@ __device__ __forceinline__ void rla_lanes(const K2Args &a, const uint32_t block_
 #ifndef WM_RLA_WAVES_PER_SIMD
 #define WM_RLA_WAVES_PER_SIMD 1        /* 8: at most 64 VGPRs (build-time experiment) */
 #endif
-__global__ __launch_bounds__(64 * WM_RLA_WPB, WM_RLA_WAVES_PER_SIMD) void k2_rla(K2Args a)
+__global__ __launch_bounds__(64 * WM_RLA_WPB, WM_RLA_WAVES_PER_SIMD) void k2_rla(K2Args a)           /* main pass: one block per 64 * WM_RLA_WPB lanes */
+{
+    __shared__ RlaLds lds;
+    rla_lanes<0>(a, blockIdx.x, lds);
+}
+
+__global__ __launch_bounds__(64 * WM_RLA_WPB, WM_RLA_WAVES_PER_SIMD) void k2_rla_list(K2Args a)      /* re-run list: a fixed grid walks it */
 {
     __shared__ RlaLds lds;
     const uint32_t n = k2_lane_count(a);
-    for (uint32_t b = blockIdx.x; (uint64_t)b * (64u * WM_RLA_WPB) < n; b += gridDim.x) rla_lanes(a, b, lds);
+    for (uint32_t b = blockIdx.x; (uint64_t)b * (64u * WM_RLA_WPB) < n; b += gridDim.x) rla_lanes<1>(a, b, lds);
 }
 
 #endif /* WM_K2_RLA_H */

@@ -134,6 +134,9 @@ __global__ __launch_bounds__(256) void k3_scan(WmPush g, const uint32_t *chips0,
 #define WM_K3_BITWORDS 76          /* >= (WM_MAXCHIPS_S1 + 1 + 63) / 64 + 1 */
 struct K3Lds { unsigned long long bits[4][WM_K3_BITWORDS]; uint8_t bytes[4][WM_PKT_MAXBYTES + 4]; };
 
+#ifndef WM_PEEK
+#define WM_PEEK(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)     /* a counter other waves are adding to */
+#endif
 #ifndef WM_WAVE_SYNC
 #define WM_WAVE_SYNC() __builtin_amdgcn_wave_barrier()       /* LDS hand-over inside one wave (DS operations of a wave are in order) */
 #endif
@@ -250,7 +253,7 @@ __device__ void burst_item(const K3Args &a, const uint32_t item, const uint32_t 
         if (ln == 0) s_bits[(n + 63u) >> 6] = 0ull;          /* k3_field may look one word ahead */
         WM_WAVE_SYNC();
         const uint32_t nb = plan.done ? plan.nbytes : 0u;
-        uint32_t err36 = 0;
+        uint32_t err36 = 0, bad_pair = 0;
         /* bytes: lane b assembles byte b, b + 64, ... */
         for (uint32_t b0 = 0; b0 < nb; b0 += 64u) {
             const uint32_t b = b0 + ln;
@@ -267,7 +270,10 @@ __device__ void burst_item(const K3Args &a, const uint32_t item, const uint32_t 
 #pragma unroll
                     for (int q = 7; q >= 0; q--) {           /* pair q: 01 -> 1, 10 -> 0 (s1_packet_decoder.h:35-37) */
                         const uint32_t pair = (sym >> (2 * q)) & 3u;
-                        if (pair == 0u || pair == 3u) ev = min(ev, 1u + 16u * b + 2u * (7u - (uint32_t)q) + 2u);   /* chip completing the pair, + 1 */
+                        /* chip completing the pair, + 1.  For the telegram's LAST pair that is n itself, which must not read as
+                         * "nothing stopped the decoder": s1_rx_last_data_bit resets on it like on any other pair
+                         * (s1_packet_decoder.h:204-215), so the error travels in a flag of its own */
+                        if (pair == 0u || pair == 3u) { ev = min(ev, 1u + 16u * b + 2u * (7u - (uint32_t)q) + 2u); bad_pair = 1u; }
                         v = (v << 1) | (pair == 1u);
                     }
                 }
@@ -277,8 +283,9 @@ __device__ void burst_item(const K3Args &a, const uint32_t item, const uint32_t 
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) ev = min(ev, __shfl_xor(ev, off));
         err36 = __ballot(err36) != 0ull;
+        bad_pair = __ballot(bad_pair) != 0ull;
         r_first = __shfl(r_first, 1); r_last = __shfl(r_last, (int)((n - 1u) & 63u)); pm_last = __shfl(pm_last, (int)((n - 1u) & 63u));
-        const bool done = plan.done && ev == n;
+        const bool done = plan.done && ev == n && !bad_pair;
         WM_WAVE_SYNC();
         /* block CRCs (t1_c1_packet_decoder.h:471-536): frame A 12 bytes then 18s, frame B 128s, the last block may be short */
         uint32_t crc_bad = 0;
@@ -292,10 +299,17 @@ __device__ void burst_item(const K3Args &a, const uint32_t item, const uint32_t 
             }
         }
         crc_bad = __ballot(crc_bad) != 0ull;
-        uint32_t slot = 0, boff = 0;
-        if (ln == 0) { slot = atomicAdd(a.n_pkts, 1u); boff = done ? atomicAdd(a.n_bytes, (nb + 3u) & ~3u) : 0u; }
+        /* storage first, then the slot: every slot below the capacity that the counter hands out is written in full (the
+         * host walks min(counter, capacity) entries of pinned memory and must never meet one that nobody wrote) */
+        uint32_t slot = 0xFFFFFFFFu, boff = 0;
+        if (ln == 0) {
+            /* a full arena is not asked again (the counters are 32 bits wide; 2^24 hits could wrap them) */
+            const bool room = !done || WM_PEEK(a.n_bytes) <= a.bytes_cap;
+            boff = done && room ? atomicAdd(a.n_bytes, (nb + 3u) & ~3u) : 0u;
+            if (room && (!done || (boff <= a.bytes_cap && a.bytes_cap - boff >= nb))) slot = atomicAdd(a.n_pkts, 1u);
+        }
         slot = __shfl(slot, 0); boff = __shfl(boff, 0);
-        if (slot >= a.pkts_cap || (done && boff + nb > a.bytes_cap)) { if (ln == 0) atomicOr(a.err, WM_ERR_BURST_OVERFLOW); return; }
+        if (slot >= a.pkts_cap) { if (ln == 0) atomicOr(a.err, WM_ERR_BURST_OVERFLOW); WM_WAVE_SYNC(); return; }
         if (done) for (uint32_t b = ln; b < nb; b += 64u) a.bytes[boff + b] = s_bytes[b];
         if (ln == 0) {
             WmPkt p;
@@ -312,10 +326,15 @@ __device__ void burst_item(const K3Args &a, const uint32_t item, const uint32_t 
     }
 
     /* ---- cut by the end of the push, or the rest of such a burst: chips for the host decoder ---- */
-    uint32_t hslot = 0, woff = 0;
-    if (ln == 0) { hslot = atomicAdd(a.n_hdr, 1u); woff = atomicAdd(a.n_words, n); }
+    uint32_t hslot = 0xFFFFFFFFu, woff = 0;
+    if (ln == 0) {                                           /* words first, then the slot (see above) */
+        if (WM_PEEK(a.n_words) <= a.words_cap) {
+            woff = atomicAdd(a.n_words, n);
+            if (woff <= a.words_cap && a.words_cap - woff >= n) hslot = atomicAdd(a.n_hdr, 1u);
+        }
+    }
     hslot = __shfl(hslot, 0); woff = __shfl(woff, 0);
-    if (hslot >= a.hdr_cap || woff + n > a.words_cap) { if (ln == 0) atomicOr(a.err, WM_ERR_BURST_OVERFLOW); return; }
+    if (hslot >= a.hdr_cap) { if (ln == 0) atomicOr(a.err, WM_ERR_BURST_OVERFLOW); return; }
     uint32_t sg0, k0; locate(0, sg0, k0);
     const uint64_t pos0 = g.m0 + (uint64_t)sg0 * seg_len + WM_CHIP_POS(chip(sg0, k0));
     /* one chip per lane and trip.  (Four independent chip -> RSSI load chains per lane were measured at -3 % for the whole

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(64 * WM_RLA_WPB, WM_FUSED_WAVES_PER_SIMD) void k2_c
     /* both parts walk their lane lists with the blocks they were given (the counts may live on the device) */
     if (blockIdx.x < clk_blocks) {
         const uint32_t n = k2_lane_count(clk);
-        for (uint32_t b = blockIdx.x; (uint64_t)b * 64u < n; b += clk_blocks) clock_lanes<false, 1, WM_FUSED_LEAN_CLOCK != 0>(clk, b, lds.c);
+        for (uint32_t b = blockIdx.x; (uint64_t)b * 64u < n; b += clk_blocks) clock_lanes<false, 1, WM_FUSED_LEAN_CLOCK != 0, 1>(clk, b, lds.c);
     } else {
         const uint32_t n = k2_lane_count(rla), nb = gridDim.x - clk_blocks;
         for (uint32_t b = blockIdx.x - clk_blocks; (uint64_t)b * (64u * WM_RLA_WPB) < n; b += nb) rla_lanes(rla, b, lds.r);

@@ -14,6 +14,7 @@
 #define __launch_bounds__(...)
 #define __shared__ static                  /* one block runs at a time: block-shared = static */
 #define WM_WAVE_SYNC() emu_wave_barrier()
+#define WM_PEEK(p) (*(p))
 struct uint2 { uint32_t x, y; };
 struct uint4 { uint32_t x, y, z, w; };
 static inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }

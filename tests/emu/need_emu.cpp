@@ -19,6 +19,7 @@ static Idx3 threadIdx, blockIdx, gridDim;
 static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 static inline uint32_t __brev(uint32_t v) { uint32_t r = 0; for (int i = 0; i < 32; i++) r |= ((v >> i) & 1u) << (31 - i); return r; }
 #define WM_WAVE_SYNC() ((void)0)
+#define WM_PEEK(p) (*(p))
 static inline unsigned long long __ballot(int p) { return p ? 1ull : 0ull; }       /* one-lane "wave": only to let the header compile */
 template <typename T> static inline T __shfl(T v, int) { return v; }
 template <typename T> static inline T __shfl_xor(T v, int) { return v; }

@@ -241,3 +241,55 @@ def test_bursts_inside_the_push_are_decoded_like_the_host_decoder_would(emu_k3, 
                 else:
                     n_abort += 1
     assert n_done > 10 and n_abort > 0 and n_raw <= 8
+
+
+def _hand_made_stream(ch, vals, rssi_val=40):
+    """A chip stream written by hand into the time2 region of chain `ch` (one chip every 8 samples): the framer
+    arrays k3 reads, the RSSI rows, and the same chips as an oracle-style record for the host decoder."""
+    seg1, seg0 = 32768, 8192
+    M = 8 * (len(vals) + 8); Mcap = (M + 255) // 256 * 256
+    nseg1, cap1, nseg0, cap0 = 1, seg1 // 4 + 8, 1, seg0 // 2 + 8
+    chips1 = np.zeros((2, nseg1, cap1), np.uint32); counts1 = np.zeros((2, nseg1), np.uint32); seen1 = np.zeros((2, nseg1), np.uint32)
+    chips0 = np.zeros((2, nseg0, cap0), np.uint32); counts0 = np.zeros((2, nseg0), np.uint32); seen0 = np.zeros((2, nseg0), np.uint32)
+    pos = 8 * np.arange(len(vals), dtype=np.uint32) + 16
+    chips1[ch, 0, :len(vals)] = (pos << 3) | np.asarray(vals, np.uint32)
+    counts1[ch, 0] = len(vals); seen1[ch, 0] = 1
+    geo = np.array([M, Mcap, F_T1C1 | F_S1 | F_RLA | F_T2A, 0, seg0, seg1, nseg0, nseg1, cap0, cap1], np.uint64)
+    fr = dict(geo=geo, chips=(chips0, chips1), counts=(counts0, counts1), seen=(seen0, seen1), Mcap=Mcap)
+    rssi = np.full((2, Mcap), rssi_val, np.uint8)
+    rec = np.zeros(len(vals), [("chain", "u1"), ("algo", "u1"), ("sample", "<i8"), ("value", "<u4"), ("rssi", "<u4")])
+    rec["chain"], rec["algo"], rec["sample"], rec["value"], rec["rssi"] = ch, 1, pos, vals, rssi_val
+    return fr, rssi, dict(chips=rec)
+
+
+def _s1_chips(data_bytes):
+    """access-code chip + Manchester chips of the bytes (01 -> 1, 10 -> 0, s1_packet_decoder.h:35-37) + idle tail."""
+    vals = [2]
+    for b in data_bytes:
+        for k in range(7, -1, -1):
+            vals += [0, 1] if (b >> k) & 1 else [1, 0]
+    return vals + [0, 1] * 16
+
+
+@pytest.mark.parametrize("where", ["clean", "last", "interior", "first_data"])
+def test_invalid_manchester_pair_anywhere_aborts_the_telegram(emu_k3, emu_need, where):
+    """the abort position of the telegram's LAST pair equals the burst length, so it used to read as
+    "nothing stopped the decoder" and a phantom line came out (the invalid pair decodes as a 0 bit and may even pass the
+    CRC).  The reference resets on it like on any other pair (s1_packet_decoder.h:204-215)."""
+    vals = _s1_chips([0x00, 0xA5, 0x3C])                     # L-field 0: the L-field and one CRC pair
+    n = 1 + 16 * 3
+    if where == "last":
+        vals[n - 2:n] = [1, 1]
+    elif where == "interior":
+        vals[1 + 16 + 6:1 + 16 + 8] = [0, 0]
+    elif where == "first_data":
+        vals[1 + 16:1 + 16 + 2] = [1, 1]
+    fr, rssi, ref = _hand_made_stream(1, vals)
+    hdr, words, pkts, pbytes = bursts_on_host(emu_k3, fr, rssi, decode=True)
+    want = host_decoder_on_every_access_code(emu_need, ref, 1, 1)[0]
+    assert len(hdr) == 0 and len(pkts) == 1
+    p = pkts[0]
+    assert (int(p["consumed"]), p["status"] == 1) == (want["consumed"], want["done"]), (where, p, want)
+    assert want["done"] == (where == "clean")
+    if where == "last":
+        assert int(p["consumed"]) == n and p["status"] == 2
