@@ -8,9 +8,9 @@ Workload (BASELINE.json configs[3], per GPU): 1024 independent synthetic 1.6 MS/
 2^22 IQ samples each (SURVEY.md 8(d) recipe: noise + T1/C1 bursts, ~20 bursts/s), resident in HBM
 before the timed region.  One "step" = one pass of the whole hot path over that batch: demodulation,
 clock recovery, both framers, burst extraction, D2H of the bursts and the host packet decoders
-(datagram text produced).  The batch is held by eight receiver contexts (128 captures each) that
-free-run through their K passes, so that one context's host decoding and latency-bound re-run tails
-are covered by the other contexts' kernels.  With N > 1 every rank owns its own 1024 captures on its own GPU
+(datagram text produced).  The batch is a wmbus_batch of the LIBRARY (include/wmbus_hip.h; the same
+object `rtl_wmbus_hip FILE...` runs): eight receiver contexts of 128 captures that free-run through
+their K passes on the library's worker threads.  With N > 1 every rank owns its own 1024 captures on its own GPU
 (file-per-GPU sharding, no data-path collective): weak scaling; torch.distributed (RCCL) is used
 only for the barrier and the max-over-ranks of the elapsed time.
 
@@ -25,13 +25,11 @@ The JSON line also carries
 """
 import os
 
-# One HIP stream per receiver context; ROCm maps streams onto 4 hardware queues by default and streams
-# that share a queue serialise against each other (8 contexts on 4 queues: -25 %).  Must be set
-# before the HIP runtime initialises.
+# (GPU_MAX_HW_QUEUES: libwmbus_hip.so sets its own default of 8 when it is loaded.  --from-host gives every context a
+# second stream for its staging copies: 16 queues, or two contexts' compute streams share one.)
 import sys as _sys
-# (--from-host gives every context a second stream for its staging copies: 16 queues, or two contexts' compute streams
-# share one)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16" if "--from-host" in _sys.argv else "8")
+if "--from-host" in _sys.argv:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import argparse
 import collections
@@ -65,8 +63,8 @@ def parse():
     ap.add_argument("--warmup-s1", type=int, default=0)
     ap.add_argument("--warmup-t1c1", type=int, default=0)
     ap.add_argument("--rla-lookback", type=int, default=0)
-    ap.add_argument("--contexts", type=int, default=8, help="receiver contexts per GPU (GPU / host-decode overlap)")
-    ap.add_argument("--stagger", type=float, default=0.0, help="seconds between context starts (the contexts' turns in the demodulation kernel stagger them anyway)")
+    ap.add_argument("--contexts", type=int, default=0, help="receiver contexts per GPU (0: the library's default split, 8 x 128 captures)")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU work: ranks only shard, meet at the barriers and reduce (CPU test of the N > 1 path)")
     ap.add_argument("--from-host", action="store_true",
                     help="informational: stage every capture from pinned host memory inside each step (PCIe-inclusive rate; "
                          "the BASELINE metric keeps the input resident in HBM)")
@@ -114,15 +112,16 @@ def cpu_baseline(caps, n_samples):
                       f"({os.path.basename(exe)} -O3, default switches, input from /dev/shm), {dt:.1f} s wall"}
 
 
-def spawn_ranks(n):
+def spawn_ranks(n, need_devices=True):
     """`python bench.py --gpus N` without a launcher: become the launcher.  One child per GPU with the
     environment torch.distributed.run would give it (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*); rank 0's
     stdout (the JSON line) passes through.  Fails loudly when the node has fewer than N devices."""
     import socket
-    wm = importlib.import_module("rtl-wmbus_amd")
-    have = wm.device_count()
-    if have < n and not os.environ.get("WMBUS_BENCH_DEVICE"):
-        raise SystemExit(f"bench.py: --gpus {n} but only {have} HIP device(s) visible")
+    if need_devices:
+        wm = importlib.import_module("rtl-wmbus_amd")
+        have = wm.device_count()
+        if have < n and not os.environ.get("WMBUS_BENCH_DEVICE"):
+            raise SystemExit(f"bench.py: --gpus {n} but only {have} HIP device(s) visible")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -139,25 +138,36 @@ def main():
     a = parse()
     shard = importlib.import_module("rtl-wmbus_amd.shard")
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
-        spawn_ranks(a.gpus)
+        spawn_ranks(a.gpus, need_devices=not a.dry_run)
     rank, world, local = shard.rank_env()
     if world != a.gpus:
         raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
-    # WMBUS_BENCH_BACKEND=gloo WMBUS_BENCH_DEVICE=0: several ranks on ONE GPU, to exercise the N > 1
-    # code path on a single-GPU box (RCCL refuses two ranks on one device); never set by the driver
-    dist = shard.init(world, local, backend=os.environ.get("WMBUS_BENCH_BACKEND"))   # imports torch BEFORE the HIP library
+    # WMBUS_BENCH_BACKEND=gloo|none WMBUS_BENCH_DEVICE=0: several ranks on ONE GPU, to exercise the N > 1
+    # code path on a single-GPU box (RCCL refuses two ranks on one device); never set by the driver.  A backend that
+    # fails to initialise falls back (nccl -> gloo -> files): the data path needs no collective.
+    group = shard.init(world, local, backend=os.environ.get("WMBUS_BENCH_BACKEND") or ("gloo" if a.dry_run else None))   # imports torch BEFORE the HIP library
+    S, n = a.streams, a.samples
+    if a.dry_run:
+        # the N > 1 plumbing without a GPU: every rank names its captures, the ranks meet at the two barriers of the timed
+        # region, the reductions run, rank 0 prints ONE line
+        seeds = [shard.capture_seed(rank, S, s_) for s_ in (0, S - 1)]
+        shard.barrier(group)
+        t0 = time.perf_counter()
+        time.sleep(0.01 * (rank + 1))
+        shard.barrier(group)
+        elapsed = shard.max_over_ranks(group, time.perf_counter() - t0)
+        allseeds = shard.gather(group, seeds)
+        nctx = a.contexts or min(8, max(1, S // 64))
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "scaling": "weak", "seed_ranges": allseeds, "elapsed_s": round(elapsed, 4),
+                              "backend": getattr(group, "backend", None), "contexts_per_gpu": nctx,
+                              "host_threads_per_context": shard.host_threads_per_context(world, nctx)}), flush=True)
+        shard.destroy(group)
+        return 0
     local = int(os.environ.get("WMBUS_BENCH_DEVICE", local))
     wm = importlib.import_module("rtl-wmbus_amd")
     if wm.device_count() < 1:
         raise SystemExit("bench.py: no HIP device (the back end has no CPU fallback)")
-
-    S, n = a.streams, a.samples
-    nctx = max(1, min(a.contexts, S))
-    # captures per context in whole waves of 64 when possible (the clock kernel's cooperative loads need
-    # n_streams % 64 == 0), spread as evenly as the granule allows
-    gran = 64 if S % 64 == 0 and S // 64 >= nctx else 1
-    units = S // gran
-    per_ctx = [gran * (units // nctx + (1 if i < units % nctx else 0)) for i in range(nctx)]
     push_bytes = 2 * n
 
     # ---- synthetic captures (host, multi-threaded), then resident in HBM -------------------------
@@ -171,69 +181,52 @@ def main():
     with cf.ThreadPoolExecutor(min(os.cpu_count() or 1, 64)) as ex:
         list(ex.map(gen, range(S)))
     t_gen = time.perf_counter() - t0
-    rxs, base = [], 0
     t_h2d = time.perf_counter()
-    for i in range(nctx):
-        # host decoder threads: share the box between the ranks of a node and their contexts (2x
-        # oversubscribed: the contexts do not decode at the same time)
-        host_threads = a.host_threads or max(4, min(32, 2 * (os.cpu_count() or 16) // max(1, world * nctx)))
-        rx = wm.Receiver(n_streams=per_ctx[i], max_push_bytes=push_bytes, device=local, seg_len=a.seg_len, rla_seg_len=a.rla_seg_len,
-                         warmup_s1=a.warmup_s1, warmup_t1c1=a.warmup_t1c1, rla_lookback=a.rla_lookback, show_algorithm=True, fixed_timestamp=True,
-                         host_threads=host_threads, input_windows=2 if a.from_host else 1)
-        for s in range(per_ctx[i]):
-            rx.stage(s, caps[base + s])
-        rxs.append(rx)
-        base += per_ctx[i]
+    nctx_req = max(0, min(a.contexts, S))
+    nctx_guess = nctx_req or min(8, max(1, S // 64))
+    # host decoder threads per context: ranks x contexts x threads within the host's hardware threads
+    host_threads = a.host_threads or shard.host_threads_per_context(world, nctx_guess)
+    batch = wm.Batch(n_streams=S, contexts=nctx_req, max_push_bytes=push_bytes, device=local, seg_len=a.seg_len, rla_seg_len=a.rla_seg_len,
+                     warmup_s1=a.warmup_s1, warmup_t1c1=a.warmup_t1c1, rla_lookback=a.rla_lookback, show_algorithm=True, fixed_timestamp=True,
+                     host_threads=host_threads, input_windows=2 if a.from_host else 1)
+    nctx = len(batch.contexts)
+    per_ctx = [cnt for _, _, cnt in batch.contexts]
+    for s in range(S):
+        batch.stage(s, caps[s])
     t_h2d = time.perf_counter() - t_h2d      # includes buffer allocation; pageable host memory
 
     host_caps = None
-    if a.from_host:                                    # pinned copies of the captures, one slab per context
-        host_caps, base = [], 0
-        for i in range(nctx):
-            slab = wm.pinned_array(per_ctx[i] * push_bytes).reshape(per_ctx[i], push_bytes)
-            for s_ in range(per_ctx[i]):
-                slab[s_] = caps[base + s_]
-            host_caps.append(slab)
-            base += per_ctx[i]
-    pool = cf.ThreadPoolExecutor(nctx)
+    if a.from_host:                                    # pinned copies of the captures: the source stages from them itself (zero copy on the host)
+        host_caps = wm.pinned_array(S * push_bytes).reshape(S, push_bytes)
+        for s_ in range(S):
+            host_caps[s_] = caps[s_]
 
-    def run_ctx(i, k_steps, stagger_s):
-        """K passes of context i over its captures.  Contexts free-run (no barrier between steps), so
-        that one context's host decoding and re-run tails are covered by the other contexts'
-        kernels instead of all contexts idling in lock step."""
-        rx, lines, tims = rxs[i], 0, []
-        if stagger_s > 0 and i:
-            time.sleep(stagger_s * i)
-        def stage_all():                                      # pinned host memory -> the window the next push reads (copy stream)
-            for s_ in range(per_ctx[i]):
-                rx.stage(s_, host_caps[i][s_])
+    def run_steps(k_steps, timings=None):
+        """K passes of every context over its captures, driven by the library (wmbus_batch_run): the contexts free-run (no
+        barrier between steps), a context's next push is on the GPU while its previous one is decoded on the host."""
+        on_push = None
+        if timings is not None:
+            def on_push(first, cnt, _lines, tm):
+                timings.setdefault(first, []).append(tm)
         if a.from_host:
-            stage_all()
-        for k in range(k_steps):
-            t_a = time.perf_counter()
-            rx.process(push_bytes)
-            t_b = time.perf_counter()
-            if a.from_host and k + 1 < k_steps:
-                stage_all()                                   # the next push's bytes cross PCIe while this one is in flight (second input window)
-            rx.collect()
-            lines += rx.lines_count()
-            tm = rx.timing()
-            tm["process_wall_ms"] = (t_b - t_a) * 1e3
-            tm["collect_wall_ms"] = (time.perf_counter() - t_b) * 1e3
-            tims.append(tm)
-        return lines, tims
+            left = {f: k_steps for _, f, _ in batch.contexts}
 
-    def run_steps(k_steps, stagger_s):
-        res = list(pool.map(lambda i: run_ctx(i, k_steps, stagger_s), range(nctx)))
-        return sum(r[0] for r in res), [r[1] for r in res]
+            def fill(first, cnt, _slab):
+                if left[first] == 0:
+                    return 0
+                left[first] -= 1
+                for s_ in range(first, first + cnt):
+                    batch.stage(s_, host_caps[s_])            # pinned host memory -> the window the next push reads (copy stream)
+                return push_bytes
+            return batch.run_from(fill, on_push, self_staged=True, want_lines=False)
+        return batch.run_resident(push_bytes, k_steps, on_push, want_lines=False)
 
     def texts_of_last_push():
         """Datagram text of every capture (index within the rank's batch) as its context's last push printed it."""
-        per, base_ = collections.defaultdict(list), 0
-        for i, rx in enumerate(rxs):
+        per = collections.defaultdict(list)
+        for rx, first, _cnt in batch.contexts:
             for ln in rx.lines():
-                per[base_ + ln["stream"]].append(ln["text"])
-            base_ += per_ctx[i]
+                per[first + ln["stream"]].append(ln["text"])
         return ["".join(per[s_]) for s_ in range(S)]
 
     # ---- parity, part 1 (untimed, before the warm-up): the FIRST pass of every context starts from the
@@ -242,7 +235,7 @@ def main():
     parity, passes_done = None, 0
     if not a.no_check:
         import oracle_ffi as O
-        run_steps(1, 0.0)
+        run_steps(1)
         passes_done += 1
         got = texts_of_last_push()
         t_o = time.perf_counter()
@@ -251,24 +244,22 @@ def main():
         parity = {"first_pass": {"captures_compared": S, "contexts": nctx, "mismatches": len(bad), "first_bad": bad[:4],
                                  "datagrams": sum(len(t.splitlines()) for t in want), "oracle_s": round(time.perf_counter() - t_o, 1)}}
     if a.warmup:
-        run_steps(a.warmup, 0.0)
+        run_steps(a.warmup)
         passes_done += a.warmup
-    stagger = max(0.0, a.stagger)
 
-    def barrier():
-        shard.barrier(dist)
-
-    barrier()
+    shard.barrier(group)
     t0 = time.perf_counter()
-    lines_total, tim_ctx = run_steps(a.steps, stagger if nctx > 1 else 0.0)
-    barrier()
+    tim_by_ctx = {}
+    stats = run_steps(a.steps, tim_by_ctx)
+    shard.barrier(group)
     elapsed = time.perf_counter() - t0
     passes_done += a.steps
-    elapsed = shard.max_over_ranks(dist, elapsed)
-    lines_total = int(shard.sum_over_ranks(dist, lines_total))
+    elapsed = shard.max_over_ranks(group, elapsed)
+    lines_total = int(shard.sum_over_ranks(group, stats["lines"]))
+    tim_ctx = [tim_by_ctx.get(first, []) for _, first, _ in batch.contexts]
     demod_ms = sum(tm["demod_ms"] for tims in tim_ctx for tm in tims)
     k1_launches = sum(len(tims) for tims in tim_ctx)
-    tim_acc = [[tims[k] for tims in tim_ctx] for k in range(a.steps)]
+    tim_acc = [[tims[k] for tims in tim_ctx if k < len(tims)] for k in range(a.steps)]
 
     total_samples = world * S * n * a.steps
     value = total_samples / elapsed / 1e6
@@ -278,12 +269,14 @@ def main():
     # pass ALONE (still HIP events on the library's stream): that duration is the kernel's own.
     samples_per_launch = S * n / nctx
     alone_ms = []
-    if rank == 0:
-        for rx in rxs:
-            rx.process(push_bytes)
-            rx.collect()
-            alone_ms.append(rx.timing()["demod_ms"])
-        passes_done += 1
+    if a.from_host:
+        for s_ in range(S):
+            batch.stage(s_, host_caps[s_])
+    for rx, _first, _cnt in batch.contexts:
+        rx.process(push_bytes)
+        rx.collect()
+        alone_ms.append(rx.timing()["demod_ms"])
+    passes_done += 1
     k1_avg_s = sum(alone_ms) / max(1, len(alone_ms)) / 1e3
     k1_concurrent_ms = demod_ms / max(1, k1_launches)
     achieved = BYTES_PER_SAMPLE * samples_per_launch / k1_avg_s / 1e9 if k1_avg_s > 0 else 0.0
@@ -295,23 +288,23 @@ def main():
         except Exception:
             traffic = None
 
-    # ---- parity, part 2: the LAST pass (carried filter / framer / decoder state of every earlier pass) of the
-    # first and last capture of every 64-capture wave of every context, against an oracle instance that has been
+    # ---- parity, part 2: the LAST pass (carried filter / framer / decoder state of every earlier pass) of eight
+    # captures of every 64-capture wave of every context (128 of 1024), against an oracle instance that has been
     # fed the same capture the same number of times.
     if parity is not None:
         got = texts_of_last_push()
-        picks, base_ = [], 0
-        for i in range(nctx):
-            for w0 in range(0, per_ctx[i], 64):
-                picks += sorted({base_ + w0, base_ + min(w0 + 63, per_ctx[i] - 1)})
-            base_ += per_ctx[i]
+        picks = []
+        for _rx, first, cnt in batch.contexts:
+            for w0 in range(0, cnt, 64):
+                w = min(64, cnt - w0)
+                picks += sorted({first + w0 + (j * (w - 1)) // 7 for j in range(8)} if w > 1 else {first + w0})
         t_o = time.perf_counter()
         want = O.run_many([caps[s_] for s_ in picks], O.make_opts(), passes=passes_done,
                           threads=max(1, (os.cpu_count() or 1) // max(1, world)))
         bad = [s_ for s_, w in zip(picks, want) if got[s_] != w]
         parity["last_pass"] = {"captures_compared": len(picks), "contexts": nctx, "pass_number": passes_done, "mismatches": len(bad),
                                "first_bad": bad[:4], "oracle_s": round(time.perf_counter() - t_o, 1)}
-        n_bad = int(shard.sum_over_ranks(dist, parity["first_pass"]["mismatches"] + len(bad)))
+        n_bad = int(shard.sum_over_ranks(group, parity["first_pass"]["mismatches"] + len(bad)))
         parity["ranks"] = world
         parity["ok"] = n_bad == 0
 
@@ -335,8 +328,10 @@ def main():
         except Exception:
             valu = None
 
+    ok = True
     if rank == 0:
-        last = tim_acc[-1]
+        def rnd(t):
+            return {k: round(v, 3) if isinstance(v, float) else v for k, v in t.items()}
         out = {
             "metric": "Msamples/s cu8 IQ->datagrams, 1024x1.6MS/s streams; %HBM roofline",
             "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -344,8 +339,9 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{S} synthetic 1.6 MS/s cu8 captures x {n} IQ samples per GPU, T1+C1 bursts, "
                                    f"default switches (T1/C1 + S1 chains, time2 + run-length framers), HBM-resident input",
-                       "streams_per_gpu": S, "samples_per_stream": n, "contexts_per_gpu": nctx,
-                       "parallelism": f"file-per-GPU x{world}, no collective"},
+                       "streams_per_gpu": S, "samples_per_stream": n, "contexts_per_gpu": nctx, "host_threads_per_context": host_threads,
+                       "orchestration": "wmbus_batch_run (libwmbus_hip.so): contexts, worker threads, pipelined host decode and the hardware-queue default live in the library",
+                       "parallelism": f"file-per-GPU x{world}, no collective", "group_backend": getattr(group, "backend", None)},
             "hbm_roofline_pct_whole_job": round(100.0 * BYTES_PER_SAMPLE * value * 1e6 / world / 1e9 / HBM_PEAK_GBPS, 3),
             "datagrams_per_step": lines_total // max(1, a.steps),
             "roofline": {"bound": "hbm", "kernel": "k1_demod2", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
@@ -359,15 +355,21 @@ def main():
                          "valu": valu,
                          "dominant": "k1_demod2 is the largest kernel of the job by work (two thirds of its VALU instructions; 20 of the 45 ms the "
                                      "kernels take one after the other, profiles/*_single_context_kernel_stats.csv) and the one the roofline is quoted "
-                                     "for; in this 8-context configuration the framer kernels (k2_clock, k2_clock_rla) are RESIDENT longer (about 60 % of "
+                                     "for; in this 8-context configuration the framer kernels (k2_clock, k2_rla) are RESIDENT longer (about 60 % of "
                                      "the summed kernel durations, profiles/*_bench_kernel_stats.csv) because they are latency-bound and overlap it",
                          "how": "HIP events around k1_demod2 on the library's stream, one context at a time after the timed "
                                 "region (inside it a launch runs beside the other contexts' kernels: avg %.3f ms each)" % k1_concurrent_ms},
-            "stage_ms_last_step": [{k: round(v, 3) if isinstance(v, float) else v for k, v in t.items()} for t in last],
-            "stage_ms_mid_step": [{k: round(v, 3) if isinstance(v, float) else v for k, v in t.items()} for t in tim_acc[a.steps // 2]],
+            "stage_ms_last_step": [rnd(t) for t in (tim_acc[-1] if tim_acc else [])],
+            "stage_ms_mid_step": [rnd(t) for t in (tim_acc[a.steps // 2] if tim_acc else [])],
             "setup_s": {"generate": round(t_gen, 1), "alloc_and_h2d": round(t_h2d, 1)},
             "input": "staged from pinned host memory inside every step (PCIe-inclusive, informational)" if a.from_host else "resident in HBM",
         }
+        cli = os.path.join(ROOT, "profiles", "cli_rate.json")     # tools/bench_cli.sh: the product's own command line, wall-clocked
+        if os.path.exists(cli):
+            try:
+                out["cli"] = json.load(open(cli))
+            except Exception:
+                pass
         if world == 1 and not a.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(caps, n)
@@ -379,12 +381,14 @@ def main():
             out["parity_check"] = (f"{fp['captures_compared']} captures x {nctx} contexts (first pass, all of them) and {lp['captures_compared']} captures "
                                    f"across {nctx} contexts (pass {lp['pass_number']}, carried state) identical to the oracle"
                                    if parity["ok"] else "MISMATCH")
+            ok = bool(parity["ok"])
         print(json.dumps(out), flush=True)
-    for rx in rxs:
-        rx.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    elif parity is not None:
+        ok = bool(parity["ok"])
+    batch.close()
+    shard.destroy(group)
+    return 0 if ok else 3                                     # a rate whose datagrams differ from the reference's is not a result
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -169,6 +169,59 @@ int  wmbus_selftest_math(int device, const float *a, const float *b, float *o_sq
 /* Number of visible HIP devices (0 if none). */
 int  wmbus_device_count(void);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Many captures on one device.  The reference is one stream per process (rtl_wmbus.c:1298-1356 IS its product); a
+ * batch is `cfg->n_streams` of those loops side by side.  The library splits the captures over several receiver
+ * contexts (default: 8, whole 64-capture groups each), drives every context on its own thread through the same
+ * stage / process / collect steps as above, and overlaps them: one context's demodulation kernel runs beside the other
+ * contexts' framer kernels and host decoding, and a context's next push is already on the GPU while its previous one
+ * is decoded on the host.  This is what `rtl_wmbus_hip FILE...` and bench.py run.
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct wmbus_batch wmbus_batch;
+
+typedef struct wmbus_batch_io {
+    /* SOURCE.  fill != NULL (needs cfg.input_windows = 2): called on a worker thread whenever streams
+     * [first_stream, first_stream + n_streams) need their next push.  Write the bytes of stream s at
+     * slab + (s - first_stream) * pitch (page-locked memory, `cap` bytes per stream) and return the byte count EVERY
+     * stream of the group advances by (a multiple of 4096, <= cap; pad ended streams with 128 = no signal), or 0 when
+     * the group's input has ended.  Calls for different groups may run concurrently.
+     * fill == NULL: the input is resident in the device windows (wmbus_batch_stage / wmbus_batch_device_input):
+     * every context makes `passes` pushes of `resident_bytes`. */
+    size_t (*fill)(void *user, unsigned first_stream, unsigned n_streams, uint8_t *slab, size_t pitch, size_t cap);
+    /* SINK (optional).  The lines of one push of one group, in the reference's stdout order per stream
+     * (wmbus_line.stream counts within the whole batch); calls are serialised, a push's lines leave as a unit. */
+    void (*lines)(void *user, unsigned first_stream, unsigned n_streams, const wmbus_line *lines, size_t n_lines,
+                  const char *text, const wmbus_timing *timing);
+    void *user;
+    size_t resident_bytes;
+    unsigned passes;
+    /* 1: `fill` stages the group's bytes itself with wmbus_batch_stage() from page-locked memory of its own (slab is
+     * NULL then): no host-side copy between the source and the PCIe transfer. */
+    unsigned self_staged;
+} wmbus_batch_io;
+
+typedef struct wmbus_batch_stats {
+    uint64_t samples;           /* input IQ samples consumed, all streams        */
+    uint64_t lines;             /* datagram lines produced                       */
+    double   seconds;           /* wall clock of wmbus_batch_run                 */
+    unsigned pushes;            /* context pushes                                */
+    unsigned warnings;          /* WMBUS_WARN_* seen                             */
+} wmbus_batch_stats;
+
+/* cfg->n_streams = all captures of the batch; contexts = 0: the default split.  On failure *out still holds an
+ * object whose wmbus_batch_last_error() explains; close it. */
+int  wmbus_batch_open(const wmbus_cfg *cfg, unsigned contexts, wmbus_batch **out);
+void wmbus_batch_close(wmbus_batch *b);
+const char *wmbus_batch_last_error(const wmbus_batch *b);
+unsigned wmbus_batch_contexts(const wmbus_batch *b);
+/* Context i and the streams it serves (its own wmbus_lines / wmbus_get_timing / taps describe its last push). */
+wmbus_ctx *wmbus_batch_context(wmbus_batch *b, unsigned i, unsigned *first_stream, unsigned *n_streams);
+/* wmbus_stage / wmbus_device_input by batch-wide stream number. */
+int  wmbus_batch_stage(wmbus_batch *b, unsigned stream, const uint8_t *cu8, size_t nbytes);
+void *wmbus_batch_device_input(wmbus_batch *b, unsigned stream);
+/* Runs until every group's source has ended (or `passes` pushes per context).  Returns 0 or the first error. */
+int  wmbus_batch_run(wmbus_batch *b, const wmbus_batch_io *io, wmbus_batch_stats *stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,7 +66,24 @@ class Timing(ctypes.Structure):
         return d
 
 
-EXPORTS = ["wmbus_default_cfg", "wmbus_open", "wmbus_close", "wmbus_last_error", "wmbus_stage", "wmbus_device_input",
+FILL_FN = ctypes.CFUNCTYPE(ctypes.c_size_t, ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t)
+LINES_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint, ctypes.POINTER(Line), ctypes.c_size_t, ctypes.c_void_p,
+                            ctypes.POINTER(Timing))
+
+
+class BatchIo(ctypes.Structure):
+    _fields_ = [("fill", FILL_FN), ("lines", LINES_FN), ("user", ctypes.c_void_p), ("resident_bytes", ctypes.c_size_t), ("passes", ctypes.c_uint),
+                ("self_staged", ctypes.c_uint)]
+
+
+class BatchStats(ctypes.Structure):
+    _fields_ = [("samples", ctypes.c_uint64), ("lines", ctypes.c_uint64), ("seconds", ctypes.c_double), ("pushes", ctypes.c_uint),
+                ("warnings", ctypes.c_uint)]
+
+
+EXPORTS = ["wmbus_batch_open", "wmbus_batch_close", "wmbus_batch_last_error", "wmbus_batch_contexts", "wmbus_batch_context", "wmbus_batch_stage",
+           "wmbus_batch_device_input", "wmbus_batch_run",
+           "wmbus_default_cfg", "wmbus_open", "wmbus_close", "wmbus_last_error", "wmbus_stage", "wmbus_device_input",
            "wmbus_process", "wmbus_collect", "wmbus_lines", "wmbus_lines_text", "wmbus_get_timing", "wmbus_read_tap",
            "wmbus_read_chips", "wmbus_device_count", "wmbus_selftest_math", "wmbus_alloc_pinned", "wmbus_free_pinned"]
 
@@ -98,6 +115,14 @@ def lib():
         L.wmbus_alloc_pinned.argtypes = [sz]; L.wmbus_alloc_pinned.restype = vp
         L.wmbus_free_pinned.argtypes = [vp]
         L.wmbus_selftest_math.argtypes = [ctypes.c_int] + [vp] * 6 + [sz]
+        L.wmbus_batch_open.argtypes = [ctypes.POINTER(Cfg), u, ctypes.POINTER(vp)]
+        L.wmbus_batch_close.argtypes = [vp]
+        L.wmbus_batch_last_error.argtypes = [vp]; L.wmbus_batch_last_error.restype = ctypes.c_char_p
+        L.wmbus_batch_contexts.argtypes = [vp]; L.wmbus_batch_contexts.restype = u
+        L.wmbus_batch_context.argtypes = [vp, u, ctypes.POINTER(u), ctypes.POINTER(u)]; L.wmbus_batch_context.restype = vp
+        L.wmbus_batch_stage.argtypes = [vp, u, vp, sz]
+        L.wmbus_batch_device_input.argtypes = [vp, u]; L.wmbus_batch_device_input.restype = vp
+        L.wmbus_batch_run.argtypes = [vp, ctypes.POINTER(BatchIo), ctypes.POINTER(BatchStats)]
         _lib = L
     return _lib
 
@@ -130,6 +155,103 @@ def selftest_math(a, b, device=0):
     return dict(sqrt=outs[0], div=outs[1], atan2=outs[2], disc=outs[3])
 
 
+def _make_cfg(n_streams=1, max_push_bytes=4 << 20, decimation=2, simultaneous=False, accurate_atan=True,
+              remove_dc=False, t1c1=True, s1=True, rla=True, time2=True, show_algorithm=True, device=0,
+              seg_len=0, rla_seg_len=0, warmup_t1c1=0, warmup_s1=0, rla_lookback=0, host_threads=0, fixed_timestamp=True,
+              prefilter=0, atan_mode=0, keep_taps=True, spill_words=0, input_windows=1, dedup_twins=False, only_crc_ok=False):
+    c = Cfg()
+    lib().wmbus_default_cfg(ctypes.byref(c))
+    c.decimation, c.simultaneous, c.accurate_atan, c.remove_dc = decimation, int(simultaneous), int(accurate_atan), int(remove_dc)
+    c.t1c1_enabled, c.s1_enabled, c.rla_enabled, c.time2_enabled = int(t1c1), int(s1), int(rla), int(time2)
+    c.show_algorithm, c.fixed_timestamp = int(show_algorithm), int(fixed_timestamp)
+    c.n_streams, c.device, c.max_push_bytes = n_streams, device, max_push_bytes
+    c.seg_len, c.rla_seg_len, c.warmup_t1c1, c.warmup_s1 = seg_len, rla_seg_len, warmup_t1c1, warmup_s1
+    c.rla_lookback, c.host_threads = rla_lookback, host_threads
+    c.keep_taps, c.prefilter, c.atan_mode, c.spill_words, c.input_windows = int(keep_taps), prefilter, atan_mode, spill_words, input_windows
+    c.dedup_twins, c.only_crc_ok = int(dedup_twins), int(only_crc_ok)
+    return c
+
+
+class Batch:
+    """wmbus_batch_*: `n_streams` captures on one device, split over several receiver contexts that the LIBRARY drives
+    (include/wmbus_hip.h).  Keyword arguments as for Receiver; `contexts` = 0 takes the library's default split."""
+
+    def __init__(self, n_streams, contexts=0, **kw):
+        L = lib()
+        self.cfg = _make_cfg(n_streams=n_streams, **kw)
+        self.n_streams = n_streams
+        self._h = ctypes.c_void_p()
+        rc = L.wmbus_batch_open(ctypes.byref(self.cfg), contexts, ctypes.byref(self._h))
+        if rc:
+            msg = L.wmbus_batch_last_error(self._h).decode() if self._h else "allocation failed"
+            L.wmbus_batch_close(self._h)
+            self._h = None
+            raise WmbusError(f"wmbus_batch_open failed ({rc}): {msg}")
+        self.contexts = []                                  # (Receiver view, first stream, streams)
+        for i in range(L.wmbus_batch_contexts(self._h)):
+            f, n = ctypes.c_uint(), ctypes.c_uint()
+            h = L.wmbus_batch_context(self._h, i, ctypes.byref(f), ctypes.byref(n))
+            self.contexts.append((Receiver._view(h, n.value), f.value, n.value))
+
+    def close(self):
+        if self._h:
+            lib().wmbus_batch_close(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc):
+        if rc:
+            raise WmbusError(f"error {rc}: {lib().wmbus_batch_last_error(self._h).decode()}")
+
+    def stage(self, stream, cu8):
+        cu8 = np.ascontiguousarray(cu8, dtype=np.uint8)
+        self._chk(lib().wmbus_batch_stage(self._h, stream, cu8.ctypes.data, cu8.size))
+
+    def run_resident(self, nbytes, passes, on_push=None, want_lines=True):
+        """Every context makes `passes` pushes of the `nbytes` staged per stream.  on_push(first_stream, n_streams,
+        [line dicts] (None unless want_lines), timing dict) is called per context push if given.  Returns the stats."""
+        return self._run(BatchIo(FILL_FN(), self._sink(on_push, want_lines), None, nbytes, passes, 0))
+
+    def run_from(self, fill, on_push=None, self_staged=False, want_lines=True):
+        """Host-sourced run (input_windows=2): fill(first_stream, n_streams, slab) -> bytes per stream, where slab is a
+        uint8 array [n_streams, max_push_bytes] over the library's page-locked staging memory (None with self_staged:
+        the callback then stages from pinned memory of its own with Batch.stage); 0 ends that group."""
+        def c_fill(user, first, n, slab, pitch, cap_):
+            a = None
+            if slab:
+                a = np.ctypeslib.as_array(ctypes.cast(slab, ctypes.POINTER(ctypes.c_uint8)), shape=(n * pitch,)).reshape(n, pitch)[:, :cap_]
+            return int(fill(first, n, a))
+        return self._run(BatchIo(FILL_FN(c_fill), self._sink(on_push, want_lines), None, 0, 0, int(self_staged)))
+
+    def _sink(self, on_push, want_lines=True):
+        if on_push is None:
+            return LINES_FN()
+
+        def c_lines(user, first, n, lines, n_lines, text, timing):
+            recs = None
+            if want_lines:
+                recs = []
+                for k in range(n_lines):
+                    ln = lines[k]
+                    recs.append(dict(stream=ln.stream, chain=ln.chain, algo=ln.algo, crc_ok=ln.crc_ok, sample=ln.sample,
+                                     text=ctypes.string_at(text + ln.text_off, ln.text_len).decode()))
+            on_push(first, n, recs, timing.contents.as_dict())
+        return LINES_FN(c_lines)
+
+    def _run(self, io):
+        st = BatchStats()
+        self._io = io                                       # the callbacks must outlive the call
+        self._chk(lib().wmbus_batch_run(self._h, ctypes.byref(io), ctypes.byref(st)))
+        return dict(samples=int(st.samples), lines=int(st.lines), seconds=float(st.seconds), pushes=int(st.pushes), warnings=int(st.warnings))
+
+
 class Receiver:
     """`n_streams` captures through the GPU back end, in lock step.
 
@@ -138,25 +260,9 @@ class Receiver:
     show_algorithm (-v).
     """
 
-    def __init__(self, n_streams=1, max_push_bytes=4 << 20, decimation=2, simultaneous=False, accurate_atan=True,
-                 remove_dc=False, t1c1=True, s1=True, rla=True, time2=True, show_algorithm=True, device=0,
-                 seg_len=0, rla_seg_len=0, warmup_t1c1=0, warmup_s1=0, rla_lookback=0, host_threads=0, fixed_timestamp=True,
-                 prefilter=0, atan_mode=0, keep_taps=True, spill_words=0, input_windows=1, dedup_twins=False, only_crc_ok=False):
+    def __init__(self, n_streams=1, **kw):
         L = lib()
-        c = Cfg()
-        L.wmbus_default_cfg(ctypes.byref(c))
-        c.decimation, c.simultaneous, c.accurate_atan, c.remove_dc = decimation, int(simultaneous), int(accurate_atan), int(remove_dc)
-        c.t1c1_enabled, c.s1_enabled, c.rla_enabled, c.time2_enabled = int(t1c1), int(s1), int(rla), int(time2)
-        c.show_algorithm, c.fixed_timestamp = int(show_algorithm), int(fixed_timestamp)
-        c.n_streams, c.device, c.max_push_bytes = n_streams, device, max_push_bytes
-        c.seg_len, c.rla_seg_len, c.warmup_t1c1, c.warmup_s1 = seg_len, rla_seg_len, warmup_t1c1, warmup_s1
-        c.rla_lookback, c.host_threads = rla_lookback, host_threads
-        c.keep_taps = int(keep_taps)
-        c.prefilter = prefilter
-        c.atan_mode = atan_mode
-        c.spill_words = spill_words
-        c.input_windows = input_windows
-        c.dedup_twins, c.only_crc_ok = int(dedup_twins), int(only_crc_ok)
+        c = _make_cfg(n_streams=n_streams, **kw)
         self.cfg = c
         self.n_streams = n_streams
         self._h = ctypes.c_void_p()
@@ -167,10 +273,17 @@ class Receiver:
             self._h = None
             raise WmbusError(f"wmbus_open failed ({rc}): {msg}")
 
+    @classmethod
+    def _view(cls, handle, n_streams):
+        """A Receiver over a context someone else owns (a wmbus_batch): never closed from here."""
+        r = cls.__new__(cls)
+        r._h, r._borrowed, r.n_streams, r.cfg = ctypes.c_void_p(handle), True, n_streams, None
+        return r
+
     def close(self):
-        if self._h:
+        if getattr(self, "_h", None) and not getattr(self, "_borrowed", False):
             lib().wmbus_close(self._h)
-            self._h = None
+        self._h = None
 
     __del__ = close
 

@@ -23,6 +23,8 @@
 #include <thread>
 #include <vector>
 
+#include <sys/time.h>
+
 #include "../../include/wmbus_hip.h"
 #include "wm_decoder.h"
 #include "wm_dev.h"
@@ -159,6 +161,14 @@ struct wmbus_ctx {
     std::vector<wmbus_line> lines; std::string text;
     WmPush last{}; bool have_last = false, in_flight = false;
     uint64_t push_seq = 0;                              /* pushes enqueued so far */
+    /* A push is enqueued in two parts: FRONT (input history, K1, hand-off rounds, both framers, carried state) and BACK
+     * (the chips half-received telegrams are owed, K3, the scalars).  Only the back needs what the host packet decoders
+     * left behind, so a caller that pipelines (wmbus_batch) enqueues the next push's front BEFORE it decodes the previous
+     * one on the host: 2 ms less in every context's chain of dependent work.  wmbus_process = front + back. */
+    bool back_due = false, enqueued = false;            /* front enqueued, back not yet; something of this push reached the stream */
+    struct timeval arrival{};                           /* wall clock when the push was handed over (its last byte had arrived) */
+    /* what wait_gpu() found, kept apart from `last` & co. because the next push's front may be enqueued before decode_host() */
+    struct { uint32_t n_hdr = 0, n_pkts = 0; uint64_t m_end = 0, seq = 0; struct timeval arrival{}; bool valid = false; } done;
     std::atomic<uint32_t> short_burst{0};               /* set by the decoder threads of one collect: 1 + header index */
     wmbus_timing tim{};
 };
@@ -289,6 +299,12 @@ __global__ void k_selftest(const float *a, const float *b, float *o_sqrt, float 
  * everything behind K1 made the turn 2.9 ms longer than the kernel). */
 struct K1Chain { std::mutex m; hipEvent_t last = nullptr; const wmbus_ctx *owner = nullptr; };
 K1Chain k1_chain[16];
+
+/* One HIP stream per receiver context; ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default) round
+ * robin, and streams that share a queue serialise against each other: eight contexts on four queues lose 25 %.  The
+ * runtime reads the variable when it initialises (the first HIP call of the process), so the library sets its default
+ * when it is loaded -- a caller's own setting wins.  (bench.py and INTEGRATION.md used to ask the caller for this.) */
+__attribute__((constructor)) void wm_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 
 double now_ms()
 {
@@ -664,15 +680,14 @@ static int launch_k3(wmbus_ctx *c, bool again)
     return 0;
 }
 
-int wmbus_process(wmbus_ctx *c, size_t nbytes)
+static int enqueue_front_impl(wmbus_ctx *c, size_t nbytes)
 {
-    if (!c) return WMBUS_EINVAL;
     if (nbytes == 0 || nbytes > c->cfg.max_push_bytes || nbytes % WMBUS_BLOCK_BYTES)
         return fail(c, WMBUS_EINVAL, "process: nbytes must be a positive multiple of 4096 and <= max_push_bytes");
     if (c->in_flight) return fail(c, WMBUS_EINVAL, "process: previous push not collected");
     HIPCHK(c, hipSetDevice(c->cfg.device));            /* HIP's current device is per host thread; a context may be driven from any */
     if (c->poisoned) return fail(c, WMBUS_EDEVICE, "process: an earlier internal error left this context unusable; close it");
-    c->tim = wmbus_timing{};
+    gettimeofday(&c->arrival, nullptr);
     if (c->committed) { c->carry_in ^= 1u; c->committed = false; }     /* the previous push's end state is this one's start state */
     const uint32_t n_new = (uint32_t)(nbytes / 2);
     uint8_t *win = c->d_in + (size_t)c->fill * c->S * c->in_stride;      /* the window wmbus_stage has been filling */
@@ -692,6 +707,7 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
     g.sp.used = c->d_nchain + (size_t)2 * c->S * c->nseg_cap[0];
     c->last = g; c->have_last = true;
     c->n_hdr = c->n_words = c->n_pkts = 0;
+    c->enqueued = true;                                 /* from here on a failure leaves half a push on the stream: the context is poisoned */
 
     /* the staged bytes arrive on the copy stream */
     if (c->copy_stream != c->stream) {
@@ -702,17 +718,11 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
     hipLaunchKernelGGL(k_copy_hist, dim3(c->S), dim3(256), 0, c->stream, c->d_hist, (uint64_t)WM_HIST_BYTES, (uint64_t)0, win, c->in_stride);
     if (g.M > 0) {
         HIPCHK(c, hipMemsetAsync(c->d_scalars, 0, c->zero_words * sizeof(uint32_t), c->stream));     /* scalars, region flags, spill chains */
-        /* chips the decoders of half-received telegrams still want: known since the previous collect */
-        for (uint32_t s = 0; s < c->S; s++)
-            for (int ch = 0; ch < 2; ch++)
-                for (int al = 0; al < 2; al++)
-                    c->h_pending[(al * 2 + ch) * c->S + s] = c->decs[((size_t)s * 2 + ch) * 2 + al].owed;
-        HIPCHK(c, hipMemcpyAsync(c->d_pending, c->h_pending, 4 * c->S * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         /* K1 */
         const uint32_t T = c->T, ntiles = (g.M + T - 1) / T;
         c->ntiles = ntiles;
         c->k1a = K1Args{g, c->d_dphi, c->d_rssi, c->d_lut, c->d_lut + 32 * WM_MAX_DECIM, c->d_ema_head, c->d_ema_tail, ntiles, c->d_scalars + SC_ERR,
-                        nullptr, ema_carry(c, false), nullptr};
+                        nullptr, ema_carry(c, false), nullptr, 0u};
         static const int turns = getenv("WMBUS_K1_TURNS") ? atoi(getenv("WMBUS_K1_TURNS")) : 1;      /* 0: no order (A/B) */
         int rc;
         {
@@ -723,6 +733,12 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
                 if (kc.last && kc.owner != c) HIPCHK(c, hipStreamWaitEvent(c->stream, kc.last, 0));
             }
             HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+            static const uint32_t k1_grid = getenv("WMBUS_K1_GRID") ? (uint32_t)atoi(getenv("WMBUS_K1_GRID")) : 0u;   /* tuning aid: bounded first-pass grid */
+            if (k1_grid && (uint64_t)ntiles * c->S > k1_grid && c->cfg.prefilter != WMBUS_PREFILTER_POLYPHASE) {
+                K1Args k1 = c->k1a;
+                k1.n_items = ntiles * c->S;
+                rc = launch_k1_any(c, k1, dim3(k1_grid, 1));
+            } else
             rc = launch_k1_any(c, c->k1a, dim3(ntiles, c->S));
             if (rc) return rc;
             HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
@@ -782,13 +798,6 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
         HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
         fr_carry(c);
         c->committed = true;
-
-        HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
-        rc = launch_k3(c, false);
-        if (rc) return rc;
-        HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, SC_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
     }
     /* the next push sees the last 4096 staged bytes in front of it */
     hipLaunchKernelGGL(k_copy_hist, dim3(c->S), dim3(256), 0, c->stream, win, c->in_stride, (uint64_t)nbytes, c->d_hist, (uint64_t)WM_HIST_BYTES);
@@ -796,8 +805,53 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
     c->fill = (c->fill + 1) % c->n_win;
     c->n0 += n_new;
     c->push_seq++;
-    c->in_flight = true;
+    c->in_flight = true; c->back_due = true;
     return WMBUS_OK;
+}
+
+/* BACK of a push: what needs the host decoders' state after the previous push -- the chips half-received telegrams are
+ * still owed -- then K3 on the settled chip streams and the scalars for the host. */
+static int enqueue_back_impl(wmbus_ctx *c)
+{
+    if (!c->back_due) return WMBUS_OK;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    c->back_due = false;
+    if (c->last.M > 0) {
+        for (uint32_t s = 0; s < c->S; s++)
+            for (int ch = 0; ch < 2; ch++)
+                for (int al = 0; al < 2; al++)
+                    c->h_pending[(al * 2 + ch) * c->S + s] = c->decs[((size_t)s * 2 + ch) * 2 + al].owed;
+        HIPCHK(c, hipMemcpyAsync(c->d_pending, c->h_pending, 4 * c->S * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
+        const int rc = launch_k3(c, false);
+        if (rc) return rc;
+        HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, SC_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
+    }
+    return WMBUS_OK;
+}
+
+/* a failure after the first enqueue leaves half a push on the stream and the carried state undefined */
+static int enqueue_front(wmbus_ctx *c, size_t nbytes)
+{
+    c->enqueued = false;
+    const int rc = enqueue_front_impl(c, nbytes);
+    if (rc && c->enqueued) c->poisoned = true;
+    return rc;
+}
+static int enqueue_back(wmbus_ctx *c)
+{
+    const int rc = enqueue_back_impl(c);
+    if (rc) c->poisoned = true;
+    return rc;
+}
+
+int wmbus_process(wmbus_ctx *c, size_t nbytes)
+{
+    if (!c) return WMBUS_EINVAL;
+    const int rc = enqueue_front(c, nbytes);
+    return rc ? rc : enqueue_back(c);
 }
 
 /* The optimistic rounds of wmbus_process left work: finish it round by round with the host in the loop (rare: a
@@ -874,6 +928,18 @@ static EntryKey entry_key(const wmbus_ctx *c, const Entry &e)
  * reference's decoder would do with them -- an access code that passes while the decoder is busy is ignored
  * (t1_c1_packet_decoder.h:272-278), a telegram the GPU has assembled is stripped and formatted, a burst cut by the end
  * of the push goes chip by chip through the persistent host decoder. */
+/* TIMESTAMP field of a line.  The reference stamps a telegram when its last chip is processed (t1_c1_packet_decoder.h:
+ * 390,458, s1_packet_decoder.h:229), which behind a live SDR is the moment that sample arrived.  A push is handed over
+ * when its LAST sample has arrived, so a telegram completed by decimated sample m of the push was on the air
+ * (m_end - 1 - m) / 800 kHz earlier (the decimated rate is 800 kS/s whatever -d is, rtl_wmbus.c:1296). */
+static void line_timestamp(const wmbus_ctx *c, uint64_t sample, const char *ts_fixed, char *ts, size_t cap)
+{
+    if (ts_fixed) { snprintf(ts, cap, "%s", ts_fixed); return; }
+    const uint64_t back = c->done.m_end > sample ? c->done.m_end - 1u - sample : 0u;
+    const int64_t us = (int64_t)c->done.arrival.tv_sec * 1000000 + c->done.arrival.tv_usec - (int64_t)(back * 5u / 4u);   /* 1.25 us per decimated sample */
+    wm_timestamp_at(ts, cap, (long)(us / 1000000), (long)(us % 1000000));
+}
+
 static void decode_stream_range(wmbus_ctx *c, const std::vector<Entry> &order, size_t lo, size_t hi,
                                 std::vector<LineRec> &out, const char *ts_fixed)
 {
@@ -901,7 +967,7 @@ static void decode_stream_range(wmbus_ctx *c, const std::vector<Entry> &order, s
                  * stored read as zero in the ident field of its line (get_serial looks at bytes 4..7 whatever L is) */
                 memset(pkt, 0, sizeof pkt);
                 memcpy(pkt, c->h_bytes + p.off, nb);
-                if (ts_fixed) snprintf(ts, sizeof ts, "%s", ts_fixed); else wm_timestamp(ts, sizeof ts);
+                line_timestamp(c, p.sample, ts_fixed, ts, sizeof ts);
                 const int ok = (p.flags & WM_PKTF_CRC_OK) != 0;
                 const size_t n = wm_packet_format(p.chain ? WM_MODE_S1 : WM_MODE_T1C1, (p.flags & WM_PKTF_C1) != 0, (p.flags & WM_PKTF_FRAME_B) != 0,
                                                   (p.flags & WM_PKTF_ERR3OF6) != 0, ok, p.L, pkt, p.pkt_rssi, p.rssi_now, tag, ts, line, sizeof line);
@@ -927,7 +993,7 @@ static void decode_stream_range(wmbus_ctx *c, const std::vector<Entry> &order, s
                 st = wm_decoder_chip(&hd.dec, val & 3u, rssi);
                 if (st == WM_DEC_DONE) {
                     int ok = 0;
-                    if (ts_fixed) snprintf(ts, sizeof ts, "%s", ts_fixed); else wm_timestamp(ts, sizeof ts);
+                    line_timestamp(c, h.pos0 + (word >> 11), ts_fixed, ts, sizeof ts);
                     const size_t n = wm_decoder_format(&hd.dec, tag, ts, rssi, line, sizeof line, &ok);
                     LineRec r; r.sample = h.pos0 + (word >> 11); r.stream = h.stream; r.chain = h.chain; r.algo = h.algo;
                     r.crc_ok = (uint8_t)ok; r.seq = seq++; r.text.assign(line, n);
@@ -943,21 +1009,23 @@ static void decode_stream_range(wmbus_ctx *c, const std::vector<Entry> &order, s
                 c->short_burst.compare_exchange_strong(none, 1u + order[j].idx);
             }
             hd.owed = cut ? std::max(1u, wm_decoder_chips_owed(&hd.dec)) : 0u;
-            hd.fed = c->push_seq;
+            hd.fed = c->done.seq;
         }
         i = j;
     }
 }
 
-int wmbus_collect(wmbus_ctx *c)
+/* First half of wmbus_collect: wait for the push, finish leftover hand-off rounds, read the counters.  Afterwards the
+ * candidate telegrams sit in pinned host memory and nothing of this push is left on the GPU. */
+static int wait_gpu(wmbus_ctx *c)
 {
-    if (!c) return WMBUS_EINVAL;
-    c->lines.clear(); c->text.clear();
-    c->short_burst.store(0);
+    c->done.valid = false;
     if (!c->in_flight) return WMBUS_OK;
+    if (c->back_due) { const int rc = enqueue_back(c); if (rc) return rc; }
     HIPCHK(c, hipSetDevice(c->cfg.device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->in_flight = false;
+    c->tim = wmbus_timing{};
     if (c->last.M > 0) {
         float ms = 0;
         hipEventElapsedTime(&ms, c->ev[3], c->ev[4]); c->tim.demod_ms = ms;
@@ -992,11 +1060,25 @@ int wmbus_collect(wmbus_ctx *c)
         for (int al = 0; al < 2; al++) for (int ch = 0; ch < 2; ch++) c->tim.chips[ch][al] = hs[SC_CHIPS + al * 2 + ch];
     }
     c->tim.bursts = c->n_hdr + c->n_pkts;
-    const double t0 = now_ms();
+    c->done.n_hdr = c->n_hdr; c->done.n_pkts = c->n_pkts; c->done.m_end = c->last.m0 + c->last.M; c->done.arrival = c->arrival; c->done.seq = c->push_seq;
+    c->done.valid = true;
+    return WMBUS_OK;
+}
 
-    std::vector<Entry> order(c->n_hdr + c->n_pkts);
-    for (uint32_t i = 0; i < c->n_hdr; i++) order[i] = Entry{i, 1};
-    for (uint32_t i = 0; i < c->n_pkts; i++) order[c->n_hdr + i] = Entry{i, 0};
+/* Second half: candidate telegrams -> lines (host packet decoders, strip, format, merge).  Touches pinned host memory
+ * and the decoders only, so the NEXT push's front may already be on the GPU. */
+static int decode_host(wmbus_ctx *c)
+{
+    c->lines.clear(); c->text.clear();
+    c->short_burst.store(0);
+    if (!c->done.valid) return WMBUS_OK;
+    c->done.valid = false;
+    const double t0 = now_ms();
+    const uint32_t n_hdr = c->done.n_hdr, n_pkts = c->done.n_pkts;
+
+    std::vector<Entry> order(n_hdr + n_pkts);
+    for (uint32_t i = 0; i < n_hdr; i++) order[i] = Entry{i, 1};
+    for (uint32_t i = 0; i < n_pkts; i++) order[n_hdr + i] = Entry{i, 0};
     std::sort(order.begin(), order.end(), [&](const Entry &x, const Entry &y) {
         const EntryKey a = entry_key(c, x), b = entry_key(c, y);
         if (a.stream != b.stream) return a.stream < b.stream;
@@ -1028,7 +1110,7 @@ int wmbus_collect(wmbus_ctx *c)
      * bursts that were dropped. */
     if (c->tim.warnings & WMBUS_WARN_BURSTS_DROPPED)
         for (auto &hd : c->decs)
-            if (hd.owed != 0 && hd.fed != c->push_seq) { wm_decoder_abort(&hd.dec); hd.owed = 0; }
+            if (hd.owed != 0 && hd.fed != c->done.seq) { wm_decoder_abort(&hd.dec); hd.owed = 0; }
     /* stdout order of the reference: by completing sample, then T1/C1 before S1, run-length before time2 */
     std::vector<LineRec> all;
     for (auto &p : parts) for (auto &r : p) all.push_back(std::move(r));
@@ -1068,6 +1150,14 @@ int wmbus_collect(wmbus_ctx *c)
         return fail(c, WMBUS_EDEVICE, "burst too short: stream %u chain %u algo %u chip %u", h.stream, h.chain, h.algo, h.chip0);
     }
     return WMBUS_OK;
+}
+
+int wmbus_collect(wmbus_ctx *c)
+{
+    if (!c) return WMBUS_EINVAL;
+    const int rc = wait_gpu(c);
+    if (rc) { c->lines.clear(); c->text.clear(); return rc; }
+    return decode_host(c);
 }
 
 size_t wmbus_lines(const wmbus_ctx *c, const wmbus_line **lines)
@@ -1151,3 +1241,5 @@ int wmbus_selftest_math(int device, const float *a, const float *b, float *o_sqr
 }
 
 }  // extern "C"
+
+#include "wm_batch.h"

@@ -1,0 +1,219 @@
+/* wm_batch.h -- wmbus_batch_*: many captures on one device (include/wmbus_hip.h).  Part of wm_api.hip's translation unit
+ * (it drives the two halves of a push, enqueue_front / enqueue_back and wait_gpu / decode_host, directly).
+ *
+ * What the headline rate needs lived in bench.py for two rounds: several receiver contexts per GPU, each on its own host
+ * thread, free-running through their pushes so that one context's latency-bound framer kernels and host decoding are
+ * covered by the other contexts' demodulation kernels (which the library already orders one after the other on the GPU,
+ * K1Chain).  It is product code now -- the batch CLI (rtl_wmbus_hip FILE...) and bench.py both go through it -- and it
+ * adds one thing a caller of the plain context API cannot do: the NEXT push's front (demodulation, framers) is enqueued
+ * BEFORE the previous push is decoded on the host, so host decoding leaves every context's chain of dependent work. */
+#ifndef WM_BATCH_H
+#define WM_BATCH_H
+
+struct wmbus_batch {
+    wmbus_cfg cfg{};
+    char err[256] = {0};
+    std::vector<wmbus_ctx *> ctx;
+    std::vector<unsigned> first, count;                 /* stream range of every context */
+    std::vector<uint8_t *> slab[2];                     /* per context: two page-locked staging slabs (host-sourced runs), allocated on first use */
+    std::mutex out_lock, err_lock;
+    std::atomic<bool> stop{false};
+    int rc = 0;
+};
+
+namespace {
+
+int batch_fail(wmbus_batch *b, int code, const char *fmt, ...)
+{
+    std::lock_guard<std::mutex> lk(b->err_lock);
+    if (b->rc == 0) {                                       /* the first error is the one reported */
+        va_list ap; va_start(ap, fmt);
+        vsnprintf(b->err, sizeof b->err, fmt, ap);
+        va_end(ap);
+        b->rc = code;
+    }
+    b->stop.store(true);
+    return code;
+}
+
+struct BatchTotals { std::atomic<uint64_t> samples{0}, lines{0}; std::atomic<unsigned> pushes{0}, warnings{0}; };
+
+/* One context's run: pushes until its source ends.  GPU work of push k+1 (front) overlaps the host decode of push k;
+ * in host-sourced runs the bytes of push k+1 are read and staged into the context's other input window while push k is
+ * in flight. */
+void batch_worker(wmbus_batch *b, unsigned i, const wmbus_batch_io *io, BatchTotals *tot)
+{
+    wmbus_ctx *c = b->ctx[i];
+    const unsigned S = b->count[i], s0 = b->first[i];
+    const size_t pitch = b->cfg.max_push_bytes;
+    unsigned passes_left = io->fill ? 0u : io->passes;
+    int cur = 0;
+    auto source = [&](int k) -> size_t {                    /* bytes of the next push (0: the input has ended), staged if host-sourced */
+        if (b->stop.load()) return 0;
+        if (!io->fill) { if (passes_left == 0) return 0; passes_left--; return io->resident_bytes; }
+        const size_t n = io->fill(io->user, s0, S, io->self_staged ? nullptr : b->slab[k][i], pitch, pitch);
+        if (n == 0) return 0;
+        if (n > pitch || n % WMBUS_BLOCK_BYTES) { batch_fail(b, WMBUS_EINVAL, "batch: the source returned %zu bytes (multiple of 4096, at most %zu)", n, pitch); return 0; }
+        for (unsigned s = 0; s < S && !io->self_staged; s++)
+            if (wmbus_stage(c, s, b->slab[k][i] + (size_t)s * pitch, n)) { batch_fail(b, WMBUS_EDEVICE, "batch: context %u: %s", i, c->err); return 0; }
+        return n;
+    };
+    size_t n_cur = source(cur);
+    bool have_prev = false;
+    while (n_cur || have_prev) {                            /* after an error elsewhere source() returns 0: the loop winds down */
+        int rc = 0;
+        if (n_cur) rc = enqueue_front(c, n_cur);
+        if (!rc && have_prev) {
+            rc = decode_host(c);
+            if (!rc) {
+                tot->lines += c->lines.size();
+                tot->warnings |= c->tim.warnings;
+                if (io->lines) {
+                    /* the lines carry batch-wide stream numbers for the sink (and are put back: the context's own view stays local) */
+                    for (auto &l : c->lines) l.stream += s0;
+                    {
+                        std::lock_guard<std::mutex> lk(b->out_lock);
+                        io->lines(io->user, s0, S, c->lines.data(), c->lines.size(), c->text.c_str(), &c->tim);
+                    }
+                    for (auto &l : c->lines) l.stream -= s0;
+                }
+            }
+        }
+        if (!rc && n_cur) rc = enqueue_back(c);
+        if (rc) { batch_fail(b, rc, "batch: context %u: %s", i, c->err); break; }
+        const size_t n_next = n_cur ? source(cur ^ 1) : 0;
+        if (n_cur) {
+            rc = wait_gpu(c);
+            if (rc) { batch_fail(b, rc, "batch: context %u: %s", i, c->err); break; }
+            tot->samples += (uint64_t)S * (n_cur / 2);
+            tot->pushes++;
+            have_prev = true;
+        } else have_prev = false;
+        n_cur = n_next; cur ^= 1;
+    }
+    if (c->in_flight) wait_gpu(c);                          /* an aborted run leaves nothing on the stream */
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *wmbus_batch_last_error(const wmbus_batch *b) { return b ? b->err : "null batch"; }
+unsigned wmbus_batch_contexts(const wmbus_batch *b) { return b ? (unsigned)b->ctx.size() : 0u; }
+
+wmbus_ctx *wmbus_batch_context(wmbus_batch *b, unsigned i, unsigned *first_stream, unsigned *n_streams)
+{
+    if (!b || i >= b->ctx.size()) return nullptr;
+    if (first_stream) *first_stream = b->first[i];
+    if (n_streams) *n_streams = b->count[i];
+    return b->ctx[i];
+}
+
+void wmbus_batch_close(wmbus_batch *b)
+{
+    if (!b) return;
+    for (auto *c : b->ctx) wmbus_close(c);
+    for (auto &v : b->slab) for (auto *p : v) if (p) hipHostFree(p);
+    delete b;
+}
+
+int wmbus_batch_open(const wmbus_cfg *cfg, unsigned contexts, wmbus_batch **out)
+{
+    if (!cfg || !out) return WMBUS_EINVAL;
+    *out = nullptr;
+    wmbus_batch *b = new wmbus_batch();
+    b->cfg = *cfg;
+    *out = b;                                               /* the caller reads the message, then closes */
+    const unsigned S = cfg->n_streams;
+    if (S < 1) return batch_fail(b, WMBUS_EINVAL, "batch: n_streams must be >= 1");
+    /* Contexts of whole 64-capture waves where the batch allows it (the clock kernel's cooperative loads need that); by
+     * default 8 of them, at most one per 64 captures: 8 x 128 for the 1024 captures of the headline configuration
+     * (4 / 6 / 10 / 12 / 16 contexts measured 96 / 111 / 141 / 120 / 117 against 144 Gsamples/s with 8). */
+    unsigned nctx = contexts ? contexts : std::min(8u, std::max(1u, S / 64u));
+    nctx = std::max(1u, std::min(nctx, S));
+    const unsigned gran = (S % 64u == 0u && S / 64u >= nctx) ? 64u : 1u, units = S / gran;
+    unsigned hw = std::thread::hardware_concurrency();
+    if (hw == 0) hw = 16;
+    unsigned at = 0;
+    for (unsigned i = 0; i < nctx; i++) {
+        const unsigned n = gran * (units / nctx + (i < units % nctx ? 1u : 0u));
+        wmbus_cfg cc = *cfg;
+        cc.n_streams = n;
+        /* host decoder threads: the contexts decode at different times, so the box is shared 2 x oversubscribed */
+        if (cc.host_threads == 0) cc.host_threads = std::max(2u, std::min(16u, 2u * hw / std::max(1u, nctx)));
+        wmbus_ctx *c = nullptr;
+        const int rc = wmbus_open(&cc, &c);
+        if (rc) {
+            batch_fail(b, rc, "batch: context %u of %u (%u captures): %s", i, nctx, n, c ? c->err : "out of memory");
+            wmbus_close(c);
+            return rc;
+        }
+        b->ctx.push_back(c); b->first.push_back(at); b->count.push_back(n);
+        at += n;
+    }
+    b->slab[0].assign(nctx, nullptr); b->slab[1].assign(nctx, nullptr);
+    return WMBUS_OK;
+}
+
+static int batch_locate(wmbus_batch *b, unsigned stream, unsigned *i)
+{
+    if (!b || stream >= b->cfg.n_streams) return WMBUS_EINVAL;
+    unsigned k = 0;
+    while (k + 1 < b->ctx.size() && stream >= b->first[k + 1]) k++;
+    *i = k;
+    return WMBUS_OK;
+}
+
+int wmbus_batch_stage(wmbus_batch *b, unsigned stream, const uint8_t *cu8, size_t nbytes)
+{
+    unsigned i;
+    if (batch_locate(b, stream, &i)) return WMBUS_EINVAL;
+    const int rc = wmbus_stage(b->ctx[i], stream - b->first[i], cu8, nbytes);
+    if (rc) snprintf(b->err, sizeof b->err, "batch: context %u: %s", i, b->ctx[i]->err);
+    return rc;
+}
+
+void *wmbus_batch_device_input(wmbus_batch *b, unsigned stream)
+{
+    unsigned i;
+    if (batch_locate(b, stream, &i)) return nullptr;
+    return wmbus_device_input(b->ctx[i], stream - b->first[i]);
+}
+
+int wmbus_batch_run(wmbus_batch *b, const wmbus_batch_io *io, wmbus_batch_stats *stats)
+{
+    if (!b || !io) return WMBUS_EINVAL;
+    if (stats) memset(stats, 0, sizeof *stats);
+    { std::lock_guard<std::mutex> lk(b->err_lock); b->rc = 0; b->err[0] = 0; }
+    b->stop.store(false);
+    if (!io->fill && (io->resident_bytes == 0 || io->resident_bytes > b->cfg.max_push_bytes || io->resident_bytes % WMBUS_BLOCK_BYTES))
+        return batch_fail(b, WMBUS_EINVAL, "batch: resident_bytes must be a positive multiple of 4096 and <= max_push_bytes");
+    if (io->fill && !io->self_staged) {
+        if (b->cfg.input_windows != 2) return batch_fail(b, WMBUS_EINVAL, "batch: a host-sourced run needs cfg.input_windows = 2");
+        for (unsigned i = 0; i < b->ctx.size(); i++)
+            for (int k = 0; k < 2; k++)
+                if (!b->slab[k][i]) {
+                    hipSetDevice(b->cfg.device);
+                    if (hipHostMalloc((void **)&b->slab[k][i], (size_t)b->count[i] * b->cfg.max_push_bytes) != hipSuccess) {
+                        b->slab[k][i] = nullptr;
+                        return batch_fail(b, WMBUS_ENOMEM, "batch: cannot allocate %zu bytes of page-locked staging", (size_t)b->count[i] * b->cfg.max_push_bytes);
+                    }
+                }
+    }
+    if (io->fill && b->cfg.input_windows != 2) return batch_fail(b, WMBUS_EINVAL, "batch: a host-sourced run needs cfg.input_windows = 2");
+    BatchTotals tot;
+    const double t0 = now_ms();
+    std::vector<std::thread> th;
+    for (unsigned i = 1; i < b->ctx.size(); i++) th.emplace_back(batch_worker, b, i, io, &tot);
+    batch_worker(b, 0, io, &tot);                           /* the caller's thread drives context 0 */
+    for (auto &t : th) t.join();
+    if (stats) {
+        stats->seconds = (now_ms() - t0) * 1e-3;
+        stats->samples = tot.samples.load(); stats->lines = tot.lines.load(); stats->pushes = tot.pushes.load(); stats->warnings = tot.warnings.load();
+    }
+    return b->rc;
+}
+
+}  // extern "C"
+
+#endif /* WM_BATCH_H */

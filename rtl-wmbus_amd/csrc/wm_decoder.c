@@ -286,13 +286,20 @@ int wm_twin_check(wm_twin state[2], int chain, int algo, uint64_t sample, const 
     return 0;
 }
 
+void wm_timestamp_at(char *dst, size_t cap, long sec, long usec)
+{
+    struct tm tmv;
+    char fmt[48];
+    time_t t = (time_t)sec;
+    if (usec < 0) { usec += 1000000; t -= 1; }
+    localtime_r(&t, &tmv);
+    strftime(fmt, sizeof fmt, "%Y-%m-%d %H:%M:%S.%%06u", &tmv);
+    snprintf(dst, cap, fmt, (unsigned)usec);
+}
+
 void wm_timestamp(char *dst, size_t cap)
 {
     struct timeval tv;
-    struct tm tmv;
-    char fmt[48];
     gettimeofday(&tv, NULL);
-    localtime_r(&tv.tv_sec, &tmv);
-    strftime(fmt, sizeof fmt, "%Y-%m-%d %H:%M:%S.%%06u", &tmv);
-    snprintf(dst, cap, fmt, (unsigned)tv.tv_usec);
+    wm_timestamp_at(dst, cap, (long)tv.tv_sec, (long)tv.tv_usec);
 }

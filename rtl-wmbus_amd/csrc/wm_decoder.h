@@ -69,6 +69,8 @@ int wm_twin_check(wm_twin state[2], int chain, int algo, uint64_t sample, const 
 
 /* Wall-clock timestamp in the reference's format (rtl_wmbus_util.h:10-39). */
 void wm_timestamp(char *dst, size_t cap);
+/* The same for a given instant (seconds and microseconds since the epoch). */
+void wm_timestamp_at(char *dst, size_t cap, long sec, long usec);
 
 /* CRC-16 EN 13757 (poly 0x3D65, init 0, final complement), exposed for tests. */
 uint16_t wm_crc16(const uint8_t *data, size_t n);

@@ -41,6 +41,7 @@ struct K1Args {
     const uint32_t *relist;
     const float *ema_carry;  /* [2][S] exact EMA carried in from the previous push */
     const uint32_t *n_relist;/* repair launches: entries in `relist` (on the device: k1_collect has just written it) */
+    uint32_t n_items;        /* first pass with a bounded grid: blocks walk items (stream * ntiles + tile) [0, n_items); 0: grid = (tiles, streams) */
 };
 
 /* =============================================================================================
@@ -264,7 +265,7 @@ __device__ __forceinline__ void k1_stage_b(const K1Args &a, const int tid, const
  * -a / -A / -p paths and the RSSI repair walk are not compiled in, so the default path carries no cost for the options
  * (any other configuration, and every repair launch, runs the GEN = true kernel: same arithmetic, same results). */
 template <int D, bool SHIFT, bool GEN>
-__device__ __forceinline__ void k1_tile(const K1Args &a, const int tile, const int stream)
+__device__ __forceinline__ void k1_tile(const K1Args &a, const int tile, const int stream, const int tid)
 {
     using G = K1Geo;
     constexpr int T = G::T, NA = G::NA, YD = G::YD, YM = G::YM;
@@ -278,7 +279,6 @@ __device__ __forceinline__ void k1_tile(const K1Args &a, const int tile, const i
     float *yDrT = (float *)smem + G::U(d, SHIFT), *yDrS = yDrT + YD;
     float *sFin = yDrS + YD, *sHead = sFin + 128, *tab = sHead + 128;
 
-    const int tid = threadIdx.x;
     const int ts = tile * T;
     const int tn = min(T, (int)g.M - ts);
     const bool chT = !GEN || (g.flags & WM_F_T1C1), chS = !GEN || (g.flags & WM_F_S1);
@@ -403,13 +403,23 @@ __device__ __forceinline__ void k1_tile(const K1Args &a, const int tile, const i
 }
 
 template <int D, bool SHIFT, bool GEN = true>
-__global__ __launch_bounds__(256) void k1_demod2(K1Args a)
+__global__ __launch_bounds__(256, GEN ? 1 : 8) void k1_demod2(K1Args a)          /* first pass: 64 VGPRs, eight waves fill a SIMD (the tile loop of the bounded grid would otherwise hoist its way to 95) */
 {
-    if (!GEN || a.relist == nullptr) { k1_tile<D, SHIFT, GEN>(a, (int)blockIdx.x, (int)blockIdx.y); return; }
+    if (!GEN || a.relist == nullptr) {
+        if (a.n_items == 0u) { k1_tile<D, SHIFT, GEN>(a, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x); return; }
+        /* bounded grid: a block walks tiles (no barrier between two tiles is needed: a tile's last LDS reads, sFin, are
+         * three barriers ahead of the next tile's writes to that array, and its staging area is dead after stage B's first) */
+        for (uint32_t i = blockIdx.x; i < a.n_items; i += gridDim.x) {
+            int tid = (int)threadIdx.x;
+            asm volatile("" : "+v"(tid));                      /* per-thread addresses are recomputed per tile, not kept in registers across the loop */
+            k1_tile<D, SHIFT, GEN>(a, (int)(i % a.ntiles), (int)(i / a.ntiles), tid);
+        }
+        return;
+    }
     /* repair launch: a fixed grid walks the list k1_collect has just written (no host round trip in between) */
     const uint32_t n = *a.n_relist;
     for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
-        k1_tile<D, SHIFT, GEN>(a, (int)(a.relist[e] % a.ntiles), (int)(a.relist[e] / a.ntiles));
+        k1_tile<D, SHIFT, GEN>(a, (int)(a.relist[e] % a.ntiles), (int)(a.relist[e] / a.ntiles), (int)threadIdx.x);
         __syncthreads();                                      /* the tile's LDS is reused by the next entry */
     }
 }

@@ -448,6 +448,7 @@ __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t bloc
 template <bool DC>
 __global__ __launch_bounds__(64 * WM_CLK_WPB) void k2_clock(K2Args a)                 /* first pass: one block per 64 * WM_CLK_WPB lanes */
 {
+    wm_framer_prio();
     __shared__ __attribute__((aligned(16))) ClkLds<WM_CLK_WPB> lds;
     clock_lanes<DC, WM_CLK_WPB, false, 0>(a, blockIdx.x, lds);
 }
@@ -455,6 +456,7 @@ __global__ __launch_bounds__(64 * WM_CLK_WPB) void k2_clock(K2Args a)           
 template <bool DC>
 __global__ __launch_bounds__(64 * WM_CLK_WPB) void k2_clock_list(K2Args a)            /* re-run list: a fixed grid whose blocks walk the list */
 {
+    wm_framer_prio();
     __shared__ __attribute__((aligned(16))) ClkLds<WM_CLK_WPB> lds;
     const uint32_t n = k2_lane_count(a);
     for (uint32_t b = blockIdx.x; (uint64_t)b * (64u * WM_CLK_WPB) < n; b += gridDim.x) clock_lanes<DC, WM_CLK_WPB, false, 1>(a, b, lds);

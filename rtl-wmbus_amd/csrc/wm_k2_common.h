@@ -29,6 +29,18 @@ struct K2Args {
     uint32_t *ckpt; uint32_t nck;
 };
 
+/* Issue priority of the latency-bound kernels behind K1 (framers, verifiers, burst kernels): a clock wave that shares its
+ * SIMD with seven demodulation waves gets an eighth of the issue slots under the default round robin, and a context's
+ * chain of dependent launches is as long as that makes it.  Build-time switch (0 = leave the default). */
+#ifndef WM_FRAMER_PRIO
+#define WM_FRAMER_PRIO 0
+#endif
+#if WM_FRAMER_PRIO
+__device__ __forceinline__ void wm_framer_prio() { __builtin_amdgcn_s_setprio(WM_FRAMER_PRIO); }
+#else
+__device__ __forceinline__ void wm_framer_prio() {}
+#endif
+
 __device__ __forceinline__ uint32_t k2_lane_count(const K2Args &a) { return a.n_ptr ? *a.n_ptr : a.n_lanes; }
 
 __device__ __forceinline__ void lane_decode(const WmPush &g, uint32_t algo, uint32_t lane, uint32_t &ch, uint32_t &stream, uint32_t &seg)

@@ -239,12 +239,14 @@ __device__ __forceinline__ void rla_lanes(const K2Args &a, const uint32_t block_
 #endif
 __global__ __launch_bounds__(64 * WM_RLA_WPB, WM_RLA_WAVES_PER_SIMD) void k2_rla(K2Args a)           /* main pass: one block per 64 * WM_RLA_WPB lanes */
 {
+    wm_framer_prio();
     __shared__ RlaLds lds;
     rla_lanes<0>(a, blockIdx.x, lds);
 }
 
 __global__ __launch_bounds__(64 * WM_RLA_WPB, WM_RLA_WAVES_PER_SIMD) void k2_rla_list(K2Args a)      /* re-run list: a fixed grid walks it */
 {
+    wm_framer_prio();
     __shared__ RlaLds lds;
     const uint32_t n = k2_lane_count(a);
     for (uint32_t b = blockIdx.x; (uint64_t)b * (64u * WM_RLA_WPB) < n; b += gridDim.x) rla_lanes<1>(a, b, lds);

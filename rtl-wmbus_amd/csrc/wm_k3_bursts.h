@@ -88,6 +88,7 @@ __global__ __launch_bounds__(256) void k3_scan(WmPush g, const uint32_t *chips0,
                                                const uint32_t *counts1, const uint32_t *seen0, const uint32_t *seen1,
                                                uint2 *hits, uint32_t *n_hits, uint32_t hits_cap, uint32_t *err)
 {
+    wm_framer_prio();
     const uint32_t n0 = 2u * g.nseg[0] * g.S;                /* run-length lanes first */
     const uint32_t ln = threadIdx.x & 63u;
     uint32_t lane = blockIdx.x * 256u + threadIdx.x, algo = 0;
@@ -361,6 +362,7 @@ __device__ void burst_item(const K3Args &a, const uint32_t item, const uint32_t 
  * context (measured: K1 ran at a quarter of its speed while this kernel was resident). */
 __global__ __launch_bounds__(256) void k3_bursts(K3Args a, uint32_t n_items_host)
 {
+    wm_framer_prio();
     __shared__ K3Lds lds;
     const uint32_t ln = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     /* the host may not know the number of hits yet (no round trip between k3_scan and this kernel): ~0 = read it here */

@@ -54,6 +54,7 @@
 #endif
 __global__ __launch_bounds__(64 * WM_RLA_WPB, WM_FUSED_WAVES_PER_SIMD) void k2_clock_rla(K2Args clk, K2Args rla, uint32_t clk_blocks)
 {
+    wm_framer_prio();
     __shared__ __attribute__((aligned(16))) union { ClkLds<1> c; RlaLds r; } lds;
     /* both parts walk their lane lists with the blocks they were given (the counts may live on the device) */
     if (blockIdx.x < clk_blocks) {
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(64 * WM_RLA_WPB, WM_FUSED_WAVES_PER_SIMD) void k2_c
 __global__ void k2_verify(WmPush g, uint32_t algo, const uint32_t *st_start, const uint32_t *st_final, uint32_t words,
                           uint32_t *list, uint32_t *n_list)
 {
+    wm_framer_prio();
     const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
     if (lane >= 2u * g.nseg[algo] * g.S) return;
     uint32_t ch, stream, seg;
