@@ -7,14 +7,16 @@
  * /root/reference/rtl_wmbus.c:869-967,1217-1372; the per-sample loop (:1298-1357) is replaced by
  * wmbus_stage()/wmbus_process()/wmbus_collect() from libwmbus_hip.so.  Plain C; the GPU is only
  * reached through the C ABI in include/wmbus_hip.h.
- * Extensions (letters the reference does not use): -B bytes per GPU push (default 1 MiB),
- * -G HIP device ordinal, -P polyphase pre-filter, -T host:port (cu8 over TCP, e.g. a raw IQ server;
- * the role of the reference's unused net_support.h:15-44 / rtl_wmbus.c:1281), and
- *   rtl_wmbus_hip [switches] a.cu8 b.cu8 ...      batch mode: one capture per file, all of them in
- * lock step on one GPU, lines prefixed "a.cu8: "; while the GPU works on one pinned slab the next one is read and
- * staged into the context's second input window (double-buffered H2D on the copy stream).  With -G all (or -G 0,2,5) batch mode shards the files over the
- * GPUs of the node, file i on device list[i mod n] (file-per-GPU, no collective): one receiver
- * context and one worker thread per device, each file's lines in its own order.  -M prints that map and exits.
+ * Extensions (letters the reference does not use): -B bytes per GPU push, -L ms (a live stream's bytes never wait longer
+ * than this for their push to fill; wm_reader.c), -G HIP device(s), -P polyphase pre-filter, -A 1|2 fast arctangents,
+ * -U / -W de-duplication, -T host:port (cu8 over TCP; the role of the reference's unused net_support.h:15-44 /
+ * rtl_wmbus.c:1281), -S statistics, and
+ *   rtl_wmbus_hip [switches] a.cu8 b.cu8 ...      batch mode: one capture per file, lines prefixed "a.cu8: ".
+ * A batch is a wmbus_batch of the library per device: the files are split over several receiver contexts (whole groups
+ * of 64, eight contexts at most) that run on their own threads and overlap each other, 8 MiB per file and push, the next
+ * push read into page-locked memory and staged into a context's second input window while the previous one is in
+ * flight.  With -G all (or -G 0,2,5) the files are sharded over the GPUs of the node, file i on device list[i mod n]
+ * (file-per-GPU, no collective), each file's lines in its own order.  -M prints that map and exits.
  */
 #include <arpa/inet.h>
 #include <netdb.h>
@@ -26,6 +28,9 @@
 #include <sys/socket.h>
 #include <unistd.h>
 
+#include <time.h>
+
+#include "wm_reader.h"
 #include "wmbus_hip.h"
 
 #define VERSION "rtl_wmbus_hip 0.1 (MI355X/gfx950 back end)"
@@ -44,7 +49,9 @@ static void print_usage(const char *prog)
     fprintf(stdout, "\t-s receive S1 and T1/C1 datagrams simultaneously. rtl_sdr _MUST_ be set to 868.625MHz (-f 868.625M)\n");
     fprintf(stdout, "\t-p [T,S] to disable processing T1/C1 or S1 mode\n");
     fprintf(stdout, "\t-f exit if flow of incoming data stops\n");
-    fprintf(stdout, "\t-B bytes per GPU push (multiple of 4096, default 1048576)\n");
+    fprintf(stdout, "\t-B bytes per GPU push (multiple of 4096; default 1048576 for a live stream, 8388608 per file in batch mode)\n");
+    fprintf(stdout, "\t-L ms a live stream's bytes wait at most this long for their push to fill (default 50; 0: only full pushes)\n");
+    fprintf(stdout, "\t-S batch mode: print samples, seconds and Msamples/s to stderr\n");
     fprintf(stdout, "\t-G HIP device ordinal (default 0); batch mode: 'all' or a list '0,2,5' shards the files, file i on device list[i mod n]\n");
     fprintf(stdout, "\t-M batch mode: print the file -> device map and exit\n");
     fprintf(stdout, "\t-U unique: print a datagram that both the time2 and the run length method decoded only once\n");
@@ -56,17 +63,17 @@ static void print_usage(const char *prog)
     fprintf(stdout, "\t-h print this help\n");
 }
 
-/* cu8 over TCP: connect and hand back a stdio stream (what net_support.h:15-44 offers the reference). */
-static FILE *open_tcp(const char *hostport)
+/* cu8 over TCP: connect and hand back the descriptor (what net_support.h:15-44 offers the reference). */
+static int open_tcp(const char *hostport)
 {
     char host[256];
     const char *colon = strrchr(hostport, ':');
-    if (!colon || colon == hostport || (size_t)(colon - hostport) >= sizeof host) { fprintf(stderr, "rtl_wmbus_hip: -T needs host:port\n"); return NULL; }
+    if (!colon || colon == hostport || (size_t)(colon - hostport) >= sizeof host) { fprintf(stderr, "rtl_wmbus_hip: -T needs host:port\n"); return -1; }
     memcpy(host, hostport, (size_t)(colon - hostport)); host[colon - hostport] = 0;
     struct addrinfo hints, *res = NULL;
     memset(&hints, 0, sizeof hints);
     hints.ai_family = AF_UNSPEC; hints.ai_socktype = SOCK_STREAM;
-    if (getaddrinfo(host, colon + 1, &hints, &res) || !res) { fprintf(stderr, "rtl_wmbus_hip: cannot resolve %s\n", hostport); return NULL; }
+    if (getaddrinfo(host, colon + 1, &hints, &res) || !res) { fprintf(stderr, "rtl_wmbus_hip: cannot resolve %s\n", hostport); return -1; }
     int fd = -1;
     for (struct addrinfo *a = res; a; a = a->ai_next) {
         fd = socket(a->ai_family, a->ai_socktype, a->ai_protocol);
@@ -75,123 +82,113 @@ static FILE *open_tcp(const char *hostport)
         close(fd); fd = -1;
     }
     freeaddrinfo(res);
-    if (fd < 0) { fprintf(stderr, "rtl_wmbus_hip: cannot connect to %s\n", hostport); return NULL; }
-    return fdopen(fd, "rb");
+    if (fd < 0) fprintf(stderr, "rtl_wmbus_hip: cannot connect to %s\n", hostport);
+    return fd;
 }
 
-/* ---- batch mode ------------------------------------------------------------------------------ */
-struct batch {
-    int n; FILE **f; int *live; size_t push; unsigned char *slab[2]; size_t filled[2];   /* bytes per stream in slab k */
+/* ---- batch mode ------------------------------------------------------------------------------
+ * One wmbus_batch per device (include/wmbus_hip.h): the library splits the device's files over several receiver
+ * contexts, drives each on its own thread and overlaps them; this file only supplies the bytes (fread into the page-locked
+ * slab the library hands out) and prints the lines. */
+struct batch_job {
+    wmbus_cfg cfg; int n; char **names; FILE **f; int *live; int rc;
+    unsigned told;                                       /* warnings already reported for this device */
+    int stats;
+    wmbus_batch_stats st;
 };
 
-/* Fill slab k: up to `push` bytes (whole 4096-byte blocks) of every file; a file that has ended
- * contributes mid-scale bytes (no signal).  filled = longest contribution. */
-static void batch_fill(struct batch *b, int k)
+static pthread_mutex_t out_lock = PTHREAD_MUTEX_INITIALIZER;      /* one push's lines leave as a unit, whichever device they come from */
+
+/* The reference never stops on an input; neither do we: exhausted chip / burst storage is reported once per device and
+ * the stream goes on (wmbus_hip.h, WMBUS_WARN_*).  Callers hold out_lock or are single-threaded. */
+static void report_warnings(unsigned warnings, unsigned *told)
 {
-    size_t most = 0;
-    for (int s = 0; s < b->n; s++) {
-        unsigned char *dst = b->slab[k] + (size_t)s * b->push;
-        size_t got = 0;
-        if (b->live[s]) {
-            got = fread(dst, WMBUS_BLOCK_BYTES, b->push / WMBUS_BLOCK_BYTES, b->f[s]) * WMBUS_BLOCK_BYTES;
-            if (got < b->push) b->live[s] = 0;
-        }
-        memset(dst + got, 128, b->push - got);
-        if (got > most) most = got;
-    }
-    b->filled[k] = most;
+    if (!(warnings & ~*told)) return;
+    if (warnings & ~*told & WMBUS_WARN_CHIPS_DROPPED) fprintf(stderr, "rtl_wmbus_hip: warning: run-length chip storage exhausted (interferer?), some chips dropped; continuing\n");
+    if (warnings & ~*told & WMBUS_WARN_BURSTS_DROPPED) fprintf(stderr, "rtl_wmbus_hip: warning: burst storage exhausted, some candidate telegrams dropped; continuing\n");
+    *told |= warnings;
 }
 
-static pthread_mutex_t out_lock = PTHREAD_MUTEX_INITIALIZER;      /* one push's lines leave as a unit */
-
-/* The reference never stops on an input; neither do we: exhausted chip / burst storage is reported once and the
- * stream goes on (wmbus_hip.h, WMBUS_WARN_*). */
-static void report_warnings(wmbus_ctx *ctx)
+/* wmbus_batch_io.fill: up to `cap` bytes (whole 4096-byte blocks) of every file of the group; a file that has ended
+ * contributes mid-scale bytes (no signal).  Returns the longest contribution; 0 when all have ended. */
+static size_t batch_fill_padded(void *user, unsigned first, unsigned n, uint8_t *slab, size_t pitch, size_t cap)
 {
-    static unsigned told = 0;
-    wmbus_timing t;
-    if (wmbus_get_timing(ctx, &t) || !(t.warnings & ~told)) return;
-    if (t.warnings & ~told & WMBUS_WARN_CHIPS_DROPPED) fprintf(stderr, "rtl_wmbus_hip: warning: run-length chip storage exhausted (interferer?), some chips dropped; continuing\n");
-    if (t.warnings & ~told & WMBUS_WARN_BURSTS_DROPPED) fprintf(stderr, "rtl_wmbus_hip: warning: burst storage exhausted, some candidate telegrams dropped; continuing\n");
-    told |= t.warnings;
+    struct batch_job *j = user;
+    size_t most = 0;
+    size_t *got = calloc(n, sizeof *got);
+    if (!got) return 0;
+    for (unsigned k = 0; k < n; k++) {
+        const unsigned s = first + k;
+        if (j->live[s]) {
+            got[k] = fread(slab + (size_t)k * pitch, WMBUS_BLOCK_BYTES, cap / WMBUS_BLOCK_BYTES, j->f[s]) * WMBUS_BLOCK_BYTES;
+            if (got[k] < cap) j->live[s] = 0;
+        }
+        if (got[k] > most) most = got[k];
+    }
+    for (unsigned k = 0; k < n; k++) if (got[k] < most) memset(slab + (size_t)k * pitch + got[k], 128, most - got[k]);
+    free(got);
+    return most;
+}
+
+static void batch_lines(void *user, unsigned first, unsigned n, const wmbus_line *ln, size_t nl, const char *text, const wmbus_timing *t)
+{
+    struct batch_job *j = user;
+    (void)first; (void)n;
+    pthread_mutex_lock(&out_lock);
+    report_warnings(t->warnings, &j->told);
+    for (size_t i = 0; i < nl; i++) {
+        fputs(j->names[ln[i].stream], stdout); fputs(": ", stdout);
+        fwrite(text + ln[i].text_off, 1, ln[i].text_len, stdout);
+    }
+    if (nl) fflush(stdout);
+    pthread_mutex_unlock(&out_lock);
+}
+
+static int run_batch(struct batch_job *j)
+{
+    int rc = EXIT_FAILURE;
+    wmbus_batch *b = NULL;
+    j->f = calloc((size_t)j->n, sizeof *j->f); j->live = calloc((size_t)j->n, sizeof *j->live);
+    if (!j->f || !j->live) goto out;
+    for (int s = 0; s < j->n; s++) {
+        j->f[s] = fopen(j->names[s], "rb");
+        if (!j->f[s]) { fprintf(stderr, "rtl_wmbus_hip: cannot open %s\n", j->names[s]); goto out; }
+        j->live[s] = 1;
+    }
+    j->cfg.n_streams = (unsigned)j->n;
+    j->cfg.input_windows = 2;                                /* the next push crosses PCIe while the previous one is in flight */
+    if (wmbus_batch_open(&j->cfg, 0, &b)) {
+        fprintf(stderr, "rtl_wmbus_hip: cannot open GPU back end: %s\n", b ? wmbus_batch_last_error(b) : "out of memory");
+        goto out;
+    }
+    wmbus_batch_io io;
+    memset(&io, 0, sizeof io);
+    io.fill = batch_fill_padded; io.lines = batch_lines; io.user = j;
+    if (wmbus_batch_run(b, &io, &j->st)) { fprintf(stderr, "rtl_wmbus_hip: %s\n", wmbus_batch_last_error(b)); goto out; }
+    if (j->stats)
+        fprintf(stderr, "rtl_wmbus_hip: device %d: %d files, %u contexts, %llu samples, %llu lines, %u pushes in %.3f s = %.1f Msamples/s\n", j->cfg.device, j->n,
+                wmbus_batch_contexts(b), (unsigned long long)j->st.samples, (unsigned long long)j->st.lines, j->st.pushes, j->st.seconds,
+                j->st.seconds > 0 ? (double)j->st.samples / j->st.seconds / 1e6 : 0.0);
+    rc = EXIT_SUCCESS;
+out:
+    wmbus_batch_close(b);                                    /* every exit path closes what it opened */
+    for (int s = 0; j->f && s < j->n; s++) if (j->f[s]) fclose(j->f[s]);
+    free(j->f); free(j->live);
+    return rc;
 }
 
 /* File i of a batch -> position in the device list (stream s -> GPU s mod n).  The only place
  * the map is defined; -M prints it, tests/test_multi_gloo.py holds it against rtl-wmbus_amd/shard.py. */
 static int shard_slot(int file_index, int n_devices) { return file_index % n_devices; }
 
-static int run_batch(wmbus_cfg cfg, int n, char **names)
-{
-    struct batch b;
-    memset(&b, 0, sizeof b);
-    b.n = n; b.push = cfg.max_push_bytes;
-    b.f = calloc((size_t)n, sizeof *b.f); b.live = calloc((size_t)n, sizeof *b.live);
-    for (int s = 0; s < n; s++) {
-        b.f[s] = fopen(names[s], "rb");
-        if (!b.f[s]) { fprintf(stderr, "rtl_wmbus_hip: cannot open %s\n", names[s]); return EXIT_FAILURE; }
-        b.live[s] = 1;
-    }
-    cfg.n_streams = (unsigned)n;
-    cfg.input_windows = 2;
-    wmbus_ctx *ctx = NULL;
-    if (wmbus_open(&cfg, &ctx)) {
-        fprintf(stderr, "rtl_wmbus_hip: cannot open GPU back end: %s\n", ctx ? wmbus_last_error(ctx) : "out of memory");
-        wmbus_close(ctx);
-        return EXIT_FAILURE;
-    }
-    for (int k = 0; k < 2; k++) {
-        b.slab[k] = wmbus_alloc_pinned((size_t)n * b.push);
-        if (!b.slab[k]) { fprintf(stderr, "rtl_wmbus_hip: cannot allocate pinned staging\n"); return EXIT_FAILURE; }
-    }
-    /* wmbus_process only enqueues: while the GPU works on one slab this thread reads the next one from the files and
-     * stages it into the context's other input window (cfg.input_windows = 2: the copies run on their own stream) */
-    int rc = 0, cur = 0, staged = 0;
-    batch_fill(&b, cur);
-    while (b.filled[cur] && !rc) {
-        const size_t nbytes = b.filled[cur];
-        for (int s = 0; s < n && !rc && !staged; s++) rc = wmbus_stage(ctx, (unsigned)s, b.slab[cur] + (size_t)s * b.push, nbytes);
-        if (!rc) rc = wmbus_process(ctx, nbytes);
-        staged = 0;
-        if (!rc) {
-            batch_fill(&b, cur ^ 1);
-            for (int s = 0; s < n && !rc && b.filled[cur ^ 1]; s++)
-                rc = wmbus_stage(ctx, (unsigned)s, b.slab[cur ^ 1] + (size_t)s * b.push, b.filled[cur ^ 1]);
-            staged = b.filled[cur ^ 1] != 0;
-        }
-        if (!rc) rc = wmbus_collect(ctx);
-        if (rc) fprintf(stderr, "rtl_wmbus_hip: %s\n", wmbus_last_error(ctx));
-        else {
-            const wmbus_line *ln = NULL;
-            const size_t nl = wmbus_lines(ctx, &ln);
-            size_t len = 0;
-            const char *text = wmbus_lines_text(ctx, &len);
-            pthread_mutex_lock(&out_lock);
-            report_warnings(ctx);
-            for (size_t i = 0; i < nl; i++) {
-                fputs(names[ln[i].stream], stdout); fputs(": ", stdout);
-                fwrite(text + ln[i].text_off, 1, ln[i].text_len, stdout);
-            }
-            fflush(stdout);
-            pthread_mutex_unlock(&out_lock);
-        }
-        cur ^= 1;
-    }
-    for (int k = 0; k < 2; k++) wmbus_free_pinned(b.slab[k]);
-    for (int s = 0; s < n; s++) fclose(b.f[s]);
-    free(b.f); free(b.live);
-    wmbus_close(ctx);
-    return rc ? EXIT_FAILURE : EXIT_SUCCESS;
-}
+/* ---- batch mode over several GPUs: one batch per device, each on its own thread ---------- */
+static void *shard_thread(void *p) { struct batch_job *j = p; j->rc = j->n ? run_batch(j) : EXIT_SUCCESS; return NULL; }
 
-/* ---- batch mode over several GPUs: one run_batch per device, each on its own thread ---------- */
-struct shard_job { wmbus_cfg cfg; int n; char **names; int rc; };
-static void *shard_thread(void *p) { struct shard_job *j = p; j->rc = j->n ? run_batch(j->cfg, j->n, j->names) : EXIT_SUCCESS; return NULL; }
-
-static int run_sharded(wmbus_cfg cfg, int n, char **names, const int *devs, int n_devs, int map_only)
+static int run_sharded(wmbus_cfg cfg, int n, char **names, const int *devs, int n_devs, int map_only, int stats)
 {
-    struct shard_job *jobs = calloc((size_t)n_devs, sizeof *jobs);
+    struct batch_job *jobs = calloc((size_t)n_devs, sizeof *jobs);
     pthread_t *th = calloc((size_t)n_devs, sizeof *th);
-    for (int k = 0; k < n_devs; k++) { jobs[k].cfg = cfg; jobs[k].cfg.device = devs[k]; jobs[k].names = calloc((size_t)n, sizeof(char *)); }
+    for (int k = 0; k < n_devs; k++) { jobs[k].cfg = cfg; jobs[k].cfg.device = devs[k]; jobs[k].names = calloc((size_t)n, sizeof(char *)); jobs[k].stats = stats; }
     for (int i = 0; i < n; i++) {
         const int k = shard_slot(i, n_devs);
         jobs[k].names[jobs[k].n++] = names[i];
@@ -199,8 +196,20 @@ static int run_sharded(wmbus_cfg cfg, int n, char **names, const int *devs, int 
     }
     int rc = EXIT_SUCCESS;
     if (!map_only) {
-        for (int k = 0; k < n_devs; k++) pthread_create(&th[k], NULL, shard_thread, &jobs[k]);
-        for (int k = 0; k < n_devs; k++) { pthread_join(th[k], NULL); if (jobs[k].rc) rc = jobs[k].rc; }
+        struct timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (int k = 1; k < n_devs; k++) pthread_create(&th[k], NULL, shard_thread, &jobs[k]);
+        shard_thread(&jobs[0]);
+        if (jobs[0].rc) rc = jobs[0].rc;
+        for (int k = 1; k < n_devs; k++) { pthread_join(th[k], NULL); if (jobs[k].rc) rc = jobs[k].rc; }
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if (stats) {
+            unsigned long long samples = 0; double run_s = 0;
+            for (int k = 0; k < n_devs; k++) { samples += jobs[k].st.samples; if (jobs[k].st.seconds > run_s) run_s = jobs[k].st.seconds; }
+            const double wall = (double)(t1.tv_sec - t0.tv_sec) + (t1.tv_nsec - t0.tv_nsec) * 1e-9;
+            fprintf(stderr, "rtl_wmbus_hip: total: %d files on %d device(s), %llu samples; decode %.3f s = %.1f Msamples/s; with set-up (contexts, page-locked staging) %.3f s = %.1f Msamples/s\n",
+                    n, n_devs, samples, run_s, run_s > 0 ? samples / run_s / 1e6 : 0.0, wall, wall > 0 ? samples / wall / 1e6 : 0.0);
+        }
     }
     for (int k = 0; k < n_devs; k++) free(jobs[k].names);
     free(jobs); free(th);
@@ -229,23 +238,20 @@ static int parse_devices(const char *arg, int *devs, int cap)
     return n ? n : -1;
 }
 
-static void on_alarm(int signo)
-{
-    (void)signo;
-    static const char msg[] = "rtl_wmbus: exiting since incoming data stopped flowing!\n";
-    if (write(2, msg, sizeof msg - 1) < 0) _exit(EXIT_FAILURE);
-    _exit(EXIT_FAILURE);
-}
+/* ---- live stream (stdin / TCP): wm_reader.c stages the bytes, this is where a push leaves -------- */
+struct live { wmbus_ctx *ctx; unsigned told; };
 
-static int flush_push(wmbus_ctx *ctx, const unsigned char *buf, size_t n)
+static int live_push(void *user, const unsigned char *buf, size_t n)
 {
-    int rc = wmbus_stage(ctx, 0, buf, n);
-    if (!rc) rc = wmbus_process(ctx, n);
-    if (!rc) rc = wmbus_collect(ctx);
-    if (rc) { fprintf(stderr, "rtl_wmbus_hip: %s\n", wmbus_last_error(ctx)); return rc; }
-    report_warnings(ctx);
+    struct live *lv = user;
+    int rc = wmbus_stage(lv->ctx, 0, buf, n);
+    if (!rc) rc = wmbus_process(lv->ctx, n);
+    if (!rc) rc = wmbus_collect(lv->ctx);
+    if (rc) { fprintf(stderr, "rtl_wmbus_hip: %s\n", wmbus_last_error(lv->ctx)); return rc; }
+    wmbus_timing t;
+    if (!wmbus_get_timing(lv->ctx, &t)) report_warnings(t.warnings, &lv->told);
     size_t len = 0;
-    const char *text = wmbus_lines_text(ctx, &len);
+    const char *text = wmbus_lines_text(lv->ctx, &len);
     if (len) { fwrite(text, 1, len, stdout); fflush(stdout); }
     return 0;
 }
@@ -256,10 +262,11 @@ int main(int argc, char **argv)
 
     wmbus_cfg cfg;
     wmbus_default_cfg(&cfg);
-    cfg.max_push_bytes = 1u << 20;
-    int check_flow = 0, opt, map_only = 0, devs[64], n_devs = 0;
+    cfg.max_push_bytes = 0;                                  /* 0: the mode's default, see below */
+    int check_flow = 0, opt, map_only = 0, devs[64], n_devs = 0, stats = 0;
+    unsigned max_latency_ms = 50;
     const char *tcp = NULL;
-    while ((opt = getopt(argc, argv, "ofad:p:r:vVst:B:G:PT:A:MUW")) != -1) {
+    while ((opt = getopt(argc, argv, "ofad:p:r:vVst:B:G:PT:A:MUWL:S")) != -1) {
         switch (opt) {
         case 'o': cfg.remove_dc = 1; break;
         case 'f': check_flow = 1; break;
@@ -288,50 +295,39 @@ int main(int argc, char **argv)
         case 'P': cfg.prefilter = WMBUS_PREFILTER_POLYPHASE; break;
         case 'A': cfg.atan_mode = atoi(optarg); break;
         case 'T': tcp = optarg; break;
+        case 'L': max_latency_ms = (unsigned)strtoul(optarg, NULL, 10); break;
+        case 'S': stats = 1; break;
         default: print_usage(argv[0]); return EXIT_FAILURE;
         }
     }
     if (getenv("WMBUS_FIXED_TS")) cfg.fixed_timestamp = 1;
 
-    if (check_flow) {
-        struct sigaction sa;
-        memset(&sa, 0, sizeof sa);
-        sa.sa_handler = on_alarm;
-        sigemptyset(&sa.sa_mask);
-        fprintf(stderr, "rtl_wmbus: monitoring flow\n");
-        sigaction(SIGALRM, &sa, NULL);
-    }
-
     if (optind < argc) {
+        /* batch mode: 8 MiB per file and push (the headline configuration's push; -B overrides) */
+        if (cfg.max_push_bytes == 0) cfg.max_push_bytes = 8u << 20;
         if (n_devs == 0) { devs[0] = cfg.device; n_devs = 1; }
-        if (n_devs == 1 && !map_only) return run_batch(cfg, argc - optind, argv + optind);
-        return run_sharded(cfg, argc - optind, argv + optind, devs, n_devs, map_only);
+        return run_sharded(cfg, argc - optind, argv + optind, devs, n_devs, map_only, stats);
     }
+    if (cfg.max_push_bytes == 0) cfg.max_push_bytes = 1u << 20;
 
-    FILE *input = stdin;
-    if (tcp && !(input = open_tcp(tcp))) return EXIT_FAILURE;
+    if (check_flow) fprintf(stderr, "rtl_wmbus: monitoring flow\n");
+    int fd = 0;
+    if (tcp && (fd = open_tcp(tcp)) < 0) return EXIT_FAILURE;
 
-    wmbus_ctx *ctx = NULL;
-    int rc = wmbus_open(&cfg, &ctx);
+    struct live lv = {NULL, 0};
+    int rc = wmbus_open(&cfg, &lv.ctx);
     if (rc) {
-        fprintf(stderr, "rtl_wmbus_hip: cannot open GPU back end: %s\n", ctx ? wmbus_last_error(ctx) : "out of memory");
-        wmbus_close(ctx);
+        fprintf(stderr, "rtl_wmbus_hip: cannot open GPU back end: %s\n", lv.ctx ? wmbus_last_error(lv.ctx) : "out of memory");
+        wmbus_close(lv.ctx);
         return EXIT_FAILURE;
     }
-
-    unsigned char *buf = malloc(cfg.max_push_bytes);
-    size_t fill = 0;
-    if (!buf) return EXIT_FAILURE;
-    for (;;) {
-        if (check_flow) alarm(2);
-        const size_t got = fread(buf + fill, WMBUS_BLOCK_BYTES, 1, input);   /* whole blocks only */
-        if (check_flow) alarm(0);
-        if (got != 1) break;                                                 /* EOF: partial tail dropped */
-        fill += WMBUS_BLOCK_BYTES;
-        if (fill == cfg.max_push_bytes) { if (flush_push(ctx, buf, fill)) { rc = 1; break; } fill = 0; }
+    /* -f: the reference arms alarm(2) around every fread (rtl_wmbus.c:1300-1302) */
+    const wm_reader_cfg rc_cfg = {fd, cfg.max_push_bytes, max_latency_ms, check_flow ? 2000u : 0u};
+    const int how = wm_reader_run(&rc_cfg, live_push, &lv);
+    wmbus_close(lv.ctx);
+    if (how == WM_READER_FLOW_STOPPED) {
+        fprintf(stderr, "rtl_wmbus: exiting since incoming data stopped flowing!\n");      /* rtl_wmbus.c:76 */
+        return EXIT_FAILURE;
     }
-    if (!rc && fill) rc = flush_push(ctx, buf, fill) ? 1 : 0;
-    free(buf);
-    wmbus_close(ctx);
-    return rc ? EXIT_FAILURE : EXIT_SUCCESS;
+    return how == WM_READER_EOF ? EXIT_SUCCESS : EXIT_FAILURE;
 }

@@ -30,12 +30,12 @@ def test_struct_sizes_match_ctypes(wm):
     import subprocess, tempfile
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "s.c")
-        open(c, "w").write('#include <stdio.h>\n#include "wmbus_hip.h"\nint main(void){printf("%zu %zu %zu\\n",'
-                           'sizeof(wmbus_cfg),sizeof(wmbus_line),sizeof(wmbus_timing));return 0;}\n')
+        open(c, "w").write('#include <stdio.h>\n#include "wmbus_hip.h"\nint main(void){printf("%zu %zu %zu %zu %zu\\n",'
+                           'sizeof(wmbus_cfg),sizeof(wmbus_line),sizeof(wmbus_timing),sizeof(wmbus_batch_io),sizeof(wmbus_batch_stats));return 0;}\n')
         exe = os.path.join(d, "s")
         subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-o", exe, c], check=True)
         sizes = list(map(int, subprocess.run([exe], capture_output=True, text=True).stdout.split()))
-    assert sizes == [ctypes.sizeof(wm.Cfg), ctypes.sizeof(wm.Line), ctypes.sizeof(wm.Timing)]
+    assert sizes == [ctypes.sizeof(wm.Cfg), ctypes.sizeof(wm.Line), ctypes.sizeof(wm.Timing), ctypes.sizeof(wm.BatchIo), ctypes.sizeof(wm.BatchStats)]
 
 
 def test_no_cpu_fallback_without_device(wm):
@@ -43,6 +43,13 @@ def test_no_cpu_fallback_without_device(wm):
         pytest.skip("a HIP device is present")
     with pytest.raises(wm.WmbusError, match="no HIP device|failed"):
         wm.Receiver(n_streams=1)
+
+
+def test_batch_needs_a_device_too(wm):
+    if wm.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(wm.WmbusError, match="no HIP device|failed"):
+        wm.Batch(n_streams=128)
 
 
 def test_cli_usage_and_exit_codes(wm):

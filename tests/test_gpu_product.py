@@ -1,0 +1,161 @@
+"""The PRODUCT's own entry points on the GPU (the headline rate was reachable only through bench.py):
+wmbus_batch_* through the ctypes mirror and through `rtl_wmbus_hip FILE...`, and the live-stream behaviour of the CLI
+behind a pipe (latency bound, -f, timestamps).  Everything is held against the oracle / the reference's goldens."""
+import json
+import os
+import re
+import subprocess
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from cases import flags_to_oracle_opts
+from conftest import GOLDEN, SAMPLES
+
+pytestmark = pytest.mark.gpu
+BUNDLED = json.load(open(os.path.join(GOLDEN, "bundled.json")))
+S2_NAME = "rtlsdr_868.950M_1M6_samples2.cu8"
+
+
+def _split_by_file(stdout, names):
+    got = {n: "" for n in names}
+    for line in stdout.decode().splitlines(True):
+        name, rest = line.split(": ", 1)
+        got[name] += rest
+    return got
+
+
+def test_cli_batch_of_320_files_runs_on_several_contexts_and_matches_the_oracle(wm, oracle, tmp_path):
+    """320 files = five 64-capture groups -> five receiver contexts on five worker threads inside ONE wmbus_batch, files of
+    three different lengths (ragged ends padded inside a group), three pushes each: every file's lines are what the capture
+    gives alone through the oracle."""
+    env = dict(os.environ, WMBUS_FIXED_TS="1")
+    n_files, push = 320, 1 << 19
+    lens = [3 * push // 2, 3 * push // 2 - 4096 * 7, push // 2 + 4096 * 3 + 100]          # IQ samples x 2 bytes; the last one has a partial tail
+    caps = [wm.synth_capture(seed=9000 + i, n_samples=lens[i % 3] // 2 + 50, kinds=15 if i % 4 else 7, frames_per_s=60.0)[0][:lens[i % 3]]
+            for i in range(n_files)]
+    names = [f"c{i:03d}.cu8" for i in range(n_files)]
+    for nm, c in zip(names, caps):
+        c.tofile(tmp_path / nm)
+    want = dict(zip(names, oracle.run_many(caps, flags_to_oracle_opts(oracle, ["-v"]), threads=min(32, os.cpu_count() or 1))))
+    p = subprocess.run([wm.CLI_PATH, "-v", "-S", "-B", str(push)] + names, cwd=tmp_path, capture_output=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert _split_by_file(p.stdout, names) == want
+    assert sum(len(t) for t in want.values()) > 50000
+    m = re.search(rb"320 files, (\d+) contexts, (\d+) samples", p.stderr)
+    assert m and int(m.group(1)) == 5                          # the library split the batch, not the caller
+    assert int(m.group(2)) == 320 * 3 * push // 2              # every group advanced by its longest file, whole pushes
+
+
+def test_batch_api_pipelines_pushes_and_keeps_every_stream_exact(wm, oracle):
+    """wmbus_batch_run with a host source (two input windows, page-locked slabs filled by the callback) and with resident
+    input: 192 captures in three contexts, five pushes each; the host decode of push k runs while push k + 1 is on the GPU,
+    half-received telegrams cross the push boundaries (continuation bursts), and every stream's text over all pushes equals
+    one oracle run over the whole capture."""
+    S, push, n_push = 192, 1 << 18, 5
+    caps = [wm.synth_capture(seed=7700 + i, n_samples=n_push * push // 2, kinds=15, frames_per_s=120.0)[0] for i in range(S)]
+    want = oracle.run_many(caps, flags_to_oracle_opts(oracle, ["-v"]), threads=min(32, os.cpu_count() or 1))
+    with wm.Batch(n_streams=S, max_push_bytes=push, input_windows=2) as b:
+        assert len(b.contexts) == 3 and [c[2] for c in b.contexts] == [64, 64, 64]
+        left = {first: 0 for _, first, _ in b.contexts}
+        text = [[] for _ in range(S)]
+
+        def fill(first, n, slab):
+            k = left[first]
+            if k == n_push:
+                return 0
+            left[first] = k + 1
+            for j in range(n):
+                slab[j, :push] = caps[first + j][k * push:(k + 1) * push]
+            return push
+
+        def on_push(first, n, lines, tm):
+            assert tm["warnings"] == 0
+            for ln in lines:
+                assert first <= ln["stream"] < first + n
+                text[ln["stream"]].append(ln["text"])
+        st = b.run_from(fill, on_push)
+        assert st["pushes"] == 3 * n_push and st["samples"] == S * n_push * push // 2
+        assert ["".join(t) for t in text] == want
+        assert st["lines"] == sum(len(t) for t in text)
+    # resident input: the same bytes every pass, carried state of the earlier passes included
+    with wm.Batch(n_streams=128, contexts=2, max_push_bytes=push) as b:
+        for s in range(128):
+            b.stage(s, caps[s][:push])
+        seen = {}
+        st = b.run_resident(push, 3, lambda first, n, lines, tm: seen.setdefault(first, []).append("".join(ln["text"] for ln in lines if ln["stream"] == first)))
+        want3 = oracle.run_many([caps[f][:push] for f in sorted(seen)], flags_to_oracle_opts(oracle, ["-v"]), passes=3, threads=2)
+        assert st["pushes"] == 6 and [seen[f][2] for f in sorted(seen)] == want3
+
+
+def test_cli_live_stream_latency_is_bounded_by_L_not_by_the_push_size(wm, samples):
+    """samples2 at its real rate (3.2 MB/s, 0.65 s of air time) into a 4 MiB push: nothing would come out before end of
+    input without the latency bound.  With -L 40 every telegram is on stdout within 40 ms (+ the GPU's few milliseconds and
+    scheduling slack) of the moment its completing sample was written into the pipe, and the text is the reference's."""
+    env = dict(os.environ, WMBUS_FIXED_TS="1")
+    data = samples["samples2"].tobytes()
+    with wm.Receiver(n_streams=1, max_push_bytes=len(data)) as rx:
+        rx.push([samples["samples2"]])
+        done_at_byte = [4 * ln["sample"] for ln in rx.lines()]           # decimated sample -> input byte (d = 2, 2 bytes per sample)
+    p = subprocess.Popen([wm.CLI_PATH, "-v", "-B", str(4 << 20), "-L", "40"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    piece, sent = 16384, []
+
+    def writer():
+        for k in range(0, len(data), piece):
+            os.write(p.stdin.fileno(), data[k:k + piece])
+            sent.append(time.monotonic())                              # the piece is in the pipe (the first ones wait for the CLI's set-up)
+            time.sleep(piece / 3.2e6)
+        p.stdin.close()
+    th = threading.Thread(target=writer)
+    th.start()
+    got, t_line = [], []
+    for _ in done_at_byte:
+        got.append(p.stdout.readline())
+        t_line.append(time.monotonic())
+    rest = p.stdout.read()
+    th.join()
+    assert p.wait() == 0, p.stderr.read()
+    assert (b"".join(got) + rest).decode() == BUNDLED[f"{S2_NAME}|-v"] and rest == b""
+    lat = [t - sent[min(b // piece, len(sent) - 1)] for t, b in zip(t_line, done_at_byte)]
+    assert max(lat) < 0.040 + 0.150, lat                                  # 1 MiB pushes alone would make this up to 0.33 s, 4 MiB 0.65 s
+    assert t_line[0] < sent[-1] - 0.1                                     # the first telegram is out long before the stream ends
+
+
+def test_cli_f_decodes_what_it_has_read_before_giving_up(wm, samples):
+    """-f (/root/reference/rtl_wmbus.c:61-79,1300-1308): the reference processes every block it has read before the alarm
+    can fire; so do we -- the staged bytes are decoded, then the message, exit code 1."""
+    env = dict(os.environ, WMBUS_FIXED_TS="1")
+    data = samples["samples2"].tobytes()
+    p = subprocess.Popen([wm.CLI_PATH, "-v", "-f", "-L", "0"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    p.stdin.write(data[:len(data) // 4096 * 4096 - 4096 * 10]); p.stdin.flush()        # ... and then the flow stops, pipe still open
+    t0 = time.monotonic()
+    try:
+        rc = p.wait(timeout=30)
+    finally:
+        p.stdin.close()
+    out, err = p.stdout.read().decode(), p.stderr.read().decode()
+    assert rc == 1 and 1.5 < time.monotonic() - t0 < 10
+    assert "monitoring flow" in err and "exiting since incoming data stopped flowing" in err
+    assert out == BUNDLED[f"{S2_NAME}|-v"]                        # all four telegrams end before the missing tail
+
+
+def test_timestamps_follow_the_completing_sample(wm, samples):
+    """Line time = hand-over time of the push - (push end - completing sample) / 800 kHz (the reference stamps at
+    last-chip processing, t1_c1_packet_decoder.h:390,458): within one push the stamps of two lines differ by exactly their
+    sample distance, and none lies after the hand-over."""
+    import datetime
+    with wm.Receiver(n_streams=1, max_push_bytes=samples["samples2"].size, fixed_timestamp=False) as rx:
+        t_before = time.time()
+        rx.push([samples["samples2"]])
+        t_after = time.time()
+        lines = rx.lines()
+    assert len(lines) == 4
+    ts = [datetime.datetime.strptime(ln["text"].split(";")[4], "%Y-%m-%d %H:%M:%S.%f").timestamp() for ln in lines]
+    for a in range(4):
+        for b in range(a + 1, 4):
+            want = (lines[b]["sample"] - lines[a]["sample"]) / 800e3
+            assert abs((ts[b] - ts[a]) - want) < 3e-6, (a, b, ts[b] - ts[a], want)
+    m_end = samples["samples2"].size // 4
+    assert t_before - 1e-3 <= ts[-1] + (m_end - 1 - lines[-1]["sample"]) / 800e3 <= t_after + 1e-3
