@@ -46,7 +46,7 @@ def test_cli_batch_of_320_files_runs_on_several_contexts_and_matches_the_oracle(
     assert sum(len(t) for t in want.values()) > 50000
     m = re.search(rb"320 files, (\d+) contexts, (\d+) samples", p.stderr)
     assert m and int(m.group(1)) == 5                          # the library split the batch, not the caller
-    assert int(m.group(2)) == 320 * 3 * push // 2              # every group advanced by its longest file, whole pushes
+    assert int(m.group(2)) == 320 * lens[0] // 2                 # every group advanced by its longest file
 
 
 def test_batch_api_pipelines_pushes_and_keeps_every_stream_exact(wm, oracle):
