@@ -69,6 +69,7 @@ def parse():
                     help="informational: stage every capture from pinned host memory inside each step (PCIe-inclusive rate; "
                          "the BASELINE metric keeps the input resident in HBM)")
     ap.add_argument("--host-threads", type=int, default=0, help="packet-decoder threads per context (0: cores / (ranks x contexts), at most 32)")
+    ap.add_argument("--tolerance-mode", action="store_true", help="informational: wmbus_cfg.tolerance_mode = 1 (soft symbols within 2e-6, not bit-identical); never the headline value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     return ap.parse_args()
@@ -188,7 +189,7 @@ def main():
     host_threads = a.host_threads or shard.host_threads_per_context(world, nctx_guess)
     batch = wm.Batch(n_streams=S, contexts=nctx_req, max_push_bytes=push_bytes, device=local, seg_len=a.seg_len, rla_seg_len=a.rla_seg_len,
                      warmup_s1=a.warmup_s1, warmup_t1c1=a.warmup_t1c1, rla_lookback=a.rla_lookback, show_algorithm=True, fixed_timestamp=True,
-                     host_threads=host_threads, input_windows=2 if a.from_host else 1)
+                     host_threads=host_threads, input_windows=2 if a.from_host else 1, tolerance_mode=int(a.tolerance_mode))
     nctx = len(batch.contexts)
     per_ctx = [cnt for _, _, cnt in batch.contexts]
     for s in range(S):
@@ -243,6 +244,12 @@ def main():
         bad = [s_ for s_ in range(S) if got[s_] != want[s_]]
         parity = {"first_pass": {"captures_compared": S, "contexts": nctx, "mismatches": len(bad), "first_bad": bad[:4],
                                  "datagrams": sum(len(t.splitlines()) for t in want), "oracle_s": round(time.perf_counter() - t_o, 1)}}
+        if a.tolerance_mode:                                   # informational run: how many LINES differ from the reference's
+            dl = 0
+            for s_ in bad:
+                g, w = collections.Counter(got[s_].splitlines()), collections.Counter(want[s_].splitlines())
+                dl += sum(((g - w) + (w - g)).values())
+            parity["first_pass"]["differing_lines"] = dl
     if a.warmup:
         run_steps(a.warmup)
         passes_done += a.warmup
@@ -363,6 +370,7 @@ def main():
             "stage_ms_mid_step": [rnd(t) for t in (tim_acc[a.steps // 2] if tim_acc else [])],
             "setup_s": {"generate": round(t_gen, 1), "alloc_and_h2d": round(t_h2d, 1)},
             "input": "staged from pinned host memory inside every step (PCIe-inclusive, informational)" if a.from_host else "resident in HBM",
+            "tolerance_mode": bool(a.tolerance_mode),
         }
         cli = os.path.join(ROOT, "profiles", "cli_rate.json")     # tools/bench_cli.sh: the product's own command line, wall-clocked
         if os.path.exists(cli):
@@ -381,10 +389,10 @@ def main():
             out["parity_check"] = (f"{fp['captures_compared']} captures x {nctx} contexts (first pass, all of them) and {lp['captures_compared']} captures "
                                    f"across {nctx} contexts (pass {lp['pass_number']}, carried state) identical to the oracle"
                                    if parity["ok"] else "MISMATCH")
-            ok = bool(parity["ok"])
+            ok = bool(parity["ok"]) or a.tolerance_mode          # tolerance mode is informational: its differences are reported, not fatal
         print(json.dumps(out), flush=True)
     elif parity is not None:
-        ok = bool(parity["ok"])
+        ok = bool(parity["ok"]) or a.tolerance_mode
     batch.close()
     shard.destroy(group)
     return 0 if ok else 3                                     # a rate whose datagrams differ from the reference's is not a result

@@ -81,6 +81,12 @@ typedef struct wmbus_cfg {
                                    that wmbus_stage() for the next push may run while the previous one is in flight (the
                                    copies run on their own HIP stream).  wmbus_device_input() names the window the next
                                    wmbus_process() will read. */
+    /* 0 (default): every soft symbol, RSSI byte and chip is bit-identical to the reference's.  1: TOLERANCE MODE for the
+     * default switches (both chains, cargf arctangent, no -P): the discriminator uses a polynomial arctangent and the two
+     * FIR low-passes fused multiply-adds, so soft symbols agree with the reference's to 2e-6 (absolute; they lie in
+     * [-1, 1]) instead of bit for bit; RSSI, clock recovery and framers stay exact on those symbols.  A telegram whose
+     * decision hangs on the last bits of a soft symbol may decode differently (DESIGN.md section 12 counts them). */
+    int tolerance_mode;
 } wmbus_cfg;
 
 enum { WMBUS_PREFILTER_BOXCAR = 0, WMBUS_PREFILTER_POLYPHASE = 1 };

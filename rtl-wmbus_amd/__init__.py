@@ -43,7 +43,7 @@ class Cfg(ctypes.Structure):
                 ("warmup_t1c1", ctypes.c_uint),
                 ("warmup_s1", ctypes.c_uint), ("rla_lookback", ctypes.c_uint), ("host_threads", ctypes.c_uint),
                 ("keep_taps", ctypes.c_int), ("prefilter", ctypes.c_int), ("atan_mode", ctypes.c_int), ("spill_words", ctypes.c_uint), ("dedup_twins", ctypes.c_int), ("only_crc_ok", ctypes.c_int),
-                ("input_windows", ctypes.c_uint)]
+                ("input_windows", ctypes.c_uint), ("tolerance_mode", ctypes.c_int)]
 
 
 class Line(ctypes.Structure):
@@ -158,7 +158,7 @@ def selftest_math(a, b, device=0):
 def _make_cfg(n_streams=1, max_push_bytes=4 << 20, decimation=2, simultaneous=False, accurate_atan=True,
               remove_dc=False, t1c1=True, s1=True, rla=True, time2=True, show_algorithm=True, device=0,
               seg_len=0, rla_seg_len=0, warmup_t1c1=0, warmup_s1=0, rla_lookback=0, host_threads=0, fixed_timestamp=True,
-              prefilter=0, atan_mode=0, keep_taps=True, spill_words=0, input_windows=1, dedup_twins=False, only_crc_ok=False):
+              prefilter=0, atan_mode=0, keep_taps=True, spill_words=0, input_windows=1, dedup_twins=False, only_crc_ok=False, tolerance_mode=0):
     c = Cfg()
     lib().wmbus_default_cfg(ctypes.byref(c))
     c.decimation, c.simultaneous, c.accurate_atan, c.remove_dc = decimation, int(simultaneous), int(accurate_atan), int(remove_dc)
@@ -168,7 +168,7 @@ def _make_cfg(n_streams=1, max_push_bytes=4 << 20, decimation=2, simultaneous=Fa
     c.seg_len, c.rla_seg_len, c.warmup_t1c1, c.warmup_s1 = seg_len, rla_seg_len, warmup_t1c1, warmup_s1
     c.rla_lookback, c.host_threads = rla_lookback, host_threads
     c.keep_taps, c.prefilter, c.atan_mode, c.spill_words, c.input_windows = int(keep_taps), prefilter, atan_mode, spill_words, input_windows
-    c.dedup_twins, c.only_crc_ok = int(dedup_twins), int(only_crc_ok)
+    c.dedup_twins, c.only_crc_ok, c.tolerance_mode = int(dedup_twins), int(only_crc_ok), int(tolerance_mode)
     return c
 
 

@@ -244,15 +244,15 @@ __global__ __launch_bounds__(256) void k_sum_counts(WmPush g, const uint32_t *co
     }
 }
 
-template <int D, bool SHIFT, bool GEN> int launch_k1v3(wmbus_ctx *c, const K1Args &a, dim3 grid)
+template <int D, bool SHIFT, bool GEN, bool FAST = false> int launch_k1v3(wmbus_ctx *c, const K1Args &a, dim3 grid)
 {
     const size_t sm = K1Geo::smem(D ? D : (int)c->d, SHIFT);
     static std::atomic<size_t> set_for[16];                 /* per device: the attribute call is not free, a push makes several launches */
     if (set_for[c->cfg.device & 15] < sm) {
-        HIPCHK(c, hipFuncSetAttribute((const void *)k1_demod2<D, SHIFT, GEN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+        HIPCHK(c, hipFuncSetAttribute((const void *)k1_demod2<D, SHIFT, GEN, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
         set_for[c->cfg.device & 15] = sm;
     }
-    hipLaunchKernelGGL((k1_demod2<D, SHIFT, GEN>), grid, dim3(256), sm, c->stream, a);
+    hipLaunchKernelGGL((k1_demod2<D, SHIFT, GEN, FAST>), grid, dim3(256), sm, c->stream, a);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -261,7 +261,9 @@ template <int D, bool SHIFT, bool GEN> int launch_k1v3(wmbus_ctx *c, const K1Arg
 template <int D, bool SHIFT> int launch_k1v2(wmbus_ctx *c, const K1Args &a, dim3 grid)
 {
     const uint32_t need = WM_F_ACCURATE | WM_F_T1C1 | WM_F_S1, never = WM_F_APPROX1 | WM_F_APPROX2;
-    if (D != 0 && a.relist == nullptr && (c->flags & need) == need && !(c->flags & never)) return launch_k1v3<D, SHIFT, false>(c, a, grid);
+    if (D != 0 && a.relist == nullptr && (c->flags & need) == need && !(c->flags & never))
+        /* tolerance mode (an option of the default switches' kernel only; everything else stays exact) */
+        return c->cfg.tolerance_mode ? launch_k1v3<D, SHIFT, false, true>(c, a, grid) : launch_k1v3<D, SHIFT, false>(c, a, grid);
     return launch_k1v3<D, SHIFT, true>(c, a, grid);
 }
 

@@ -259,6 +259,46 @@ WM_HD float wm_discriminator_tab(float i, float q, float pi_, float pq_, const f
     return wm_mul(wm_atan2f_tab(im, re, tab), wm_u2f(0x3ea2f983u));    /* (float)M_1_PI */
 }
 
+/* TOLERANCE MODE (wmbus_cfg.tolerance_mode = 1, never the default; BASELINE north_star: "demodulated soft symbols within a
+ * stated float tolerance").  The same discriminator with a polynomial arctangent: atan(r) / pi for r = min / max in [0, 1]
+ * as r * P(r^2), P of degree 6 fitted to 1.1e-7 (absolute, in the discriminator's units of pi radians; 2.4e-7 measured
+ * with the reciprocal and the float evaluation, tests/exact_math_check.c), one hardware reciprocal instead of two correctly
+ * rounded divisions, fused multiply-adds.  Octant and sign
+ * handling mirrors atan2f's (signed zeros included: atan2f(-0, x < 0) = -pi flips the symbol from +1 to -1, so it must
+ * not be "within tolerance" of the other sign).  About 28 instructions against 71. */
+WM_HD float wm_discriminator_tol(float i, float q, float pi_, float pq_)
+{
+    const float c = pi_, d = -pq_;
+    const float re = wm_sub(wm_mul(i, c), wm_mul(q, d));                /* exact integers either way */
+    const float im = wm_add(wm_mul(i, d), wm_mul(q, c));
+    const uint32_t hx = wm_f2u(re), hy = wm_f2u(im);
+    const float ax = wm_u2f(hx & 0x7fffffffu), ay = wm_u2f(hy & 0x7fffffffu);
+    const float mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r = mn * __builtin_amdgcn_rcpf(mx > 1e-30f ? mx : 1e-30f);
+    float p = __builtin_fmaf(0.002168180188164115f, r * r, -0.010696296580135822f);
+    const float s = r * r;
+    p = __builtin_fmaf(p, s, 0.02534468285739422f);
+    p = __builtin_fmaf(p, s, -0.04212284833192825f);
+    p = __builtin_fmaf(p, s, 0.06305018067359924f);
+    p = __builtin_fmaf(p, s, -0.1060524731874466f);
+    p = __builtin_fmaf(p, s, 0.31830865144729614f);
+#else
+    const float r = mn / (mx > 1e-30f ? mx : 1e-30f);
+    const float s = r * r;
+    float p = fmaf(0.002168180188164115f, s, -0.010696296580135822f);
+    p = fmaf(p, s, 0.02534468285739422f);
+    p = fmaf(p, s, -0.04212284833192825f);
+    p = fmaf(p, s, 0.06305018067359924f);
+    p = fmaf(p, s, -0.1060524731874466f);
+    p = fmaf(p, s, 0.31830865144729614f);
+#endif
+    float z = p * r;                                                    /* atan(min / max) / pi in [0, 1/4] */
+    z = ay > ax ? 0.5f - z : z;
+    z = (hx >> 31) ? 1.0f - z : z;
+    return wm_copysign_bits(z, hy);
+}
+
 /* Polar discriminator (rtl_wmbus.c:517-534 / 553-570): y = s * conj(s_prev), cargf(y)/pi.
  * gcc expands the complex product as (a*c - b*d) + j(a*d + b*c) with (c,d) = (i', -q'). */
 WM_HD float wm_discriminator(float i, float q, float pi_, float pq_)

@@ -118,6 +118,9 @@ __device__ __forceinline__ void k1_boxcars(const uint32_t *w, int d_rt, wm_s2 s8
  * moving-average and the polyphase front ends.  Rows: element a of a discriminator row at word
  * a + 4, of a magnitude row at a + a/16 (the two chains' rows may alias when they carry the same
  * data).  Ends with the magnitude rows' barrier already passed by every thread. */
+/* FAST (wmbus_cfg.tolerance_mode, never the default): one fused multiply-add per tap instead of the reference's separately
+ * rounded product and sum -- the soft symbol then differs from the reference's by rounding noise. */
+template <bool FAST = false>
 __device__ __forceinline__ void k1_fir_t(const K1Args &a, const float *yDrT, const int slot, const int stream, const int ts, const int tn)
 {
     const WmPush &g = a.g;
@@ -134,12 +137,13 @@ __device__ __forceinline__ void k1_fir_t(const K1Args &a, const float *yDrT, con
     for (int j = 0; j < 4; j++) {
         float s = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 11; k++) s = wm_add(s, wm_mul(FIR_T[k], w[12 + j - k]));
+        for (int k = 0; k < 11; k++) s = FAST ? __builtin_fmaf(FIR_T[k], w[12 + j - k], s) : wm_add(s, wm_mul(FIR_T[k], w[12 + j - k]));
         acc[j] = s;
     }
     *(float4 *)(a.dphi + (uint64_t)stream * g.Mcap + (uint64_t)ts + m0l) = make_float4(acc[0], acc[1], acc[2], acc[3]);
 }
 
+template <bool FAST = false>
 __device__ __forceinline__ void k1_fir_s(const K1Args &a, const float *yDrS, const int slot, const int stream, const int ts, const int tn)
 {
     const WmPush &g = a.g;
@@ -156,7 +160,7 @@ __device__ __forceinline__ void k1_fir_s(const K1Args &a, const float *yDrS, con
     for (int j = 0; j < 4; j++) {
         float s = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 46; k++) s = wm_add(s, wm_mul(FIR_S[k], w[48 + j - k]));
+        for (int k = 0; k < 46; k++) s = FAST ? __builtin_fmaf(FIR_S[k], w[48 + j - k], s) : wm_add(s, wm_mul(FIR_S[k], w[48 + j - k]));
         acc[j] = s;
     }
     *(float4 *)(a.dphi + ((uint64_t)g.S + stream) * g.Mcap + (uint64_t)ts + m0l) = make_float4(acc[0], acc[1], acc[2], acc[3]);
@@ -174,7 +178,7 @@ __device__ __forceinline__ void k1_fir_s(const K1Args &a, const float *yDrS, con
 #ifndef WM_K1_BALANCED
 #define WM_K1_BALANCED 1
 #endif
-template <bool GEN>
+template <bool GEN, bool FAST = false>
 __device__ __forceinline__ void k1_stage_b(const K1Args &a, const int tid, const int tile, const int stream, const int ts, const int tn,
                                            const bool chT, const bool chS, const float *yDrT, const float *yDrS,
                                            const float *yMgT, const float *yMgS, float *sFin, float *sHead)
@@ -241,14 +245,14 @@ __device__ __forceinline__ void k1_stage_b(const K1Args &a, const int tid, const
                 *(uint4 *)(a.rssi + row * g.Mcap + ts + m0l) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
             sFin[rt] = ema; sHead[rt] = head;
         }
-        if (WM_K1_BALANCED) { if (chS) k1_fir_s(a, yDrS, 64 * wv + e, stream, ts, tn); }
-        else if (chT) { k1_fir_t(a, yDrT, 128 * wv + e, stream, ts, tn); k1_fir_t(a, yDrT, 128 * wv + 64 + e, stream, ts, tn); }
+        if (WM_K1_BALANCED) { if (chS) k1_fir_s<FAST>(a, yDrS, 64 * wv + e, stream, ts, tn); }
+        else if (chT) { k1_fir_t<FAST>(a, yDrT, 128 * wv + e, stream, ts, tn); k1_fir_t<FAST>(a, yDrT, 128 * wv + 64 + e, stream, ts, tn); }
     } else if (WM_K1_BALANCED) {
-        if (chS) k1_fir_s(a, yDrS, 64 * wv + e, stream, ts, tn);
-        if (chT) { k1_fir_t(a, yDrT, 128 * (wv - 2) + e, stream, ts, tn); k1_fir_t(a, yDrT, 128 * (wv - 2) + 64 + e, stream, ts, tn); }
+        if (chS) k1_fir_s<FAST>(a, yDrS, 64 * wv + e, stream, ts, tn);
+        if (chT) { k1_fir_t<FAST>(a, yDrT, 128 * (wv - 2) + e, stream, ts, tn); k1_fir_t<FAST>(a, yDrT, 128 * (wv - 2) + 64 + e, stream, ts, tn); }
     } else if (chS) {
-        k1_fir_s(a, yDrS, 128 * (wv - 2) + e, stream, ts, tn);
-        k1_fir_s(a, yDrS, 128 * (wv - 2) + 64 + e, stream, ts, tn);
+        k1_fir_s<FAST>(a, yDrS, 128 * (wv - 2) + e, stream, ts, tn);
+        k1_fir_s<FAST>(a, yDrS, 128 * (wv - 2) + 64 + e, stream, ts, tn);
     }
     __syncthreads();
     /* certify: a lane's warm-up must have landed exactly on its predecessor's trajectory; a tile
@@ -264,7 +268,7 @@ __device__ __forceinline__ void k1_stage_b(const K1Args &a, const int tid, const
 /* GEN = false: the kernel of the DEFAULT switches (both chains, cargf arctangent, first pass): the switch tests, the
  * -a / -A / -p paths and the RSSI repair walk are not compiled in, so the default path carries no cost for the options
  * (any other configuration, and every repair launch, runs the GEN = true kernel: same arithmetic, same results). */
-template <int D, bool SHIFT, bool GEN>
+template <int D, bool SHIFT, bool GEN, bool FAST = false>
 __device__ __forceinline__ void k1_tile(const K1Args &a, const int tile, const int stream, const int tid)
 {
     using G = K1Geo;
@@ -364,8 +368,8 @@ __device__ __forceinline__ void k1_tile(const K1Args &a, const int tile, const i
         if (accurate && chT && chS && !approx) {             /* default switches: no branch between the eight */
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                drT[j] = wm_discriminator_tab(fT[j + 1][0], fT[j + 1][1], fT[j][0], fT[j][1], tab);
-                drS[j] = wm_discriminator_tab(fS[j + 1][0], fS[j + 1][1], fS[j][0], fS[j][1], tab);
+                drT[j] = FAST ? wm_discriminator_tol(fT[j + 1][0], fT[j + 1][1], fT[j][0], fT[j][1]) : wm_discriminator_tab(fT[j + 1][0], fT[j + 1][1], fT[j][0], fT[j][1], tab);
+                drS[j] = FAST ? wm_discriminator_tol(fS[j + 1][0], fS[j + 1][1], fS[j][0], fS[j][1]) : wm_discriminator_tab(fS[j + 1][0], fS[j + 1][1], fS[j][0], fS[j][1], tab);
             }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -399,27 +403,27 @@ __device__ __forceinline__ void k1_tile(const K1Args &a, const int tile, const i
         for (int j = 0; j < 4; j++) { yMgT[qb + j] = mgT[j]; yMgS[qb + j] = mgS[j]; }
     }
 
-    k1_stage_b<GEN>(a, tid, tile, stream, ts, tn, chT, chS, yDrT, yDrS, yMgT, yMgS, sFin, sHead);
+    k1_stage_b<GEN, FAST>(a, tid, tile, stream, ts, tn, chT, chS, yDrT, yDrS, yMgT, yMgS, sFin, sHead);
 }
 
-template <int D, bool SHIFT, bool GEN = true>
+template <int D, bool SHIFT, bool GEN = true, bool FAST = false>
 __global__ __launch_bounds__(256, GEN ? 1 : 8) void k1_demod2(K1Args a)          /* first pass: 64 VGPRs, eight waves fill a SIMD (the tile loop of the bounded grid would otherwise hoist its way to 95) */
 {
     if (!GEN || a.relist == nullptr) {
-        if (a.n_items == 0u) { k1_tile<D, SHIFT, GEN>(a, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x); return; }
+        if (a.n_items == 0u) { k1_tile<D, SHIFT, GEN, FAST>(a, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x); return; }
         /* bounded grid: a block walks tiles (no barrier between two tiles is needed: a tile's last LDS reads, sFin, are
          * three barriers ahead of the next tile's writes to that array, and its staging area is dead after stage B's first) */
         for (uint32_t i = blockIdx.x; i < a.n_items; i += gridDim.x) {
             int tid = (int)threadIdx.x;
             asm volatile("" : "+v"(tid));                      /* per-thread addresses are recomputed per tile, not kept in registers across the loop */
-            k1_tile<D, SHIFT, GEN>(a, (int)(i % a.ntiles), (int)(i / a.ntiles), tid);
+            k1_tile<D, SHIFT, GEN, FAST>(a, (int)(i % a.ntiles), (int)(i / a.ntiles), tid);
         }
         return;
     }
     /* repair launch: a fixed grid walks the list k1_collect has just written (no host round trip in between) */
     const uint32_t n = *a.n_relist;
     for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
-        k1_tile<D, SHIFT, GEN>(a, (int)(a.relist[e] % a.ntiles), (int)(a.relist[e] / a.ntiles), (int)threadIdx.x);
+        k1_tile<D, SHIFT, GEN, FAST>(a, (int)(a.relist[e] % a.ntiles), (int)(a.relist[e] / a.ntiles), (int)threadIdx.x);
         __syncthreads();                                      /* the tile's LDS is reused by the next entry */
     }
 }

@@ -57,6 +57,7 @@ static void print_usage(const char *prog)
     fprintf(stdout, "\t-U unique: print a datagram that both the time2 and the run length method decoded only once\n");
     fprintf(stdout, "\t-W like -U, and only datagrams with a correct CRC (what wmbusmeters keeps)\n");
     fprintf(stdout, "\t-A 1|2 atan2_approximation / atan2_approximation2 (atan2.h) instead of cargf in the discriminator\n");
+    fprintf(stdout, "\t-F tolerance mode: soft symbols within 2e-6 of the reference's instead of bit-identical (faster; default switches only)\n");
     fprintf(stdout, "\t-P polyphase low-pass (ppf.h) instead of the moving average before decimation (1.6 MS/s, -d 2, no -s)\n");
     fprintf(stdout, "\t-T host:port read the cu8 stream from a TCP server instead of stdin\n");
     fprintf(stdout, "\tFILE... batch mode: decode several cu8 files at once (lines prefixed with the file name)\n");
@@ -266,7 +267,7 @@ int main(int argc, char **argv)
     int check_flow = 0, opt, map_only = 0, devs[64], n_devs = 0, stats = 0;
     unsigned max_latency_ms = 50;
     const char *tcp = NULL;
-    while ((opt = getopt(argc, argv, "ofad:p:r:vVst:B:G:PT:A:MUWL:S")) != -1) {
+    while ((opt = getopt(argc, argv, "ofad:p:r:vVst:B:G:PT:A:MUWL:SF")) != -1) {
         switch (opt) {
         case 'o': cfg.remove_dc = 1; break;
         case 'f': check_flow = 1; break;
@@ -297,6 +298,7 @@ int main(int argc, char **argv)
         case 'T': tcp = optarg; break;
         case 'L': max_latency_ms = (unsigned)strtoul(optarg, NULL, 10); break;
         case 'S': stats = 1; break;
+        case 'F': cfg.tolerance_mode = 1; break;
         default: print_usage(argv[0]); return EXIT_FAILURE;
         }
     }

@@ -74,6 +74,36 @@ int main(int argc, char **argv)
             tot++;
         }
     }
+    /* tolerance mode's discriminator (wmbus_cfg.tolerance_mode, never the default): within 4e-7 of the exact one on the
+     * operand domain, same octant / signed-zero behaviour (-1 and +1 are NOT close: atan2f(-0, x < 0) = -pi) */
+    {
+        double worst = 0.0;
+        for (long k = 0; k < n / 4; k++) {
+            const uint64_t r = rnd();
+            const int lim = (k & 1) ? 2880 : 1016;
+            int v[4];
+            for (int j = 0; j < 4; j++) v[j] = (int)((r >> (16 * j)) & 0xFFFF) % (2 * ((k & 2) ? 12 : lim) + 1) - ((k & 2) ? 12 : lim);
+            if ((k & 0xFF) == 0) v[(k >> 8) & 3] = 0;                     /* exact zeros among the operands */
+            const float ex = wm_discriminator((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+            const float to = wm_discriminator_tol((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+            const double e = fabs((double)ex - (double)to);
+            if (e > worst) worst = e;
+            if (e > 4e-7) { static int shown; if (shown++ < 10) printf("TOLERANCE %d %d %d %d: exact %a fast %a\n", v[0], v[1], v[2], v[3], ex, to); bad++; }
+            tot++;
+        }
+        const float z2[2] = {0.0f, -0.0f};
+        for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) for (int c = 0; c < 2; c++) for (int d = 0; d < 2; d++) {
+            /* products of signed zeros and of zeros with non-zeros, as a silent stretch or a start of stream forms them */
+            const float cases[3][4] = {{z2[a], z2[b], z2[c], z2[d]}, {5.0f, z2[b], -3.0f, z2[d]}, {z2[a], 4.0f, z2[c], -2.0f}};
+            for (int t = 0; t < 3; t++) {
+                const float ex = wm_discriminator(cases[t][0], cases[t][1], cases[t][2], cases[t][3]);
+                const float to = wm_discriminator_tol(cases[t][0], cases[t][1], cases[t][2], cases[t][3]);
+                if (fabs((double)ex - (double)to) > 4e-7 || (wm_f2u(ex) >> 31) != (wm_f2u(to) >> 31)) { printf("TOLERANCE zero case %d: exact %a fast %a\n", t, ex, to); bad++; }
+                tot++;
+            }
+        }
+        printf("tolerance-mode discriminator: worst |error| %.3g\n", worst);
+    }
     printf("checked %ld cases, %ld mismatches\n", tot, bad);
     return bad != 0;
 }

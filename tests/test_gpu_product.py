@@ -159,3 +159,27 @@ def test_timestamps_follow_the_completing_sample(wm, samples):
             assert abs((ts[b] - ts[a]) - want) < 3e-6, (a, b, ts[b] - ts[a], want)
     m_end = samples["samples2"].size // 4
     assert t_before - 1e-3 <= ts[-1] + (m_end - 1 - lines[-1]["sample"]) / 800e3 <= t_after + 1e-3
+
+
+@pytest.mark.parametrize("name,flags", [(S2_NAME, ["-v"]), ("rtlsdr_868.625M_2M4_issue48.cu8", ["-d", "3", "-s", "-o", "-v"])])
+def test_tolerance_mode_keeps_the_bundled_datagrams_and_states_its_tolerance(wm, oracle, name, flags):
+    """wmbus_cfg.tolerance_mode / CLI -F (never the default; BASELINE north_star allows "soft symbols within a stated float
+    tolerance" as long as datagram bytes stay identical): polynomial arctangent + FMA low-passes.  On the reference's own
+    captures the text is identical and every soft symbol lies within 2e-6 of the oracle's; RSSI bytes stay bit-identical."""
+    from cases import flags_to_kwargs
+    cu8 = np.fromfile(os.path.join(SAMPLES, name), np.uint8)
+    ref = oracle.run(cu8, flags_to_oracle_opts(oracle, flags), taps=True)
+    with wm.Receiver(n_streams=1, max_push_bytes=cu8.size // 4096 * 4096, tolerance_mode=1, **flags_to_kwargs(flags)) as rx:
+        text = rx.run(cu8)[0]
+        m = ref["m"]
+        worst, differ = 0.0, 0
+        for ch in (0, 1):
+            d = rx.read_tap("dphi", ch, 0, m).astype(np.float64) - ref["dphi_fir"][ch].astype(np.float64)
+            worst = max(worst, float(np.abs(d).max()))
+            differ += int(np.count_nonzero(d))
+            assert np.array_equal(rx.read_tap("rssi", ch, 0, m), ref["rssi"][ch].astype(np.uint32).astype(np.uint8))
+    assert text == ref["text"] == BUNDLED[f"{name}|{' '.join(flags)}"]
+    assert 0 < worst < 2e-6 and differ > m // 2                # really the other arithmetic, and within the stated tolerance
+    env = dict(os.environ, WMBUS_FIXED_TS="1")
+    p = subprocess.run([wm.CLI_PATH, "-F"] + flags, input=cu8.tobytes(), capture_output=True, env=env)
+    assert p.returncode == 0 and p.stdout.decode() == ref["text"]
