@@ -302,11 +302,13 @@ __global__ void k_selftest(const float *a, const float *b, float *o_sqrt, float 
 struct K1Chain { std::mutex m; hipEvent_t last = nullptr; const wmbus_ctx *owner = nullptr; };
 K1Chain k1_chain[16];
 
-/* One HIP stream per receiver context; ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default) round
- * robin, and streams that share a queue serialise against each other: eight contexts on four queues lose 25 %.  The
- * runtime reads the variable when it initialises (the first HIP call of the process), so the library sets its default
- * when it is loaded -- a caller's own setting wins.  (bench.py and INTEGRATION.md used to ask the caller for this.) */
-__attribute__((constructor)) void wm_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+/* One HIP stream per receiver context (two with cfg.input_windows = 2); ROCm maps streams onto GPU_MAX_HW_QUEUES hardware
+ * queues (4 by default) round robin, and streams that share a queue serialise against each other: eight contexts on four
+ * queues run at 81 instead of 143 Gsamples/s, ten on eight at 107 (r03 A/B).  The runtime reads the variable when it
+ * initialises (the first HIP call of the process), so the library sets its default when it is loaded -- a caller's own
+ * setting wins.  16 covers the default batch (8 contexts, 12 in tolerance mode) with and without copy streams; with 16
+ * queues and 8 contexts the rate is the one with 8 queues.  (bench.py and INTEGRATION.md used to ask the caller for this.) */
+__attribute__((constructor)) void wm_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 
 double now_ms()
 {

@@ -10,7 +10,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 
 COPIES = [("trace/bench_kernel_stats.csv", "bench_kernel_stats.csv"),
           ("trace/bench_domain_stats.csv", "bench_domain_stats.csv"),
@@ -55,12 +55,23 @@ def per_kernel(name):
 fetch, write = per_kernel("pmc_fetch_size.csv"), per_kernel("pmc_write_size.csv")
 
 
+def family(kernel):
+    """Kernel name -> the family its numbers are booked under, or None to skip: the list kernels (re-run lists) ride with
+    their first-pass kernels, the option / repair variant of K1 (k1_demod2<D, SHIFT, GEN = true, ..>: empty list launches in
+    the bench) is left out."""
+    k = kernel.replace("void ", "").split("(")[0].strip()
+    base = k.split("<")[0]
+    if base == "k1_demod2":
+        args = [a.strip() for a in k[k.index("<") + 1:k.rindex(">")].split(",")] if "<" in k else []
+        if len(args) >= 3 and args[2] == "true":
+            return None
+    return {"k2_clock_list": "k2_clock", "k2_rla_list": "k2_rla"}.get(base, base)
+
+
 def pick(d, prefix):
     n = s = 0
     for k, (ln, kb) in d.items():
-        base = k.replace("void ", "").split("(")[0].split("<")[0]
-        if prefix == "k1_demod2" and k.rstrip().endswith("true>"):
-            continue                                   # the option / repair variant of the kernel (empty list launches here)
+        base = family(k)
         if base == prefix:
             n += ln
             s += kb
@@ -73,9 +84,9 @@ if os.path.exists(sqp):
     S, N = 1024, 1 << 22
     per = {}
     for r in csv.DictReader(open(sqp)):
-        if r["kernel"].rstrip().endswith("true>") and r["kernel"].startswith("k1_demod2"):
+        base = family(r["kernel"])
+        if base is None:
             continue                                   # repair / option variant: empty list launches
-        base = r["kernel"].split("<")[0]
         d = per.setdefault(base, {"launches": 0, "avg_ms_under_pmc": 0.0})
         d[r["counter"]] = d.get(r["counter"], 0.0) + float(r["sum"])
         if r["counter"] == "SQ_INSTS_VALU":

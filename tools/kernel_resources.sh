@@ -17,9 +17,9 @@ for ln in sys.stdin:
 def dem(n):
     try: return subprocess.run(["c++filt", n], capture_output=True, text=True).stdout.strip().split("(")[0].replace("(anonymous namespace)::", "")
     except Exception: return n
-print("%-34s %5s %5s %5s %8s %8s %8s %6s %5s" % ("kernel", "VGPR", "AGPR", "SGPR", "v-spill", "s-spill", "scratch", "LDS", "occ"))
+print("%-44s %5s %5s %5s %8s %8s %8s %6s %5s" % ("kernel", "VGPR", "AGPR", "SGPR", "v-spill", "s-spill", "scratch", "LDS", "occ"))
 for r in rows:
-    print("%-34s %5s %5s %5s %8s %8s %8s %6s %5s" % (dem(r["name"])[:34], r.get("VGPRs"), r.get("AGPRs"), r.get("TotalSGPRs"), r.get("VGPRs Spill"), r.get("SGPRs Spill"),
+    print("%-44s %5s %5s %5s %8s %8s %8s %6s %5s" % (dem(r["name"]).replace("void ", "")[:44], r.get("VGPRs"), r.get("AGPRs"), r.get("TotalSGPRs"), r.get("VGPRs Spill"), r.get("SGPRs Spill"),
           r.get("ScratchSize [bytes/lane]"), r.get("LDS Size [bytes/block]"), r.get("Occupancy [waves/SIMD]")))
 print("\nocc = waves per SIMD the register budget allows (VGPR + AGPR share one 512-entry file per lane); LDS is the static part only (K1 adds dynamic LDS: 18.3 KB at d = 2)")
 '
