@@ -726,7 +726,7 @@ static int enqueue_front_impl(wmbus_ctx *c, size_t nbytes)
         const uint32_t T = c->T, ntiles = (g.M + T - 1) / T;
         c->ntiles = ntiles;
         c->k1a = K1Args{g, c->d_dphi, c->d_rssi, c->d_lut, c->d_lut + 32 * WM_MAX_DECIM, c->d_ema_head, c->d_ema_tail, ntiles, c->d_scalars + SC_ERR,
-                        nullptr, ema_carry(c, false), nullptr, 0u};
+                        nullptr, ema_carry(c, false), nullptr};
         static const int turns = getenv("WMBUS_K1_TURNS") ? atoi(getenv("WMBUS_K1_TURNS")) : 1;      /* 0: no order (A/B) */
         int rc;
         {
@@ -737,12 +737,6 @@ static int enqueue_front_impl(wmbus_ctx *c, size_t nbytes)
                 if (kc.last && kc.owner != c) HIPCHK(c, hipStreamWaitEvent(c->stream, kc.last, 0));
             }
             HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-            static const uint32_t k1_grid = getenv("WMBUS_K1_GRID") ? (uint32_t)atoi(getenv("WMBUS_K1_GRID")) : 0u;   /* tuning aid: bounded first-pass grid */
-            if (k1_grid && (uint64_t)ntiles * c->S > k1_grid && c->cfg.prefilter != WMBUS_PREFILTER_POLYPHASE) {
-                K1Args k1 = c->k1a;
-                k1.n_items = ntiles * c->S;
-                rc = launch_k1_any(c, k1, dim3(k1_grid, 1));
-            } else
             rc = launch_k1_any(c, c->k1a, dim3(ntiles, c->S));
             if (rc) return rc;
             HIPCHK(c, hipEventRecord(c->ev[4], c->stream));

@@ -41,7 +41,6 @@ struct K1Args {
     const uint32_t *relist;
     const float *ema_carry;  /* [2][S] exact EMA carried in from the previous push */
     const uint32_t *n_relist;/* repair launches: entries in `relist` (on the device: k1_collect has just written it) */
-    uint32_t n_items;        /* first pass with a bounded grid: blocks walk items (stream * ntiles + tile) [0, n_items); 0: grid = (tiles, streams) */
 };
 
 /* =============================================================================================
@@ -407,19 +406,13 @@ __device__ __forceinline__ void k1_tile(const K1Args &a, const int tile, const i
 }
 
 template <int D, bool SHIFT, bool GEN = true, bool FAST = false>
-__global__ __launch_bounds__(256, GEN ? 1 : 8) void k1_demod2(K1Args a)          /* first pass: 64 VGPRs, eight waves fill a SIMD (the tile loop of the bounded grid would otherwise hoist its way to 95) */
+__global__ __launch_bounds__(256, GEN ? 1 : 8) void k1_demod2(K1Args a)          /* first pass: at most 64 VGPRs -- eight waves fill a SIMD's register file exactly */
 {
-    if (!GEN || a.relist == nullptr) {
-        if (a.n_items == 0u) { k1_tile<D, SHIFT, GEN, FAST>(a, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x); return; }
-        /* bounded grid: a block walks tiles (no barrier between two tiles is needed: a tile's last LDS reads, sFin, are
-         * three barriers ahead of the next tile's writes to that array, and its staging area is dead after stage B's first) */
-        for (uint32_t i = blockIdx.x; i < a.n_items; i += gridDim.x) {
-            int tid = (int)threadIdx.x;
-            asm volatile("" : "+v"(tid));                      /* per-thread addresses are recomputed per tile, not kept in registers across the loop */
-            k1_tile<D, SHIFT, GEN, FAST>(a, (int)(i % a.ntiles), (int)(i / a.ntiles), tid);
-        }
-        return;
-    }
+    /* One tile per block.  (A bounded grid whose blocks walk several tiles made the kernel itself 6 % faster -- fewer block
+     * launches, per-thread addresses kept across tiles -- and the whole job 10 % slower: the framer kernels of the other
+     * contexts get onto a CU when demodulation blocks retire, and blocks that live twice as long halve their chances; r03
+     * A/B in DESIGN.md section 10.) */
+    if (!GEN || a.relist == nullptr) { k1_tile<D, SHIFT, GEN, FAST>(a, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x); return; }
     /* repair launch: a fixed grid walks the list k1_collect has just written (no host round trip in between) */
     const uint32_t n = *a.n_relist;
     for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {

@@ -40,3 +40,20 @@ def samples():
         "samples2": np.fromfile(os.path.join(SAMPLES, "rtlsdr_868.950M_1M6_samples2.cu8"), np.uint8),
         "issue48": np.fromfile(os.path.join(SAMPLES, "rtlsdr_868.625M_2M4_issue48.cu8"), np.uint8),
     }
+
+
+@pytest.fixture(scope="session")
+def libm_is_glibc_235():
+    """True when this host's atan2f gives glibc 2.35's answers (tests/golden/atan2f_kat.bin, made by make_atan2f_kat.py).
+    The exact path restates that generation; the oracle and the reference call the host's libm.  Where they differ the
+    REFERENCE prints other soft symbols, and comparisons against the host's libm / the oracle's taps say nothing about
+    the kernels: such tests skip with this reason instead of failing."""
+    import ctypes
+    import numpy as np
+    kat = np.fromfile(os.path.join(GOLDEN, "atan2f_kat.bin"), "<u4").reshape(-1, 3)
+    libm = ctypes.CDLL("libm.so.6")
+    libm.atan2f.restype = ctypes.c_float
+    libm.atan2f.argtypes = [ctypes.c_float, ctypes.c_float]
+    y, x = kat[:, 0].copy().view(np.float32), kat[:, 1].copy().view(np.float32)
+    got = np.array([libm.atan2f(float(a), float(b)) for a, b in zip(y[::8], x[::8])], np.float32).view(np.uint32)
+    return bool(np.array_equal(got, kat[::8, 2]))

@@ -2,6 +2,8 @@
 import os
 import subprocess
 
+import pytest
+
 from conftest import ROOT
 
 
@@ -9,6 +11,8 @@ def test_atan2f_restatement_matches_libm(tmp_path):
     exe = str(tmp_path / "exact_math_check")
     subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-o", exe, os.path.join(ROOT, "tests", "exact_math_check.c"), "-lm"],
                    check=True)
-    p = subprocess.run([exe, "20000000"], capture_output=True, text=True)
+    p = subprocess.run([exe, "20000000", os.path.join(ROOT, "tests", "golden", "atan2f_kat.bin")], capture_output=True, text=True)
+    if p.returncode == 77:      # wm_exact.h reproduced glibc 2.35's known answers, this host's libm did not
+        pytest.skip("host libm's atan2f is not the glibc 2.35 generation the exact path restates: " + p.stdout.strip().splitlines()[-1])
     assert p.returncode == 0, p.stdout
-    assert " 0 mismatches" in p.stdout
+    assert " 0 mismatches" in p.stdout and "host libm differs on 0" in p.stdout

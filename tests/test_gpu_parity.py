@@ -39,7 +39,7 @@ def compare_chips(rx, ref, stream=0, chains=(0, 1), algos=(0, 1)):
             assert np.array_equal(pos, oc["sample"])
 
 
-def test_device_arithmetic_is_ieee_and_glibc_exact(wm, oracle):
+def test_device_arithmetic_is_ieee_and_glibc_exact(wm, oracle, libm_is_glibc_235):
     """The kernels' scalar arithmetic (wm_exact.h) on the device against this host's IEEE / glibc:
       * square root: EXHAUSTIVE over the RSSI operand domain, every integer in [0, 2^24) (the
         kernels take the root of the unscaled integer sums i^2 + q^2) plus the k/64, k/256 forms;
@@ -57,6 +57,10 @@ def test_device_arithmetic_is_ieee_and_glibc_exact(wm, oracle):
     def host2(fn, x, y):
         out = np.empty_like(x); fn(x.ctypes.data_as(fp), y.ctypes.data_as(fp), out.ctypes.data_as(fp), x.size); return out
 
+    # ---- glibc 2.35's known answers first: the device must reproduce them whatever libm this host has
+    kat = np.fromfile(os.path.join(GOLDEN, "atan2f_kat.bin"), "<u4").reshape(-1, 3)
+    r = wm.selftest_math(kat[:, 0].copy().view(np.float32), kat[:, 1].copy().view(np.float32))
+    assert np.array_equal(r["atan2"].view(np.uint32), kat[:, 2]), "device atan2f against glibc 2.35's known answers"
     rng = np.random.default_rng(11)
     # ---- sqrt, exhaustive on the integer domain, in 4 slabs of 2^22
     for slab in range(4):
@@ -83,6 +87,8 @@ def test_device_arithmetic_is_ieee_and_glibc_exact(wm, oracle):
         nz = re != 0
         want = host2(L.wmo_ieee_div, im, np.where(nz, re, np.float32(1)))
         assert np.array_equal(r["div"][nz].view(np.uint32), want[nz].view(np.uint32)), f"divide round {rnd}"
+        if not libm_is_glibc_235:
+            continue                                              # this host's libm is another generation: nothing to compare the arctangent with
         want = host2(L.wmo_libm_atan2f, im, re)
         assert np.array_equal(r["atan2"].view(np.uint32), want.view(np.uint32)), f"atan2f round {rnd}"
         # range-reduced operands of the second division: t in [7/16, 39/16) -> (2t-1)/(2+t), (t-1)/(t+1), (t-1.5)/(1+1.5t); -1/t
@@ -102,6 +108,9 @@ def test_device_arithmetic_is_ieee_and_glibc_exact(wm, oracle):
     yy, xx = np.meshgrid(z, z)
     yy = np.ascontiguousarray(yy.ravel()); xx = np.ascontiguousarray(xx.ravel())
     r = wm.selftest_math(yy, xx)
+    if not libm_is_glibc_235:
+        pytest.skip("device arithmetic reproduces glibc 2.35's known answers; this host's libm is another generation (the reference itself "
+                    "would print other soft symbols here), so the libm comparisons were left out")
     assert np.array_equal(r["atan2"].view(np.uint32), host2(L.wmo_libm_atan2f, yy, xx).view(np.uint32))
 
 
