@@ -25,7 +25,10 @@ The JSON line also carries
 """
 import os
 
-# (GPU_MAX_HW_QUEUES: libwmbus_hip.so sets its own default of 16 when it is loaded; nothing to do here any more.)
+# GPU_MAX_HW_QUEUES: libwmbus_hip.so sets its own default (16) when it is loaded -- but in a multi-rank run torch
+# initialises the HIP runtime first (shard.init: torch.cuda.set_device for RCCL), and the runtime reads the variable only
+# once.  So the same default is put in place here, before anything can have started HIP.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import argparse
 import collections
