@@ -165,10 +165,10 @@ def main():
                               "host_threads_per_context": shard.host_threads_per_context(world, nctx)}), flush=True)
         shard.destroy(group)
         return 0
-    local = int(os.environ.get("WMBUS_BENCH_DEVICE", local))
     wm = importlib.import_module("rtl-wmbus_amd")
     if wm.device_count() < 1:
         raise SystemExit("bench.py: no HIP device (the back end has no CPU fallback)")
+    local = int(os.environ.get("WMBUS_BENCH_DEVICE", local % wm.device_count()))   # a launcher may narrow the visible devices per rank
     push_bytes = 2 * n
 
     # ---- synthetic captures (host, multi-threaded), then resident in HBM -------------------------

@@ -142,8 +142,9 @@ def init(world, local_rank, backend=None, rank=None):
             if dist.is_initialized():
                 dist.destroy_process_group()
             if b == "nccl":
-                torch.cuda.set_device(local_rank)
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=120))
+                dev = local_rank % max(1, torch.cuda.device_count())     # a launcher may narrow the visible devices per rank
+                torch.cuda.set_device(dev)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", dev), timeout=datetime.timedelta(seconds=120))
                 t = torch.ones(1, device="cuda")
                 dist.all_reduce(t)                           # RCCL builds its rings lazily: fail here, not inside the timed region
                 torch.cuda.synchronize()
