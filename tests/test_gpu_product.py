@@ -183,3 +183,33 @@ def test_tolerance_mode_keeps_the_bundled_datagrams_and_states_its_tolerance(wm,
     env = dict(os.environ, WMBUS_FIXED_TS="1")
     p = subprocess.run([wm.CLI_PATH, "-F"] + flags, input=cu8.tobytes(), capture_output=True, env=env)
     assert p.returncode == 0 and p.stdout.decode() == ref["text"]
+
+
+def test_rccl_group_works_next_to_the_hip_library(wm):
+    """The process group bench.py uses for N > 1 (shard.init, backend nccl = RCCL) with ONE rank on this box, next to
+    contexts of libwmbus_hip.so in the same process: barrier, max / sum reductions and the object gather all run, and a
+    receiver opened afterwards still works (torch and the library share the HIP runtime).  The 8-rank run is the
+    driver's; the transport's first contact with this process layout should not be there."""
+    import importlib
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = (
+        "import os, sys, importlib\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT='29547')\n"
+        "shard = importlib.import_module('rtl-wmbus_amd.shard')\n"
+        "g = shard.init(1, 0, backend='nccl', force=True)\n"
+        "assert g.backend == 'nccl', g.backend\n"
+        "shard.barrier(g)\n"
+        "assert shard.max_over_ranks(g, 2.5) == 2.5 and shard.sum_over_ranks(g, 7) == 7 and shard.gather(g, [1, 2]) == [[1, 2]]\n"
+        "wm = importlib.import_module('rtl-wmbus_amd')\n"
+        "cu8 = wm.synth_capture(seed=5, n_samples=1 << 17, kinds=7, frames_per_s=100.0)[0]\n"
+        "with wm.Receiver(n_streams=1, max_push_bytes=cu8.size) as rx:\n"
+        "    n = len(rx.run(cu8)[0].splitlines())\n"
+        "shard.barrier(g); shard.destroy(g)\n"
+        "print('OK', n)\n")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    ok = [ln for ln in p.stdout.splitlines() if ln.startswith("OK ")]
+    assert p.returncode == 0 and ok, p.stderr[-2000:]
+    assert int(ok[0].split()[1]) > 0
