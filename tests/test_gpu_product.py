@@ -213,3 +213,21 @@ def test_rccl_group_works_next_to_the_hip_library(wm):
     ok = [ln for ln in p.stdout.splitlines() if ln.startswith("OK ")]
     assert p.returncode == 0 and ok, p.stderr[-2000:]
     assert int(ok[0].split()[1]) > 0
+
+
+def test_tolerance_mode_over_the_synthetic_goldens(wm):
+    """Tolerance mode on every synthetic golden of the reference binary (tests/golden/synthetic.json; the switch
+    combinations that do not run the default switches' kernel simply stay exact): the weak-signal and the all-modes cases
+    are where a decision could hang on the last bits of a soft symbol.  The claim in DESIGN.md section 12 is "no line
+    differs on these either"; a difference here is a finding about the mode, to be written down, not hidden."""
+    from cases import SYNTH_CASES, flags_to_kwargs, synth_case_capture
+    synth = json.load(open(os.path.join(GOLDEN, "synthetic.json")))
+    differing = {}
+    for case in SYNTH_CASES:
+        cu8 = synth_case_capture(wm, case)[0]
+        with wm.Receiver(n_streams=1, max_push_bytes=cu8.size // 4096 * 4096, tolerance_mode=1, keep_taps=False, **flags_to_kwargs(case["flags"])) as rx:
+            text = rx.run(cu8)[0]
+        if text != synth[case["id"]]:
+            a, b = set(text.splitlines()), set(synth[case["id"]].splitlines())
+            differing[case["id"]] = len(a ^ b)
+    assert differing == {}, differing
