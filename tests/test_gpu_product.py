@@ -231,3 +231,31 @@ def test_tolerance_mode_over_the_synthetic_goldens(wm):
             a, b = set(text.splitlines()), set(synth[case["id"]].splitlines())
             differing[case["id"]] = len(a ^ b)
     assert differing == {}, differing
+
+
+def test_batch_api_argument_errors_and_odd_splits(wm, oracle):
+    """Error behaviour of wmbus_batch_* (messages through wmbus_batch_last_error, nothing left half-open) and batches that do
+    not split into whole 64-capture groups."""
+    with pytest.raises(wm.WmbusError, match="n_streams"):
+        wm.Batch(n_streams=0)
+    with wm.Batch(n_streams=130, max_push_bytes=1 << 18) as b:           # two contexts of 65: not whole waves, lane-private loads
+        assert [c[2] for c in b.contexts] == [65, 65]
+        with pytest.raises(wm.WmbusError, match="input_windows"):
+            b.run_from(lambda first, n, slab: 0)                           # a host source needs the second input window
+        with pytest.raises(wm.WmbusError, match="resident_bytes"):
+            b.run_resident(4096 * 3 + 1, 1)
+        caps = [wm.synth_capture(seed=8800 + i, n_samples=1 << 17, kinds=15, frames_per_s=150.0)[0] for i in range(130)]
+        for s, c in enumerate(caps):
+            b.stage(s, c)
+        text = [""] * 130
+        def on_push(first, n, lines, tm):
+            for ln in lines:
+                text[ln["stream"]] += ln["text"]
+        st = b.run_resident(1 << 18, 1, on_push)
+        assert st["pushes"] == 2 and st["samples"] == 130 << 17
+        assert text == oracle.run_many(caps, flags_to_oracle_opts(oracle, ["-v"]), threads=16)
+    with wm.Batch(n_streams=64, max_push_bytes=1 << 16, input_windows=2) as b:
+        with pytest.raises(wm.WmbusError, match="multiple of 4096"):
+            b.run_from(lambda first, n, slab: 4097)                        # a source that returns a ragged byte count
+        st = b.run_from(lambda first, n, slab: 0)                          # an empty source is not an error
+        assert st["pushes"] == 0 and st["samples"] == 0
