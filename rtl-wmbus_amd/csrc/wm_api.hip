@@ -468,6 +468,10 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
                                  : (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1u << 20, dec_total / 8), 1u << 29);
     c->pkts_cap = c->hdr_cap;
     c->bytes_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1u << 20, dec_total / 64), 1u << 30);
+    if (const char *caps = getenv("WMBUS_DEBUG_BURST_CAPS")) {     /* tests: "hdr:words:pkts:bytes" -- tiny burst storage, to reach the overflow paths */
+        unsigned v[4] = {c->hdr_cap, c->words_cap, c->pkts_cap, c->bytes_cap};
+        if (sscanf(caps, "%u:%u:%u:%u", &v[0], &v[1], &v[2], &v[3]) == 4) { c->hdr_cap = v[0]; c->words_cap = v[1]; c->pkts_cap = v[2]; c->bytes_cap = v[3]; }
+    }
     A(dalloc(&c->d_hits, (size_t)c->hits_cap));
     A(dalloc(&c->d_pending, (size_t)4 * c->S));
     A(hipHostMalloc((void **)&c->h_scalars, SC_COUNT * sizeof(uint32_t)));

@@ -259,3 +259,38 @@ def test_batch_api_argument_errors_and_odd_splits(wm, oracle):
             b.run_from(lambda first, n, slab: 4097)                        # a source that returns a ragged byte count
         st = b.run_from(lambda first, n, slab: 0)                          # an empty source is not an error
         assert st["pushes"] == 0 and st["samples"] == 0
+
+
+@pytest.mark.parametrize("caps", ["65536:300:65536:1048576", "65536:1048576:6:1048576", "65536:1048576:65536:200", "3:1048576:65536:1048576"],
+                         ids=["words", "pkts", "bytes", "hdr"])
+def test_exhausted_burst_storage_is_a_warning_and_never_hands_out_garbage(wm, oracle, caps):
+    """with burst storage exhausted the K3 counters used to run ahead of what had been written, and the
+    host walked unwritten slots of pinned memory.  Storage is now taken BEFORE a slot, a dropped continuation aborts its
+    decoder, and the push succeeds with WMBUS_WARN_BURSTS_DROPPED: every line that still comes out is one of the oracle's
+    (same text), none is invented, the stream goes on, and with the pressure gone (second receiver, default storage) the
+    same bytes decode completely."""
+    cu8 = wm.synth_capture(seed=4242, n_samples=1 << 20, kinds=15, frames_per_s=150.0)[0]
+    want = oracle.run(cu8, flags_to_oracle_opts(oracle, ["-v"]))["text"].splitlines()
+    code = (
+        "import sys, importlib, json, numpy as np\n"
+        f"sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})\n"
+        "wm = importlib.import_module('rtl-wmbus_amd')\n"
+        "cu8 = wm.synth_capture(seed=4242, n_samples=1 << 20, kinds=15, frames_per_s=150.0)[0]\n"
+        "out, warn = [], 0\n"
+        "with wm.Receiver(n_streams=1, max_push_bytes=1 << 18) as rx:\n"
+        "    for off in range(0, cu8.size, 1 << 18):\n"
+        "        out.append(rx.push([cu8[off:off + (1 << 18)]]))\n"
+        "        warn |= rx.timing()['warnings']\n"
+        "print('RESULT ' + json.dumps({'text': ''.join(out), 'warn': warn}))\n")
+    import sys
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, WMBUS_DEBUG_BURST_CAPS=caps))
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][0][7:])
+    got = r["text"].splitlines()
+    assert r["warn"] & 2                                      # WMBUS_WARN_BURSTS_DROPPED
+    assert 0 < len(got) < len(want)
+    it = iter(want)
+    assert all(any(g == w for w in it) for g in got), "a line that the reference does not print, or out of order"
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][0][7:])
+    assert r["warn"] == 0 and r["text"].splitlines() == want
