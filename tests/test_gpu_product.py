@@ -119,6 +119,7 @@ def test_cli_live_stream_latency_is_bounded_by_L_not_by_the_push_size(wm, sample
     assert p.wait() == 0, p.stderr.read()
     assert (b"".join(got) + rest).decode() == BUNDLED[f"{S2_NAME}|-v"] and rest == b""
     lat = [t - sent[min(b // piece, len(sent) - 1)] for t, b in zip(t_line, done_at_byte)]
+    print("latency of the lines (s):", [round(x, 4) for x in lat])
     assert max(lat) < 0.040 + 0.150, lat                                  # 1 MiB pushes alone would make this up to 0.33 s, 4 MiB 0.65 s
     assert t_line[0] < sent[-1] - 0.1                                     # the first telegram is out long before the stream ends
 
