@@ -133,12 +133,14 @@ int wmbus_batch_open(const wmbus_cfg *cfg, unsigned contexts, wmbus_batch **out)
      * twelve contexts cover it better than eight: 167 against 162 Gsamples/s) */
     unsigned nctx = contexts ? contexts : std::min(cfg->tolerance_mode ? 12u : 8u, std::max(1u, S / 64u));
     nctx = std::max(1u, std::min(nctx, S));
-    const unsigned gran = (S % 64u == 0u && S / 64u >= nctx) ? 64u : 1u, units = S / gran;
+    /* whole groups of 64 wherever the batch has that many captures per context; a remainder (S not a multiple of 64) rides
+     * with the last context, which alone then takes the clock kernel's lane-private load path */
+    const unsigned gran = S / 64u >= nctx ? 64u : 1u, units = S / gran, rest = S - units * gran;
     unsigned hw = std::thread::hardware_concurrency();
     if (hw == 0) hw = 16;
     unsigned at = 0;
     for (unsigned i = 0; i < nctx; i++) {
-        const unsigned n = gran * (units / nctx + (i < units % nctx ? 1u : 0u));
+        const unsigned n = gran * (units / nctx + (i < units % nctx ? 1u : 0u)) + (i + 1 == nctx ? rest : 0u);
         wmbus_cfg cc = *cfg;
         cc.n_streams = n;
         /* host decoder threads: the contexts decode at different times, so the box is shared 2 x oversubscribed */

@@ -239,8 +239,8 @@ def test_batch_api_argument_errors_and_odd_splits(wm, oracle):
     not split into whole 64-capture groups."""
     with pytest.raises(wm.WmbusError, match="n_streams"):
         wm.Batch(n_streams=0)
-    with wm.Batch(n_streams=130, max_push_bytes=1 << 18) as b:           # two contexts of 65: not whole waves, lane-private loads
-        assert [c[2] for c in b.contexts] == [65, 65]
+    with wm.Batch(n_streams=130, max_push_bytes=1 << 18) as b:           # a whole group of 64 + one context with the remainder (lane-private loads)
+        assert [c[2] for c in b.contexts] == [64, 66]
         with pytest.raises(wm.WmbusError, match="input_windows"):
             b.run_from(lambda first, n, slab: 0)                           # a host source needs the second input window
         with pytest.raises(wm.WmbusError, match="resident_bytes"):
