@@ -189,6 +189,13 @@ static int run_sharded(wmbus_cfg cfg, int n, char **names, const int *devs, int 
 {
     struct batch_job *jobs = calloc((size_t)n_devs, sizeof *jobs);
     pthread_t *th = calloc((size_t)n_devs, sizeof *th);
+    /* host decoder threads per context: devices x contexts (8 per batch) x threads within the host's hardware threads */
+    long cpus = sysconf(_SC_NPROCESSORS_ONLN);
+    if (cpus < 1) cpus = 16;
+    unsigned per_ctx = (unsigned)(cpus / (8L * n_devs));
+    if (per_ctx < 1) per_ctx = 1;
+    if (per_ctx > 16) per_ctx = 16;
+    if (cfg.host_threads == 0 && n_devs > 1) cfg.host_threads = per_ctx;
     for (int k = 0; k < n_devs; k++) { jobs[k].cfg = cfg; jobs[k].cfg.device = devs[k]; jobs[k].names = calloc((size_t)n, sizeof(char *)); jobs[k].stats = stats; }
     for (int i = 0; i < n; i++) {
         const int k = shard_slot(i, n_devs);
