@@ -70,6 +70,7 @@ def parse():
     ap.add_argument("--host-threads", type=int, default=0, help="packet-decoder threads per context (0: cores / (ranks x contexts), at most 32)")
     ap.add_argument("--tolerance-mode", action="store_true", help="informational: wmbus_cfg.tolerance_mode = 1 (soft symbols within 2e-6, not bit-identical); never the headline value")
     ap.add_argument("--no-tolerance-leg", action="store_true", help="skip the informational tolerance-mode leg behind the main measurement")
+    ap.add_argument("--seed-offset", type=int, default=0, help="other synthetic captures than the headline batch (capture s gets seed 0xC0FFEE + offset + s); evidence runs only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     return ap.parse_args()
@@ -176,7 +177,7 @@ def main():
     caps = [None] * S
 
     def gen(s):
-        caps[s] = wm.synth_capture(seed=shard.capture_seed(rank, S, s), n_samples=n, kinds=wm.T1 | wm.C1A | wm.C1B,
+        caps[s] = wm.synth_capture(seed=shard.capture_seed(rank, S, s) + a.seed_offset, n_samples=n, kinds=wm.T1 | wm.C1A | wm.C1B,
                                    frames_per_s=20.0)[0]
 
     with cf.ThreadPoolExecutor(min(os.cpu_count() or 1, 64)) as ex:
