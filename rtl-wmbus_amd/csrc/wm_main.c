@@ -21,7 +21,6 @@
 #include <arpa/inet.h>
 #include <netdb.h>
 #include <pthread.h>
-#include <signal.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -117,7 +116,7 @@ static size_t batch_fill_padded(void *user, unsigned first, unsigned n, uint8_t 
     struct batch_job *j = user;
     size_t most = 0;
     size_t *got = calloc(n, sizeof *got);
-    if (!got) return 0;
+    if (!got) { fprintf(stderr, "rtl_wmbus_hip: out of memory\n"); return 0; }
     for (unsigned k = 0; k < n; k++) {
         const unsigned s = first + k;
         if (j->live[s]) {
