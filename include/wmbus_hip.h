@@ -217,6 +217,9 @@ typedef struct wmbus_batch_stats {
 /* cfg->n_streams = all captures of the batch; contexts = 0: the default split.  On failure *out still holds an
  * object whose wmbus_batch_last_error() explains; close it. */
 int  wmbus_batch_open(const wmbus_cfg *cfg, unsigned contexts, wmbus_batch **out);
+/* The split wmbus_batch_open would make, without opening anything (no device needed): returns the number of contexts and
+ * writes the captures of each into counts[0 .. min(contexts, cap)). */
+unsigned wmbus_batch_plan(const wmbus_cfg *cfg, unsigned contexts, unsigned *counts, unsigned cap);
 void wmbus_batch_close(wmbus_batch *b);
 const char *wmbus_batch_last_error(const wmbus_batch *b);
 unsigned wmbus_batch_contexts(const wmbus_batch *b);

@@ -81,7 +81,7 @@ class BatchStats(ctypes.Structure):
                 ("warnings", ctypes.c_uint)]
 
 
-EXPORTS = ["wmbus_batch_open", "wmbus_batch_close", "wmbus_batch_last_error", "wmbus_batch_contexts", "wmbus_batch_context", "wmbus_batch_stage",
+EXPORTS = ["wmbus_batch_plan", "wmbus_batch_open", "wmbus_batch_close", "wmbus_batch_last_error", "wmbus_batch_contexts", "wmbus_batch_context", "wmbus_batch_stage",
            "wmbus_batch_device_input", "wmbus_batch_run",
            "wmbus_default_cfg", "wmbus_open", "wmbus_close", "wmbus_last_error", "wmbus_stage", "wmbus_device_input",
            "wmbus_process", "wmbus_collect", "wmbus_lines", "wmbus_lines_text", "wmbus_get_timing", "wmbus_read_tap",
@@ -116,6 +116,7 @@ def lib():
         L.wmbus_free_pinned.argtypes = [vp]
         L.wmbus_selftest_math.argtypes = [ctypes.c_int] + [vp] * 6 + [sz]
         L.wmbus_batch_open.argtypes = [ctypes.POINTER(Cfg), u, ctypes.POINTER(vp)]
+        L.wmbus_batch_plan.argtypes = [ctypes.POINTER(Cfg), u, ctypes.POINTER(u), u]; L.wmbus_batch_plan.restype = u
         L.wmbus_batch_close.argtypes = [vp]
         L.wmbus_batch_last_error.argtypes = [vp]; L.wmbus_batch_last_error.restype = ctypes.c_char_p
         L.wmbus_batch_contexts.argtypes = [vp]; L.wmbus_batch_contexts.restype = u
@@ -170,6 +171,14 @@ def _make_cfg(n_streams=1, max_push_bytes=4 << 20, decimation=2, simultaneous=Fa
     c.keep_taps, c.prefilter, c.atan_mode, c.spill_words, c.input_windows = int(keep_taps), prefilter, atan_mode, spill_words, input_windows
     c.dedup_twins, c.only_crc_ok, c.tolerance_mode = int(dedup_twins), int(only_crc_ok), int(tolerance_mode)
     return c
+
+
+def batch_plan(n_streams, contexts=0, tolerance_mode=0):
+    """Captures per context of a wmbus_batch of `n_streams` (no device needed)."""
+    c = _make_cfg(n_streams=n_streams, tolerance_mode=tolerance_mode)
+    out = (ctypes.c_uint * max(1, n_streams))()
+    n = lib().wmbus_batch_plan(ctypes.byref(c), contexts, out, max(1, n_streams))
+    return [int(out[i]) for i in range(n)]
 
 
 class Batch:

@@ -117,6 +117,26 @@ void wmbus_batch_close(wmbus_batch *b)
     delete b;
 }
 
+/* How a batch is split (no device needed): the number of contexts and, if `counts` is given, the captures of each. */
+unsigned wmbus_batch_plan(const wmbus_cfg *cfg, unsigned contexts, unsigned *counts, unsigned cap)
+{
+    if (!cfg || cfg->n_streams < 1) return 0;
+    const unsigned S = cfg->n_streams;
+    /* Contexts of whole 64-capture waves where the batch allows it (the clock kernel's cooperative loads need that); by
+     * default 8 of them, at most one per 64 captures: 8 x 128 for the 1024 captures of the headline configuration
+     * (4 / 6 / 10 / 12 / 16 contexts measured 96 / 111 / 141 / 120 / 117 against 144 Gsamples/s with 8).
+     * (tolerance mode: the demodulation kernel is a third shorter, the framers' share of a context's chain larger, and
+     * twelve contexts cover it better than eight: 167 against 162 Gsamples/s) */
+    unsigned nctx = contexts ? contexts : std::min(cfg->tolerance_mode ? 12u : 8u, std::max(1u, S / 64u));
+    nctx = std::max(1u, std::min(nctx, S));
+    /* whole groups of 64 wherever the batch has that many captures per context; a remainder (S not a multiple of 64) rides
+     * with the last context, which alone then takes the clock kernel's lane-private load path */
+    const unsigned gran = S / 64u >= nctx ? 64u : 1u, units = S / gran, rest = S - units * gran;
+    for (unsigned i = 0; i < nctx && counts && i < cap; i++)
+        counts[i] = gran * (units / nctx + (i < units % nctx ? 1u : 0u)) + (i + 1 == nctx ? rest : 0u);
+    return nctx;
+}
+
 int wmbus_batch_open(const wmbus_cfg *cfg, unsigned contexts, wmbus_batch **out)
 {
     if (!cfg || !out) return WMBUS_EINVAL;
@@ -126,21 +146,13 @@ int wmbus_batch_open(const wmbus_cfg *cfg, unsigned contexts, wmbus_batch **out)
     *out = b;                                               /* the caller reads the message, then closes */
     const unsigned S = cfg->n_streams;
     if (S < 1) return batch_fail(b, WMBUS_EINVAL, "batch: n_streams must be >= 1");
-    /* Contexts of whole 64-capture waves where the batch allows it (the clock kernel's cooperative loads need that); by
-     * default 8 of them, at most one per 64 captures: 8 x 128 for the 1024 captures of the headline configuration
-     * (4 / 6 / 10 / 12 / 16 contexts measured 96 / 111 / 141 / 120 / 117 against 144 Gsamples/s with 8). */
-    /* (tolerance mode: the demodulation kernel is a third shorter, the framers' share of a context's chain larger, and
-     * twelve contexts cover it better than eight: 167 against 162 Gsamples/s) */
-    unsigned nctx = contexts ? contexts : std::min(cfg->tolerance_mode ? 12u : 8u, std::max(1u, S / 64u));
-    nctx = std::max(1u, std::min(nctx, S));
-    /* whole groups of 64 wherever the batch has that many captures per context; a remainder (S not a multiple of 64) rides
-     * with the last context, which alone then takes the clock kernel's lane-private load path */
-    const unsigned gran = S / 64u >= nctx ? 64u : 1u, units = S / gran, rest = S - units * gran;
+    std::vector<unsigned> plan(S);
+    const unsigned nctx = wmbus_batch_plan(cfg, contexts, plan.data(), S);
     unsigned hw = std::thread::hardware_concurrency();
     if (hw == 0) hw = 16;
     unsigned at = 0;
     for (unsigned i = 0; i < nctx; i++) {
-        const unsigned n = gran * (units / nctx + (i < units % nctx ? 1u : 0u)) + (i + 1 == nctx ? rest : 0u);
+        const unsigned n = plan[i];
         wmbus_cfg cc = *cfg;
         cc.n_streams = n;
         /* host decoder threads: the contexts decode at different times, so the box is shared 2 x oversubscribed */

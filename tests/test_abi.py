@@ -68,3 +68,20 @@ def test_synth_is_deterministic(wm):
     b, fb = wm.synth_capture(seed=1234, n_samples=1 << 16, kinds=15, frames_per_s=200.0)
     c, _ = wm.synth_capture(seed=1235, n_samples=1 << 16, kinds=15, frames_per_s=200.0)
     assert np.array_equal(a, b) and fa == fb and not np.array_equal(a, c)
+
+
+def test_batch_plan_splits_into_whole_groups_of_64(wm):
+    """wmbus_batch_plan (no device needed): whole 64-capture groups per context where the batch has them, the remainder
+    with the last context, 8 contexts by default (12 in tolerance mode), never an empty context."""
+    assert wm.batch_plan(1024) == [128] * 8
+    assert wm.batch_plan(1024, tolerance_mode=1) == [128] * 4 + [64] * 8
+    assert wm.batch_plan(320) == [64] * 5
+    assert wm.batch_plan(130) == [64, 66]
+    assert wm.batch_plan(1500) == [192] * 7 + [156]
+    assert wm.batch_plan(63) == [63] and wm.batch_plan(1) == [1]
+    assert wm.batch_plan(1024, contexts=3) == [384, 320, 320]
+    assert wm.batch_plan(5, contexts=8) == [1] * 5
+    for s in range(1, 700, 7):
+        for c in (0, 1, 2, 5, 8, 13):
+            p = wm.batch_plan(s, contexts=c)
+            assert sum(p) == s and min(p) >= 1 and (c == 0 or len(p) == min(c, s))
