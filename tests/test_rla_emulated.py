@@ -22,7 +22,8 @@ F_T1C1, F_S1 = 8, 16                                     # WM_F_* of wm_dev.h
 def emu():
     deps = [SRC] + [os.path.join(CSRC, f) for f in ("wm_k2_rla.h", "wm_k2_common.h", "wm_dev.h")]
     if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
-        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I" + CSRC, "-Wno-unknown-pragmas", "-o", SO, SRC], check=True)
+        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I" + CSRC, "-Wno-unknown-pragmas"] + os.environ.get("WMBUS_EMU_CFLAGS", "").split() +
+                       ["-o", SO, SRC], check=True)
     L = ctypes.CDLL(SO)
     L.wm_emu_rla.restype = ctypes.c_long
     L.wm_emu_rla.argtypes = [ctypes.c_void_p] + [ctypes.c_uint] * 7 + [ctypes.c_void_p] * 4
