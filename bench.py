@@ -72,6 +72,8 @@ def parse():
     ap.add_argument("--no-tolerance-leg", action="store_true", help="skip the informational tolerance-mode leg behind the main measurement")
     ap.add_argument("--seed-offset", type=int, default=0, help="other synthetic captures than the headline batch (capture s gets seed 0xC0FFEE + offset + s); evidence runs only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="skip the informational legs behind the main measurement (configs[1] / configs[2], the CLI's own rate)")
+    ap.add_argument("--quick", action="store_true", help="A/B runs: --no-check --no-cpu-baseline --no-legs --no-tolerance-leg")
     ap.add_argument("--no-check", action="store_true")
     return ap.parse_args()
 
@@ -114,6 +116,132 @@ def cpu_baseline(caps, n_samples):
                       f"({os.path.basename(exe)} -O3, default switches, input from /dev/shm), {dt:.1f} s wall"}
 
 
+def first_pass_picks(S, rank, world):
+    """Captures of a rank's batch whose FIRST pass is compared with the oracle: every world-th one, so that the oracle work
+    of a node does not grow with the number of ranks (the ranks of one node share its host cores).  One rank: all of them."""
+    return list(range(rank % world, S, world)) if world > 1 else list(range(S))
+
+
+def last_pass_picks(contexts, world, per_wave=8):
+    """Captures whose LAST pass (carried state of every earlier push) is compared: `per_wave` of every 64-capture wave of
+    every context at one rank (8 -> 128 of 1024), per_wave / world -- at least one -- with several ranks."""
+    k = max(1, -(-per_wave // max(1, world)))
+    picks = []
+    for first, cnt in contexts:
+        for w0 in range(0, cnt, 64):
+            w = min(64, cnt - w0)
+            picks += sorted({first + w0 + (j * (w - 1)) // max(1, k - 1) for j in range(k)} if w > 1 and k > 1 else {first + w0})
+    return picks
+
+
+def oracle_estimate_s(n_captures, n_samples, passes, threads, per_core_msamples_s=16.0, usable_cores=16):
+    """What the parity check will cost on this host (printed so that a log shows where the time went): core-seconds of the
+    scalar oracle / the cores the box really gives us (the bench hosts show 256 hardware threads and deliver ~16 cores' worth:
+    64 reference processes reach 252 Msamples/s together, one alone 16.4)."""
+    return round(n_captures * passes * n_samples / (per_core_msamples_s * 1e6) / max(1, min(threads, usable_cores)), 1)
+
+
+def leg_single_stream(wm, O, name, n, kw, okw, synth_kw, reps=7):
+    """configs[1] / configs[2] (informational): ONE capture of n IQ samples resident in HBM, pushed whole; wall clock per
+    push (process + collect: every kernel, the host decode) and the stages' HIP-event times; first push against the oracle."""
+    cu8 = wm.synth_capture(n_samples=n, **synth_kw)[0]
+    want = O.run(cu8, O.make_opts(**okw))["text"]
+    with wm.Receiver(n_streams=1, max_push_bytes=2 * n, keep_taps=False, **kw) as rx:
+        got = rx.push([cu8])
+        ms, tim = [], None
+        for _ in range(reps):
+            t = time.perf_counter()
+            rx.process(2 * n)
+            rx.collect()
+            ms.append((time.perf_counter() - t) * 1e3)
+            tim = rx.timing()
+    med = sorted(ms)[len(ms) // 2]
+    return {"workload": name, "samples_per_push": n, "ms_per_push": round(med, 3), "value": round(n / med / 1e3, 1), "unit": "Msamples/s",
+            "datagrams": len(want.splitlines()), "parity_ok": got == want,
+            "stage_ms": {k: round(tim[k], 3) for k in ("demod_ms", "clock_ms", "rla_ms", "gather_ms", "gpu_total_ms", "host_decode_ms")},
+            "reruns": {k: tim[k] for k in ("clock_reruns", "rla_reruns", "ema_retries", "slow_path")}}
+
+
+def leg_c3_batch(wm, O, shard, S, n, device, steps):
+    """configs[2] at batch size (informational): S captures at 4.0 MS/s through `-d 5 -s` (both chains fed from the +-325 kHz
+    translation), resident in HBM.  Rate, the demodulation kernel alone, 16 captures' first pass against the oracle."""
+    caps = [None] * S
+    skw = dict(fs_khz=4000, kinds=15, frames_per_s=50.0, t1c1_center_khz=325.0, s1_center_khz=-325.0)
+
+    def gen(s_):
+        caps[s_] = wm.synth_capture(seed=0xC3C3C3 + s_, n_samples=n, **skw)[0]
+    with cf.ThreadPoolExecutor(min(os.cpu_count() or 1, 64)) as ex:
+        list(ex.map(gen, range(S)))
+    b = wm.Batch(n_streams=S, contexts=0, max_push_bytes=2 * n, device=device, decimation=5, simultaneous=True, show_algorithm=True, fixed_timestamp=True,
+                 host_threads=shard.host_threads_per_context(1, 8), keep_taps=False)
+    try:
+        for s_ in range(S):
+            b.stage(s_, caps[s_])
+        b.run_resident(2 * n, 1)
+        per = collections.defaultdict(list)
+        for rx, first, _c in b.contexts:
+            for ln in rx.lines():
+                per[first + ln["stream"]].append(ln["text"])
+        picks = sorted({(j * (S - 1)) // 15 for j in range(16)}) if S > 1 else [0]
+        want = O.run_many([caps[s_] for s_ in picks], O.make_opts(decimation=5, simultaneous=1))
+        bad = [s_ for s_, w in zip(picks, want) if "".join(per[s_]) != w]
+        b.run_resident(2 * n, 2)
+        t0 = time.perf_counter()
+        b.run_resident(2 * n, steps)
+        dt = time.perf_counter() - t0
+        alone = []
+        for rx, _f, _c in b.contexts:
+            rx.process(2 * n); rx.collect(); alone.append(rx.timing()["demod_ms"])
+        spl = S * n / len(b.contexts)
+        k1 = sum(alone) / len(alone)
+        return {"workload": f"{S} captures x {n} IQ samples at 4.0 MS/s, -d 5 -s, T1 + C1 at +325 kHz and S1 at -325 kHz, HBM-resident",
+                "value": round(S * n * steps / dt / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps,
+                "contexts_per_gpu": len(b.contexts), "kernel": "k1_demod2<5, true, false, false>", "k1_alone_ms": round(k1, 3),
+                "k1_hbm_frac": round(BYTES_PER_SAMPLE * spl / (k1 / 1e3) / 1e9 / HBM_PEAK_GBPS, 4),
+                "parity": {"captures_compared": len(picks), "mismatches": len(bad), "datagrams": sum(len(w.splitlines()) for w in want)}}
+    finally:
+        b.close()
+
+
+def leg_cli(wm, n_files=256, passes=8, distinct=32):
+    """The PRODUCT's own command line, measured in THIS run: `rtl_wmbus_hip -v -S f0000.cu8 ...` over n_files capture files of
+    passes x 8 MiB in /dev/shm (names are symlinks onto `distinct` different captures), wall-clocked by the program itself:
+    decode = wmbus_batch_run (file reads into page-locked slabs, H2D, kernels, host decode, printing); with_setup adds the
+    HIP runtime's start, opening the contexts and page-locking the staging."""
+    import re
+    import shutil
+    import tempfile
+    d = tempfile.mkdtemp(prefix="wmbus_cli_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        n = passes * (1 << 22)
+
+        def gen(i):
+            wm.synth_capture(seed=0xC0FFEE + i, n_samples=n, kinds=wm.T1 | wm.C1A | wm.C1B, frames_per_s=20.0)[0].tofile(os.path.join(d, f"src{i:02d}.cu8"))
+        with cf.ThreadPoolExecutor(min(os.cpu_count() or 1, distinct)) as ex:
+            list(ex.map(gen, range(distinct)))
+        files = []
+        for i in range(n_files):
+            f = os.path.join(d, f"f{i:04d}.cu8")
+            os.symlink(os.path.join(d, f"src{i % distinct:02d}.cu8"), f)
+            files.append(f)
+        runs = []
+        for _rep in range(3):                                     # the first run touches the page cache and the code objects
+            t = time.perf_counter()
+            p = subprocess.run([wm.CLI_PATH, "-v", "-S"] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+            wall = time.perf_counter() - t
+            m = re.search(rb"total: (\d+) files on (\d+) device\(s\), (\d+) samples; decode ([\d.]+) s = ([\d.]+) Msamples/s; with set-up .*? ([\d.]+) s = ([\d.]+) Msamples/s", p.stderr)
+            if p.returncode or not m:
+                return {"value": None, "error": f"rc {p.returncode}: {p.stderr[-300:]!r}"}
+            runs.append({"decode_s": float(m.group(4)), "decode_msamples_s": float(m.group(5)), "with_setup_s": float(m.group(6)),
+                         "with_setup_msamples_s": float(m.group(7)), "process_wall_s": round(wall, 3), "lines": p.stdout.count(b"\n")})
+        best = max(runs[1:], key=lambda r: r["decode_msamples_s"])
+        return {"command": f"rtl_wmbus_hip -v -S f0000.cu8 ... f{n_files - 1:04d}.cu8 (batch mode, {n_files} files of {passes} x 8 MiB in /dev/shm)", "measured": "in this run",
+                "value": best["decode_msamples_s"], "unit": "Msamples/s", "with_setup_msamples_s": best["with_setup_msamples_s"], "samples": n_files * n, "runs": runs,
+                "pcie_bound_msamples_s": 24800.0}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def spawn_ranks(n, need_devices=True):
     """`python bench.py --gpus N` without a launcher: become the launcher.  One child per GPU with the
     environment torch.distributed.run would give it (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*); rank 0's
@@ -128,8 +256,10 @@ def spawn_ranks(n, need_devices=True):
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     procs = []
+    import uuid
+    tag = uuid.uuid4().hex[:12]                               # this launch's file-group directory (shard.FileGroup)
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env = dict(os.environ, WMBUS_GROUP_TAG=tag, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     rcs = [p.wait() for p in procs]
@@ -138,6 +268,8 @@ def spawn_ranks(n, need_devices=True):
 
 def main():
     a = parse()
+    if a.quick:
+        a.no_check = a.no_cpu_baseline = a.no_legs = a.no_tolerance_leg = True
     shard = importlib.import_module("rtl-wmbus_amd.shard")
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         spawn_ranks(a.gpus, need_devices=not a.dry_run)
@@ -160,10 +292,22 @@ def main():
         elapsed = shard.max_over_ranks(group, time.perf_counter() - t0)
         allseeds = shard.gather(group, seeds)
         nctx = a.contexts or min(8, max(1, S // 64))
+        # the parity sampling of a real run (same functions), with the split the library would make (wmbus_batch_plan needs no device)
+        wm_ = importlib.import_module("rtl-wmbus_amd")
+        plan, at = [], 0
+        for cnt in wm_.batch_plan(S, contexts=a.contexts):
+            plan.append((at, cnt)); at += cnt
+        fp, lp = first_pass_picks(S, rank, world), last_pass_picks(plan, world)
+        counts = shard.gather(group, [len(fp), len(lp)])
+        threads = max(1, (os.cpu_count() or 1) // world)
         if rank == 0:
             print(json.dumps({"dry_run": True, "n_gpus": world, "scaling": "weak", "seed_ranges": allseeds, "elapsed_s": round(elapsed, 4),
                               "backend": getattr(group, "backend", None), "contexts_per_gpu": nctx,
-                              "host_threads_per_context": shard.host_threads_per_context(world, nctx)}), flush=True)
+                              "host_threads_per_context": shard.host_threads_per_context(world, nctx),
+                              "parity_picks_per_rank": counts, "parity_picks_total": [sum(c[0] for c in counts), sum(c[1] for c in counts)],
+                              "generator_threads_per_rank": max(1, min((os.cpu_count() or 1) // world, 64)),
+                              "oracle_estimate_s": {"first_pass": oracle_estimate_s(len(fp) * world, n, 1, threads * world),
+                                                    "last_pass": oracle_estimate_s(len(lp) * world, n, a.warmup + a.steps + 2, threads * world)}}), flush=True)
         shard.destroy(group)
         return 0
     wm = importlib.import_module("rtl-wmbus_amd")
@@ -180,7 +324,7 @@ def main():
         caps[s] = wm.synth_capture(seed=shard.capture_seed(rank, S, s) + a.seed_offset, n_samples=n, kinds=wm.T1 | wm.C1A | wm.C1B,
                                    frames_per_s=20.0)[0]
 
-    with cf.ThreadPoolExecutor(min(os.cpu_count() or 1, 64)) as ex:
+    with cf.ThreadPoolExecutor(max(1, min((os.cpu_count() or 1) // world, 64))) as ex:     # the ranks of a node share its cores
         list(ex.map(gen, range(S)))
     t_gen = time.perf_counter() - t0
     t_h2d = time.perf_counter()
@@ -235,20 +379,24 @@ def main():
     # reference's zero-initialised state, exactly like a fresh oracle run, so EVERY capture of EVERY context is
     # compared with the oracle's text (farmed over this host's cores).
     parity, passes_done = None, 0
+    o_threads = max(1, (os.cpu_count() or 1) // max(1, world))
     if not a.no_check:
         import oracle_ffi as O
         run_steps(1)
         passes_done += 1
         got = texts_of_last_push()
         t_o = time.perf_counter()
-        want = want_first = O.run_many(caps, O.make_opts(), threads=max(1, (os.cpu_count() or 1) // max(1, world)))
-        bad = [s_ for s_ in range(S) if got[s_] != want[s_]]
-        parity = {"first_pass": {"captures_compared": S, "contexts": nctx, "mismatches": len(bad), "first_bad": bad[:4],
-                                 "datagrams": sum(len(t.splitlines()) for t in want), "oracle_s": round(time.perf_counter() - t_o, 1)}}
+        fpicks = first_pass_picks(S, rank, world)              # one rank: every capture; N ranks: every N-th of each rank's
+        want_by = dict(zip(fpicks, O.run_many([caps[s_] for s_ in fpicks], O.make_opts(), threads=o_threads)))
+        want_first = want_by
+        bad = [s_ for s_ in fpicks if got[s_] != want_by[s_]]
+        parity = {"first_pass": {"captures_compared": len(fpicks), "of": S, "contexts": nctx, "mismatches": len(bad), "first_bad": bad[:4],
+                                 "datagrams": sum(len(t.splitlines()) for t in want_by.values()), "oracle_s": round(time.perf_counter() - t_o, 1),
+                                 "oracle_estimate_s": oracle_estimate_s(len(fpicks) * world, n, 1, o_threads * world)}}
         if a.tolerance_mode:                                   # informational run: how many LINES differ from the reference's
             dl = 0
             for s_ in bad:
-                g, w = collections.Counter(got[s_].splitlines()), collections.Counter(want[s_].splitlines())
+                g, w = collections.Counter(got[s_].splitlines()), collections.Counter(want_by[s_].splitlines())
                 dl += sum(((g - w) + (w - g)).values())
             parity["first_pass"]["differing_lines"] = dl
     if a.warmup:
@@ -288,11 +436,13 @@ def main():
     k1_avg_s = sum(alone_ms) / max(1, len(alone_ms)) / 1e3
     k1_concurrent_ms = demod_ms / max(1, k1_launches)
     achieved = BYTES_PER_SAMPLE * samples_per_launch / k1_avg_s / 1e9 if k1_avg_s > 0 else 0.0
-    traffic = None
+    traffic, traffic_from = None, None
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tf):
         try:
-            traffic = int(json.load(open(tf))["k1_demod_hbm_bytes_per_input_sample"] * samples_per_launch)
+            tj = json.load(open(tf))
+            traffic = int(tj["k1_demod_hbm_bytes_per_input_sample"] * samples_per_launch)
+            traffic_from = {"file": "profiles/traffic.json", "collected_at": tj.get("collected_at", "unknown"), "job_hbm_bytes_per_step": tj.get("job_hbm_bytes_per_step")}
         except Exception:
             traffic = None
 
@@ -301,19 +451,17 @@ def main():
     # fed the same capture the same number of times.
     if parity is not None:
         got = texts_of_last_push()
-        picks = []
-        for _rx, first, cnt in batch.contexts:
-            for w0 in range(0, cnt, 64):
-                w = min(64, cnt - w0)
-                picks += sorted({first + w0 + (j * (w - 1)) // 7 for j in range(8)} if w > 1 else {first + w0})
+        picks = last_pass_picks([(first, cnt) for _rx, first, cnt in batch.contexts], world)
         t_o = time.perf_counter()
-        want = O.run_many([caps[s_] for s_ in picks], O.make_opts(), passes=passes_done,
-                          threads=max(1, (os.cpu_count() or 1) // max(1, world)))
+        want = O.run_many([caps[s_] for s_ in picks], O.make_opts(), passes=passes_done, threads=o_threads)
         bad = [s_ for s_, w in zip(picks, want) if got[s_] != w]
         parity["last_pass"] = {"captures_compared": len(picks), "contexts": nctx, "pass_number": passes_done, "mismatches": len(bad),
-                               "first_bad": bad[:4], "oracle_s": round(time.perf_counter() - t_o, 1)}
+                               "first_bad": bad[:4], "oracle_s": round(time.perf_counter() - t_o, 1),
+                               "oracle_estimate_s": oracle_estimate_s(len(picks) * world, n, passes_done, o_threads * world)}
         n_bad = int(shard.sum_over_ranks(group, parity["first_pass"]["mismatches"] + len(bad)))
+        compared = shard.gather(group, [parity["first_pass"]["captures_compared"], len(picks)])
         parity["ranks"] = world
+        parity["all_ranks"] = {"first_pass_captures": sum(c[0] for c in compared), "last_pass_captures": sum(c[1] for c in compared)}
         parity["ok"] = n_bad == 0
 
     # VALU roofline (BASELINE.md section 3 asks for it next to the HBM one; it is the roof that binds): wave-instructions per
@@ -331,6 +479,7 @@ def main():
                     "frac": round(wi / k1_avg_s / 1e12 / peak, 4),
                     "whole_job": {"wave_instr_per_step": int(wj), "achieved_T_per_s": round(wj / (elapsed / a.steps) / 1e12, 4),
                                   "frac": round(wj / (elapsed / a.steps) / 1e12 / peak, 4)},
+                    "collected_at": vj.get("collected_at", "unknown"),
                     "how": "SQ_INSTS_VALU per launch from the committed rocprofv3 --pmc pass (profiles/valu.json, profiles/*_pmc_sq_counters.csv) / "
                            "the HIP-event duration of this run; peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction"}
         except Exception:
@@ -355,7 +504,7 @@ def main():
                     per[first + ln["stream"]].append(ln["text"])
             want1 = want_first                                  # the oracle's text of every capture's first pass, computed above
             dl = dc = 0
-            for s_ in range(S):
+            for s_ in sorted(want1):
                 g = "".join(per[s_])
                 if g != want1[s_]:
                     dc += 1
@@ -365,13 +514,33 @@ def main():
             t0 = time.perf_counter()
             b2.run_resident(push_bytes, a.steps)
             dt = time.perf_counter() - t0
+            # the mode's LAST pass (carried filter / framer / decoder state of every push so far) of two captures of every
+            # 64-capture wave, against an oracle instance fed the same capture the same number of times (the
+            # carried-state check of this mode only existed in builder-kept files)
+            tol_passes = 1 + max(1, a.warmup) + a.steps
+            per = collections.defaultdict(list)
+            for rx, first, _cnt in b2.contexts:
+                for ln in rx.lines():
+                    per[first + ln["stream"]].append(ln["text"])
+            tpicks = last_pass_picks([(first, cnt) for _rx, first, cnt in b2.contexts], 1, per_wave=2)
+            t_o = time.perf_counter()
+            wantl = O.run_many([caps[s_] for s_ in tpicks], O.make_opts(), passes=tol_passes, threads=o_threads)
+            ldl = ldc = 0
+            for s_, w in zip(tpicks, wantl):
+                g = "".join(per[s_])
+                if g != w:
+                    ldc += 1
+                    cg, cw = collections.Counter(g.splitlines()), collections.Counter(w.splitlines())
+                    ldl += sum(((cg - cw) + (cw - cg)).values())
+            tol_last = {"captures_compared": len(tpicks), "pass_number": tol_passes, "captures_with_differing_text": ldc, "differing_lines": ldl,
+                        "datagrams": sum(len(w.splitlines()) for w in wantl), "oracle_s": round(time.perf_counter() - t_o, 1)}
             alone = []
             for rx, _f, _c in b2.contexts:
                 rx.process(push_bytes); rx.collect(); alone.append(rx.timing()["demod_ms"])
             spl = S * n / len(b2.contexts)
             tol = {"value": round(S * n * a.steps / dt / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(dt / a.steps * 1e3, 2), "contexts_per_gpu": len(b2.contexts),
-                   "captures_compared": S, "captures_with_differing_text": dc, "differing_lines": dl, "datagrams": sum(len(t.splitlines()) for t in want1),
-                   "soft_symbol_tolerance_abs": 2e-6,
+                   "captures_compared": len(want1), "captures_with_differing_text": dc, "differing_lines": dl, "datagrams": sum(len(t.splitlines()) for t in want1.values()),
+                   "last_pass": tol_last, "soft_symbol_tolerance_abs": 2e-6,
                    "k1_alone_ms": round(sum(alone) / len(alone), 3),
                    "k1_hbm_frac": round(BYTES_PER_SAMPLE * spl / (sum(alone) / len(alone) / 1e3) / 1e9 / HBM_PEAK_GBPS, 4),
                    "what": "wmbus_cfg.tolerance_mode = 1 (CLI -F): polynomial arctangent (|error| <= 2.4e-7 of a half turn) + FMA low-passes in the demodulation "
@@ -380,6 +549,30 @@ def main():
             batch = None
         except Exception as e:                                # the informational leg must never cost the bench line
             tol = {"value": None, "error": repr(e)}
+
+    # ---- informational legs (N = 1): BASELINE configs[1] and configs[2] -- one 1.6 MS/s stream; one stream and the batch at
+    # 4.0 MS/s through `-d 5 -s` -- and the product's own command line.  Each in its own try: never the headline, never fatal.
+    legs = {}
+    if world == 1 and not a.no_legs and not a.from_host and not a.tolerance_mode:
+        import oracle_ffi as O
+        if batch is not None:
+            batch.close()
+            batch = None
+        for key, fn in (
+            ("c2_single_stream", lambda: leg_single_stream(wm, O, "configs[1]: one 1.6 MS/s capture, default switches (T1/C1 + S1 chains), HBM-resident", n,
+                                                           dict(device=local), {}, dict(seed=0xC2C2, kinds=wm.T1 | wm.C1A | wm.C1B, frames_per_s=20.0))),
+            ("c3_single_stream", lambda: leg_single_stream(wm, O, "configs[2]: one 4.0 MS/s capture, -d 5 -s, S1 + T1 + C1 concurrently, HBM-resident", n,
+                                                           dict(device=local, decimation=5, simultaneous=True), dict(decimation=5, simultaneous=1),
+                                                           dict(seed=0xC3C3, fs_khz=4000, kinds=15, frames_per_s=50.0, t1c1_center_khz=325.0, s1_center_khz=-325.0))),
+            ("c3_batch", lambda: leg_c3_batch(wm, O, shard, S, n, local, max(3, a.steps // 4))),
+            ("cli", lambda: leg_cli(wm)),
+        ):
+            try:
+                t_l = time.perf_counter()
+                legs[key] = fn()
+                legs[key]["leg_s"] = round(time.perf_counter() - t_l, 1)
+            except Exception as e:
+                legs[key] = {"value": None, "error": repr(e)}
 
     ok = True
     if rank == 0:
@@ -398,7 +591,7 @@ def main():
             "hbm_roofline_pct_whole_job": round(100.0 * BYTES_PER_SAMPLE * value * 1e6 / world / 1e9 / HBM_PEAK_GBPS, 3),
             "datagrams_per_step": lines_total // max(1, a.steps),
             "roofline": {"bound": "hbm", "kernel": "k1_demod2", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_from": traffic_from,
                          "algorithmic_bytes_per_launch": int(BYTES_PER_SAMPLE * samples_per_launch),
                          "avg_launch_ms": round(k1_avg_s * 1e3, 3),
                          "launches_timed": len(alone_ms),
@@ -420,12 +613,18 @@ def main():
         }
         if tol is not None:
             out["tolerance_mode_leg"] = tol
-        cli = os.path.join(ROOT, "profiles", "cli_rate.json")     # tools/bench_cli.sh: the product's own command line, wall-clocked
-        if os.path.exists(cli):
-            try:
-                out["cli"] = json.load(open(cli))
-            except Exception:
-                pass
+        for key in ("c2_single_stream", "c3_single_stream", "c3_batch", "cli"):
+            if key in legs:
+                out[key] = legs[key]
+        if "cli" not in legs:                                  # not measured in this run: say where the number comes from
+            cli = os.path.join(ROOT, "profiles", "cli_rate.json")     # tools/bench_cli.sh, wall-clocked on an earlier visit
+            if os.path.exists(cli):
+                try:
+                    cj = json.load(open(cli))
+                    out["cli_replayed"] = {"replayed_from": "profiles/cli_rate.json", "collected_at": cj.get("collected_at", "unknown commit"), "value": cj.get("value"),
+                                           "unit": cj.get("unit"), "note": "NOT measured in this run"}
+                except Exception:
+                    pass
         if world == 1 and not a.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(caps, n)
@@ -434,7 +633,7 @@ def main():
         if parity is not None:
             fp, lp = parity["first_pass"], parity["last_pass"]
             out["parity"] = parity
-            out["parity_check"] = (f"{fp['captures_compared']} captures x {nctx} contexts (first pass, all of them) and {lp['captures_compared']} captures "
+            out["parity_check"] = (f"{fp['captures_compared']} of {fp['of']} captures x {nctx} contexts (first pass) and {lp['captures_compared']} captures "
                                    f"across {nctx} contexts (pass {lp['pass_number']}, carried state) identical to the oracle"
                                    if parity["ok"] else "MISMATCH")
             ok = bool(parity["ok"]) or a.tolerance_mode          # tolerance mode is informational: its differences are reported, not fatal

@@ -55,7 +55,8 @@ typedef struct wmbus_cfg {
     int device;                 /* HIP device ordinal                                */
     size_t max_push_bytes;      /* capacity per stream per push, multiple of 4096    */
     /* tuning (0 = default) */
-    unsigned seg_len;           /* clock-recovery time segment, decimated samples (power of two, 1024 ... 2^20) */
+    unsigned seg_len;           /* clock-recovery time segment, decimated samples (power of two, 1024 ... 2^20); 0: 32768 for
+                                   >= 64 captures, shorter for fewer (a small batch is bound by how long one lane walks) */
     unsigned rla_seg_len;       /* run-length framer time segment                    */
     unsigned warmup_t1c1;       /* IIR warm-up before a segment, T1/C1 chain         */
     unsigned warmup_s1;         /* IIR warm-up before a segment, S1 chain            */
@@ -124,6 +125,15 @@ typedef struct wmbus_timing {
  * interferer makes the run-length framer emit more chips than even the spill arena holds, or more candidate bursts
  * than the burst arena, the excess is dropped (datagrams inside it may be lost), all carried state stays exact. */
 enum { WMBUS_WARN_CHIPS_DROPPED = 1, WMBUS_WARN_BURSTS_DROPPED = 2 };
+
+/* Process-wide HIP runtime defaults this library wants, applied through the environment: GPU_MAX_HW_QUEUES=16 unless the
+ * caller has set the variable (ROCm maps HIP streams onto 4 hardware queues by default and streams that share a queue
+ * serialise: a batch of eight contexts runs at 55 % of its rate on four).  The runtime reads the variable ONCE, at the
+ * first HIP call of the process, so this must run before that -- wmbus_batch_open() calls it, the CLI calls it first thing
+ * in main(); an application that uses HIP before it opens a batch calls it (or exports the variable) itself.  The library
+ * does nothing at load time.  WMBUS_KEEP_HW_QUEUES=1 in the environment turns the call into a no-op.  Not thread-safe
+ * against concurrent getenv/setenv (it is a setenv): call it before starting threads. */
+void wmbus_runtime_init(void);
 
 void wmbus_default_cfg(wmbus_cfg *cfg);
 

@@ -83,7 +83,7 @@ class BatchStats(ctypes.Structure):
 
 EXPORTS = ["wmbus_batch_plan", "wmbus_batch_open", "wmbus_batch_close", "wmbus_batch_last_error", "wmbus_batch_contexts", "wmbus_batch_context", "wmbus_batch_stage",
            "wmbus_batch_device_input", "wmbus_batch_run",
-           "wmbus_default_cfg", "wmbus_open", "wmbus_close", "wmbus_last_error", "wmbus_stage", "wmbus_device_input",
+           "wmbus_runtime_init", "wmbus_default_cfg", "wmbus_open", "wmbus_close", "wmbus_last_error", "wmbus_stage", "wmbus_device_input",
            "wmbus_process", "wmbus_collect", "wmbus_lines", "wmbus_lines_text", "wmbus_get_timing", "wmbus_read_tap",
            "wmbus_read_chips", "wmbus_device_count", "wmbus_selftest_math", "wmbus_alloc_pinned", "wmbus_free_pinned"]
 
@@ -97,6 +97,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise WmbusError(f"{LIB_PATH} is missing: run __graft_entry__.build() / make -C rtl-wmbus_amd")
         L = ctypes.CDLL(LIB_PATH)
+        L.wmbus_runtime_init()           # before the first HIP call of the process (the hardware-queue default, see wmbus_hip.h)
         vp, u, sz = ctypes.c_void_p, ctypes.c_uint, ctypes.c_size_t
         L.wmbus_default_cfg.argtypes = [ctypes.POINTER(Cfg)]
         L.wmbus_open.argtypes = [ctypes.POINTER(Cfg), ctypes.POINTER(vp)]

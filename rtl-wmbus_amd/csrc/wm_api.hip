@@ -111,8 +111,10 @@ struct wmbus_ctx {
     char err[256] = {0};
     hipStream_t stream = nullptr;                      /* every kernel of the context */
     hipStream_t copy_stream = nullptr;                 /* wmbus_stage's H2D copies (north_star: "pinned hipMemcpyAsync on a side stream") */
-    hipEvent_t ev[9] = {};
+    hipStream_t side_stream = nullptr;                 /* run-length framer beside the clock kernel's re-run rounds (see enqueue_front_impl); nullptr: one stream */
+    hipEvent_t ev[11] = {};                            /* [9], [10]: side-stream interval (timing) */
     hipEvent_t ev_staged = nullptr;                    /* recorded on copy_stream at process(): the push's input is in HBM */
+    hipEvent_t ev_ready = nullptr, ev_fork = nullptr, ev_join = nullptr;   /* cross-stream order only (no timing): input ready for K1; fork / join of the side stream */
     uint32_t n_win = 1, fill = 0;                      /* input windows (cfg.input_windows) and the one wmbus_stage fills now */
     /* geometry */
     uint32_t d = 2, S = 1, C[2] = {8192, 32768}, Mcap = 0, nseg_cap[2] = {0, 0}, ntiles_cap = 0, T = WM_K1_TILE2;
@@ -154,7 +156,7 @@ struct wmbus_ctx {
     WmPkt *h_pkts = nullptr; uint8_t *h_bytes = nullptr;
     void *dv_hdr = nullptr, *dv_words = nullptr, *dv_pkts = nullptr, *dv_bytes = nullptr;    /* their device views */
     uint32_t n_hdr = 0, n_words = 0, n_pkts = 0;
-    K1Args k1a{}; K2Args k2clk{}, k2rla{}; uint32_t ntiles = 0; bool fused = false;    /* this push's launch arguments (collect's slow path re-uses them) */
+    K1Args k1a{}; K2Args k2clk{}, k2rla{}; uint32_t ntiles = 0; bool fused = false, forked = false;    /* this push's launch arguments (collect's slow path re-uses them) */
     std::vector<HostDecoder> decs;                      /* [stream][chain][algo] */
     std::vector<wm_twin> twins;                         /* [stream][chain][2]: the last lines printed (cfg.dedup_twins) */
     std::unique_ptr<WorkerPool> pool;                   /* packet-decoder workers, created on first use */
@@ -191,6 +193,7 @@ template <typename T> hipError_t dalloc(T **p, size_t n) { return hipMalloc((voi
 /* Hand-off verification runs a few rounds WITHOUT asking the host: verify -> re-run list on the device -> list launch
  * with a fixed grid -> verify ..., each round with its own counter; the host only looks at the last counters when it
  * collects the push and finishes the (rare) leftovers round by round. */
+enum { WM_MAX_DEVICES = 64 };                    /* per-device tables (K1 order, kernel attributes); wmbus_open refuses ordinals beyond */
 enum { WM_EMA_ROUNDS = 1, WM_FR_ROUNDS = 2 };   /* bench workload: clock re-runs 1400, then < 10, then 0; run-length 2300, then 0 */
 /* debugging aid: WMBUS_OPT_ROUNDS=0 skips the unattended re-run launches (the counters of the rounds stay zero), so
  * that every hand-off failure is finished by the host-driven path */
@@ -244,38 +247,38 @@ __global__ __launch_bounds__(256) void k_sum_counts(WmPush g, const uint32_t *co
     }
 }
 
-template <int D, bool SHIFT, bool GEN, bool FAST = false> int launch_k1v3(wmbus_ctx *c, const K1Args &a, dim3 grid)
+template <int D, bool SHIFT, bool GEN, bool FAST = false> int launch_k1v3(wmbus_ctx *c, const K1Args &a, dim3 grid, hipStream_t st)
 {
     const size_t sm = K1Geo::smem(D ? D : (int)c->d, SHIFT);
-    static std::atomic<size_t> set_for[16];                 /* per device: the attribute call is not free, a push makes several launches */
-    if (set_for[c->cfg.device & 15] < sm) {
+    static std::atomic<size_t> set_for[WM_MAX_DEVICES];     /* per device: the attribute call is not free, a push makes several launches */
+    if (set_for[c->cfg.device] < sm) {
         HIPCHK(c, hipFuncSetAttribute((const void *)k1_demod2<D, SHIFT, GEN, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-        set_for[c->cfg.device & 15] = sm;
+        set_for[c->cfg.device] = sm;
     }
-    hipLaunchKernelGGL((k1_demod2<D, SHIFT, GEN, FAST>), grid, dim3(256), sm, c->stream, a);
+    hipLaunchKernelGGL((k1_demod2<D, SHIFT, GEN, FAST>), grid, dim3(256), sm, st, a);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
 
 /* the default switches' first pass runs the kernel without the option paths (k1_demod2<.., GEN = false>) */
-template <int D, bool SHIFT> int launch_k1v2(wmbus_ctx *c, const K1Args &a, dim3 grid)
+template <int D, bool SHIFT> int launch_k1v2(wmbus_ctx *c, const K1Args &a, dim3 grid, hipStream_t st)
 {
     const uint32_t need = WM_F_ACCURATE | WM_F_T1C1 | WM_F_S1, never = WM_F_APPROX1 | WM_F_APPROX2;
     if (D != 0 && a.relist == nullptr && (c->flags & need) == need && !(c->flags & never))
         /* tolerance mode (an option of the default switches' kernel only; everything else stays exact) */
-        return c->cfg.tolerance_mode ? launch_k1v3<D, SHIFT, false, true>(c, a, grid) : launch_k1v3<D, SHIFT, false>(c, a, grid);
-    return launch_k1v3<D, SHIFT, true>(c, a, grid);
+        return c->cfg.tolerance_mode ? launch_k1v3<D, SHIFT, false, true>(c, a, grid, st) : launch_k1v3<D, SHIFT, false>(c, a, grid, st);
+    return launch_k1v3<D, SHIFT, true>(c, a, grid, st);
 }
 
-int launch_k1_ppf(wmbus_ctx *c, const K1Args &a, dim3 grid)
+int launch_k1_ppf(wmbus_ctx *c, const K1Args &a, dim3 grid, hipStream_t st)
 {
     const size_t sm = K1PpfGeo::smem();
-    static std::atomic<size_t> set_for[16];
-    if (set_for[c->cfg.device & 15] < sm) {
+    static std::atomic<size_t> set_for[WM_MAX_DEVICES];
+    if (set_for[c->cfg.device] < sm) {
         HIPCHK(c, hipFuncSetAttribute((const void *)k1_demod_ppf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
-        set_for[c->cfg.device & 15] = sm;
+        set_for[c->cfg.device] = sm;
     }
-    hipLaunchKernelGGL(k1_demod_ppf, grid, dim3(256), sm, c->stream, a);
+    hipLaunchKernelGGL(k1_demod_ppf, grid, dim3(256), sm, st, a);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -299,17 +302,21 @@ __global__ void k_selftest(const float *a, const float *b, float *o_sqrt, float 
  * memory-bound framer kernels is complementary).  The order is kept on the GPU: a context's K1 waits for the event
  * behind the K1 launched before it, so no host thread sits in the way (a host-side turn held across the launches of
  * everything behind K1 made the turn 2.9 ms longer than the kernel). */
-struct K1Chain { std::mutex m; hipEvent_t last = nullptr; const wmbus_ctx *owner = nullptr; };
-K1Chain k1_chain[16];
+/* WMBUS_K1_STREAM=1 (default): the order is that of ONE shared HIP stream per device which carries nothing but the contexts'
+ * demodulation kernels -- consecutive launches on one queue follow each other within microseconds, while an event wait
+ * between two queues cost 100-190 us per hand-off (r03 trace: median gap 128 us between one context's K1 and the next's,
+ * 8 x per step).  A context's own stream hands its input over with an event and picks the result up with another. */
+struct K1Chain { std::mutex m; hipEvent_t last = nullptr; const wmbus_ctx *owner = nullptr; hipStream_t stream = nullptr; };
+K1Chain k1_chain[WM_MAX_DEVICES];
 
 /* One HIP stream per receiver context (two with cfg.input_windows = 2); ROCm maps streams onto GPU_MAX_HW_QUEUES hardware
  * queues (4 by default) round robin, and streams that share a queue serialise against each other: eight contexts on four
  * queues run at 81 instead of 143 Gsamples/s, ten on eight at 107 (r03 A/B).  The runtime reads the variable when it
- * initialises (the first HIP call of the process), so the library sets its default when it is loaded -- a caller's own
- * setting wins.  16 covers the default batch (8 contexts, 12 in tolerance mode) with and without copy streams; with 16
+ * initialises (the first HIP call of the process), so wmbus_runtime_init() (include/wmbus_hip.h) must run before that:
+ * wmbus_batch_open calls it, the CLI calls it first thing, an embedder that uses HIP itself calls it (or sets the
+ * variable) before its own first HIP call -- a caller's own setting wins.  (Rounds 2-3 did this in a load-time constructor:
+ * a setenv behind the host application's back)  16 covers the default batch (8 contexts, 12 in tolerance mode) with and without copy streams; with 16
  * queues and 8 contexts the rate is the one with 8 queues.  (bench.py and INTEGRATION.md used to ask the caller for this.) */
-__attribute__((constructor)) void wm_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
-
 double now_ms()
 {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -318,6 +325,13 @@ double now_ms()
 }  // namespace
 
 extern "C" {
+
+void wmbus_runtime_init(void)
+{
+    /* setenv is not safe against concurrent getenv: call this before the process starts threads that read the
+     * environment (the CLI: first statement of main) */
+    if (!getenv("WMBUS_KEEP_HW_QUEUES")) setenv("GPU_MAX_HW_QUEUES", "16", 0);
+}
 
 void wmbus_default_cfg(wmbus_cfg *cfg)
 {
@@ -341,7 +355,7 @@ void wmbus_close(wmbus_ctx *c)
     if (!c) return;
     if (c->stream) hipStreamSynchronize(c->stream);
     {
-        K1Chain &kc = k1_chain[c->cfg.device & 15];
+        K1Chain &kc = k1_chain[c->cfg.device];
         std::lock_guard<std::mutex> lk(kc.m);
         if (kc.owner == c) { kc.last = nullptr; kc.owner = nullptr; }      /* nobody may wait on an event that is about to go */
     }
@@ -353,7 +367,8 @@ void wmbus_close(wmbus_ctx *c)
     void *host[] = {c->h_scalars, c->h_hdr, c->h_words, c->h_pending, c->h_pkts, c->h_bytes};
     for (void *p : host) if (p) hipHostFree(p);
     for (auto &e : c->ev) if (e) hipEventDestroy(e);
-    if (c->ev_staged) hipEventDestroy(c->ev_staged);
+    for (hipEvent_t e : {c->ev_staged, c->ev_ready, c->ev_fork, c->ev_join}) if (e) hipEventDestroy(e);
+    if (c->side_stream) { hipStreamSynchronize(c->side_stream); hipStreamDestroy(c->side_stream); }
     if (c->copy_stream && c->copy_stream != c->stream) { hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); }
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -377,12 +392,22 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
         return bail(fail(c, WMBUS_EINVAL, "atan_mode must be WMBUS_ATAN_LIBM, WMBUS_ATAN_APPROX1 or WMBUS_ATAN_APPROX2"));
     if (cfg->prefilter == WMBUS_PREFILTER_POLYPHASE && (cfg->decimation != 2 || cfg->simultaneous))
         return bail(fail(c, WMBUS_EINVAL, "the polyphase pre-filter is the 1.6 MS/s design of rtl_wmbus.c:258-294: decimation 2, no -s"));
+    if (cfg->device < 0 || cfg->device >= WM_MAX_DEVICES) return bail(fail(c, WMBUS_EINVAL, "device must be 0..%d", WM_MAX_DEVICES - 1));
     if (wmbus_device_count() <= cfg->device) return bail(fail(c, WMBUS_ENODEVICE, "no HIP device %d (this library has no CPU fallback)", cfg->device));
     if (hipSetDevice(cfg->device) != hipSuccess) return bail(fail(c, WMBUS_EDEVICE, "hipSetDevice(%d) failed", cfg->device));
 
     c->d = cfg->decimation; c->S = cfg->n_streams;
-    c->C[1] = cfg->seg_len ? cfg->seg_len : 32768u;    /* in-box A/B with the fused framer launches: 65536 -3 %, 16384 -4 % */
-    c->C[0] = cfg->rla_seg_len ? cfg->rla_seg_len : 8192u;
+    /* Time segments: 32768 / 8192 decimated samples for batches of whole waves (r02 / r03 A/Bs: clock 65536 -8 %, 16384 -25 %;
+     * run-length 16384 -9 %, 4096 -20 %).  A batch with fewer captures than a wave has lanes is bound by how long ONE lane
+     * walks (5 us per 32 samples whatever runs beside it), not by the work: its segments shrink with the capture count, down
+     * to 4096 / 2048 for a single capture (one 2^22-sample push of one capture: 19 -> 9 ms; the result does not depend on the
+     * segmentation, test_result_independent_of_segmentation). */
+    {
+        uint32_t k = 1;
+        while (k < 8u && c->S * k < 64u) k *= 2u;          /* 1 for >= 64 captures ... 8 for fewer than 16 */
+        c->C[1] = cfg->seg_len ? cfg->seg_len : 32768u / k;
+        c->C[0] = cfg->rla_seg_len ? cfg->rla_seg_len : std::max(2048u, 8192u / k);
+    }
     for (int a = 0; a < 2; a++)
         if (c->C[a] < 1024u || c->C[a] > (1u << 20) || (c->C[a] & (c->C[a] - 1)))
             return bail(fail(c, WMBUS_EINVAL, "seg_len / rla_seg_len must be powers of two in [1024, 1048576]"));
@@ -421,6 +446,18 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
     if (c->n_win == 2) A(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking)); else c->copy_stream = c->stream;
     for (auto &ev : c->ev) A(hipEventCreate(&ev));
     A(hipEventCreateWithFlags(&c->ev_staged, hipEventDisableTiming));
+    A(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
+    A(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    A(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    {
+        /* the run-length framer beside the clock kernel's re-run rounds (second stream, see enqueue_front_impl): shortens a
+         * context's chain of dependent launches by 4-5 ms.  Pays where that chain is what binds: tolerance mode (K1 a third
+         * shorter) and small batches; the exact 8-context batch is bound by the demodulation kernels' ring instead (r03 A/B:
+         * -1 % there, +3.5 % in tolerance mode).  WMBUS_RLA_SIDE=0/1 overrides. */
+        const char *e_ = getenv("WMBUS_RLA_SIDE");
+        const bool side = e_ ? atoi(e_) != 0 : (cfg->tolerance_mode != 0);
+        if (side && cfg->rla_enabled && !cfg->remove_dc) A(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+    }
     A(dalloc(&c->d_in, (size_t)c->in_stride * c->S * c->n_win));
     A(dalloc(&c->d_hist, (size_t)WM_HIST_BYTES * c->S));
     A(dalloc(&c->d_dphi, (size_t)rows * c->Mcap));
@@ -564,15 +601,16 @@ static void *st_carry(wmbus_ctx *c, int algo, bool out)
     return (char *)c->d_st_carry[algo] + (size_t)(c->carry_in ^ (out ? 1u : 0u)) * 2 * c->S * w;
 }
 
-static int launch_k1_any(wmbus_ctx *c, const K1Args &k1, dim3 grid)
+static int launch_k1_any(wmbus_ctx *c, const K1Args &k1, dim3 grid, hipStream_t st = nullptr)
 {
     const bool sh = c->flags & WM_F_SHIFT;
-    if (c->cfg.prefilter == WMBUS_PREFILTER_POLYPHASE) return launch_k1_ppf(c, k1, grid);
-    if (c->d == 2) return sh ? launch_k1v2<2, true>(c, k1, grid) : launch_k1v2<2, false>(c, k1, grid);
-    if (c->d == 3) return sh ? launch_k1v2<3, true>(c, k1, grid) : launch_k1v2<3, false>(c, k1, grid);
-    if (c->d == 4) return sh ? launch_k1v2<4, true>(c, k1, grid) : launch_k1v2<4, false>(c, k1, grid);
-    if (c->d == 5) return sh ? launch_k1v2<5, true>(c, k1, grid) : launch_k1v2<5, false>(c, k1, grid);
-    return sh ? launch_k1v2<0, true>(c, k1, grid) : launch_k1v2<0, false>(c, k1, grid);      /* any other rate */
+    if (!st) st = c->stream;
+    if (c->cfg.prefilter == WMBUS_PREFILTER_POLYPHASE) return launch_k1_ppf(c, k1, grid, st);
+    if (c->d == 2) return sh ? launch_k1v2<2, true>(c, k1, grid, st) : launch_k1v2<2, false>(c, k1, grid, st);
+    if (c->d == 3) return sh ? launch_k1v2<3, true>(c, k1, grid, st) : launch_k1v2<3, false>(c, k1, grid, st);
+    if (c->d == 4) return sh ? launch_k1v2<4, true>(c, k1, grid, st) : launch_k1v2<4, false>(c, k1, grid, st);
+    if (c->d == 5) return sh ? launch_k1v2<5, true>(c, k1, grid, st) : launch_k1v2<5, false>(c, k1, grid, st);
+    return sh ? launch_k1v2<0, true>(c, k1, grid, st) : launch_k1v2<0, false>(c, k1, grid, st);      /* any other rate */
 }
 
 /* EMA hand-offs between tiles (k1_verify), the first uncertified tile of every row into the repair list (k1_collect),
@@ -597,17 +635,19 @@ static void ema_commit(wmbus_ctx *c)
     hipLaunchKernelGGL(k1_commit, dim3((2 * c->S + 63) / 64), dim3(64), 0, c->stream, c->d_ema_tail, ema_carry(c, true), c->ntiles, 2 * c->S);
 }
 
-static void fr_verify(wmbus_ctx *c, int algo, uint32_t cnt)
+static void fr_verify(wmbus_ctx *c, int algo, uint32_t cnt, hipStream_t st = nullptr)
 {
+    if (!st) st = c->stream;
     const K2Args &a = algo == WMBUS_ALGO_RLA ? c->k2rla : c->k2clk;
     const uint32_t lanes = 2u * a.g.nseg[algo] * a.g.S, words = (algo == WMBUS_ALGO_RLA ? sizeof(WmRlaState) : sizeof(WmClkState)) / 4;
-    hipLaunchKernelGGL(k2_verify, dim3((lanes + 255) / 256), dim3(256), 0, c->stream, a.g, (uint32_t)algo, (const uint32_t *)a.st_start,
+    hipLaunchKernelGGL(k2_verify, dim3((lanes + 255) / 256), dim3(256), 0, st, a.g, (uint32_t)algo, (const uint32_t *)a.st_start,
                        (const uint32_t *)a.st_final, words, algo == WMBUS_ALGO_RLA ? c->d_list2 : c->d_list, c->d_scalars + cnt);
 }
 
 /* one framer's kernel alone: every lane (cnt == ~0) or the re-run list whose length is scalar `cnt` */
-static void fr_launch(wmbus_ctx *c, int algo, uint32_t cnt)
+static void fr_launch(wmbus_ctx *c, int algo, uint32_t cnt, hipStream_t st = nullptr)
 {
+    if (!st) st = c->stream;
     K2Args a = algo == WMBUS_ALGO_RLA ? c->k2rla : c->k2clk;
     const uint32_t lanes = 2u * a.g.nseg[algo] * a.g.S;
     const bool all = cnt == 0xFFFFFFFFu;
@@ -616,14 +656,14 @@ static void fr_launch(wmbus_ctx *c, int algo, uint32_t cnt)
     /* list launches: blocks for 3/16 of the lanes (a re-run list is a few percent of them; the blocks walk whatever is more) */
     const uint32_t B = 64 * (algo == WMBUS_ALGO_RLA ? WM_RLA_WPB : WM_CLK_WPB), grid = all ? (lanes + B - 1) / B : std::max(16u, (lanes / B) * 3u / 16u);
     if (algo == WMBUS_ALGO_RLA) {
-        if (all) hipLaunchKernelGGL(k2_rla, dim3(grid), dim3(B), 0, c->stream, a);
-        else hipLaunchKernelGGL(k2_rla_list, dim3(grid), dim3(B), 0, c->stream, a);
+        if (all) hipLaunchKernelGGL(k2_rla, dim3(grid), dim3(B), 0, st, a);
+        else hipLaunchKernelGGL(k2_rla_list, dim3(grid), dim3(B), 0, st, a);
     }
     else if (all) {
-        if (c->flags & WM_F_DC) hipLaunchKernelGGL(k2_clock<true>, dim3(grid), dim3(B), 0, c->stream, a);
-        else hipLaunchKernelGGL(k2_clock<false>, dim3(grid), dim3(B), 0, c->stream, a);
-    } else if (c->flags & WM_F_DC) hipLaunchKernelGGL(k2_clock_list<true>, dim3(grid), dim3(B), 0, c->stream, a);
-    else hipLaunchKernelGGL(k2_clock_list<false>, dim3(grid), dim3(B), 0, c->stream, a);
+        if (c->flags & WM_F_DC) hipLaunchKernelGGL(k2_clock<true>, dim3(grid), dim3(B), 0, st, a);
+        else hipLaunchKernelGGL(k2_clock<false>, dim3(grid), dim3(B), 0, st, a);
+    } else if (c->flags & WM_F_DC) hipLaunchKernelGGL(k2_clock_list<true>, dim3(grid), dim3(B), 0, st, a);
+    else hipLaunchKernelGGL(k2_clock_list<false>, dim3(grid), dim3(B), 0, st, a);
 }
 
 /* the fused launch: clock re-run list (scalar cnt_c) + run-length framer, all lanes (cnt_r == ~0) or its list */
@@ -732,19 +772,30 @@ static int enqueue_front_impl(wmbus_ctx *c, size_t nbytes)
         c->k1a = K1Args{g, c->d_dphi, c->d_rssi, c->d_lut, c->d_lut + 32 * WM_MAX_DECIM, c->d_ema_head, c->d_ema_tail, ntiles, c->d_scalars + SC_ERR,
                         nullptr, ema_carry(c, false), nullptr};
         static const int turns = getenv("WMBUS_K1_TURNS") ? atoi(getenv("WMBUS_K1_TURNS")) : 1;      /* 0: no order (A/B) */
+        static const int k1_shared = getenv("WMBUS_K1_STREAM") ? atoi(getenv("WMBUS_K1_STREAM")) : 1;   /* 0: order by events between the contexts' own streams (r03) */
         int rc;
         {
-            K1Chain &kc = k1_chain[c->cfg.device & 15];
+            K1Chain &kc = k1_chain[c->cfg.device];
             std::unique_lock<std::mutex> lk(kc.m, std::defer_lock);
-            if (turns) {
-                lk.lock();
-                if (kc.last && kc.owner != c) HIPCHK(c, hipStreamWaitEvent(c->stream, kc.last, 0));
+            if (turns) lk.lock();
+            if (turns && k1_shared) {
+                if (!kc.stream) HIPCHK(c, hipStreamCreateWithFlags(&kc.stream, hipStreamNonBlocking));
+                HIPCHK(c, hipEventRecord(c->ev_ready, c->stream));
+                HIPCHK(c, hipStreamWaitEvent(kc.stream, c->ev_ready, 0));
+                HIPCHK(c, hipEventRecord(c->ev[3], kc.stream));
+                rc = launch_k1_any(c, c->k1a, dim3(ntiles, c->S), kc.stream);
+                if (rc) return rc;
+                HIPCHK(c, hipEventRecord(c->ev[4], kc.stream));
+                HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev[4], 0));
+                kc.last = c->ev[4]; kc.owner = c;
+            } else {
+                if (turns && kc.last && kc.owner != c) HIPCHK(c, hipStreamWaitEvent(c->stream, kc.last, 0));
+                HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+                rc = launch_k1_any(c, c->k1a, dim3(ntiles, c->S));
+                if (rc) return rc;
+                HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+                if (turns) { kc.last = c->ev[4]; kc.owner = c; }
             }
-            HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-            rc = launch_k1_any(c, c->k1a, dim3(ntiles, c->S));
-            if (rc) return rc;
-            HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
-            if (turns) { kc.last = c->ev[4]; kc.owner = c; }
         }
         /* Everything behind K1 is enqueued while it runs -- no step of a push waits for the host any more:
          * hand-off verification makes its first rounds on the device (counters per round), K3 reads its item
@@ -776,6 +827,7 @@ static int enqueue_front_impl(wmbus_ctx *c, size_t nbytes)
         static const bool fuse = getenv("WMBUS_FUSE_FRAMERS") && atoi(getenv("WMBUS_FUSE_FRAMERS")) != 0;   /* tuning aid */
         const bool rla = c->flags & WM_F_RLA;
         c->fused = rla && !(c->flags & WM_F_DC) && fuse;
+        c->forked = false;
         HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
         fr_launch(c, WMBUS_ALGO_T2A, 0xFFFFFFFFu);                 /* the clock kernel's first pass */
         if (c->fused) {
@@ -787,6 +839,22 @@ static int enqueue_front_impl(wmbus_ctx *c, size_t nbytes)
                 fr_launch_fused(c, SC_CLK + r, r ? SC_RLA + r : 0xFFFFFFFFu);
             }
             HIPCHK(c, hipEventRecord(c->ev[8], c->stream));
+        } else if (rla && c->side_stream && !(c->flags & WM_F_DC)) {
+            /* Without the DC remover the slicer words are final after the clock kernel's FIRST pass (the sign of a soft
+             * symbol carries no state), so the run-length framer and its re-run round need not wait for the clock
+             * kernel's re-run rounds: they run beside them on the context's side stream, 4-5 ms off the context's chain
+             * of dependent launches. */
+            HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
+            HIPCHK(c, hipEventRecord(c->ev[9], c->side_stream));
+            fr_launch(c, WMBUS_ALGO_RLA, 0xFFFFFFFFu, c->side_stream);
+            for (unsigned r = 1; r < WM_FR_ROUNDS && opt_rounds; r++) { fr_verify(c, WMBUS_ALGO_RLA, SC_RLA + r, c->side_stream); fr_launch(c, WMBUS_ALGO_RLA, SC_RLA + r, c->side_stream); }
+            HIPCHK(c, hipEventRecord(c->ev[10], c->side_stream));
+            HIPCHK(c, hipEventRecord(c->ev_join, c->side_stream));
+            for (unsigned r = 0; r < WM_FR_ROUNDS && opt_rounds; r++) { fr_verify(c, WMBUS_ALGO_T2A, SC_CLK + r); fr_launch(c, WMBUS_ALGO_T2A, SC_CLK + r); }
+            HIPCHK(c, hipEventRecord(c->ev[8], c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+            c->forked = true;
         } else {
             for (unsigned r = 0; r < WM_FR_ROUNDS && opt_rounds; r++) { fr_verify(c, WMBUS_ALGO_T2A, SC_CLK + r); fr_launch(c, WMBUS_ALGO_T2A, SC_CLK + r); }
             HIPCHK(c, hipEventRecord(c->ev[8], c->stream));
@@ -1033,7 +1101,8 @@ static int wait_gpu(wmbus_ctx *c)
         hipEventElapsedTime(&ms, c->ev[3], c->ev[4]); c->tim.demod_ms = ms;
         hipEventElapsedTime(&ms, c->ev[2], c->ev[3]); c->tim.turn_wait_ms = ms;  /* on the GPU: behind the other contexts' demodulation kernels */
         hipEventElapsedTime(&ms, c->ev[0], c->ev[8]); c->tim.clock_ms = ms;      /* fused: every framer launch; else the clock kernel's */
-        hipEventElapsedTime(&ms, c->ev[8], c->ev[1]); c->tim.rla_ms = ms;        /* un-fused: the run-length framer's launches */
+        if (c->forked) { hipEventElapsedTime(&ms, c->ev[9], c->ev[10]); c->tim.rla_ms = ms; }   /* side stream: beside the clock kernel's re-run rounds */
+        else { hipEventElapsedTime(&ms, c->ev[8], c->ev[1]); c->tim.rla_ms = ms; }                /* un-fused: the run-length framer's launches */
         hipEventElapsedTime(&ms, c->ev[5], c->ev[6]); c->tim.gather_ms = ms;
         hipEventElapsedTime(&ms, c->ev[6], c->ev[7]); c->tim.d2h_ms = ms;
         hipEventElapsedTime(&ms, c->ev[2], c->ev[7]); c->tim.gpu_total_ms = ms;

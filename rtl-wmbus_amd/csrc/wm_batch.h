@@ -19,6 +19,7 @@ struct wmbus_batch {
     std::mutex out_lock, err_lock;
     std::atomic<bool> stop{false};
     int rc = 0;
+    bool opened = false;                                /* wmbus_batch_open succeeded: every planned context exists */
 };
 
 namespace {
@@ -51,6 +52,18 @@ void batch_worker(wmbus_batch *b, unsigned i, const wmbus_batch_io *io, BatchTot
     auto source = [&](int k) -> size_t {                    /* bytes of the next push (0: the input has ended), staged if host-sourced */
         if (b->stop.load()) return 0;
         if (!io->fill) { if (passes_left == 0) return 0; passes_left--; return io->resident_bytes; }
+        if (!io->self_staged && !b->slab[k][i]) {
+            /* Page-locked staging is allocated HERE, by the context's own thread when it first needs the slab: the driver
+             * pins one allocation at a time (16 GB for 1024 files of 8 MiB pushes: 2.4-3 s), so a batch that pinned
+             * everything before its first push spent longer setting up than decoding; now the first contexts decode while
+             * the others' slabs are still being pinned, and a context's second slab is pinned while its first push runs. */
+            hipSetDevice(b->cfg.device);
+            if (hipHostMalloc((void **)&b->slab[k][i], (size_t)S * pitch) != hipSuccess) {
+                b->slab[k][i] = nullptr;
+                batch_fail(b, WMBUS_ENOMEM, "batch: cannot allocate %zu bytes of page-locked staging", (size_t)S * pitch);
+                return 0;
+            }
+        }
         const size_t n = io->fill(io->user, s0, S, io->self_staged ? nullptr : b->slab[k][i], pitch, pitch);
         if (n == 0) return 0;
         if (n > pitch || n % WMBUS_BLOCK_BYTES) { batch_fail(b, WMBUS_EINVAL, "batch: the source returned %zu bytes (multiple of 4096, at most %zu)", n, pitch); return 0; }
@@ -141,6 +154,7 @@ int wmbus_batch_open(const wmbus_cfg *cfg, unsigned contexts, wmbus_batch **out)
 {
     if (!cfg || !out) return WMBUS_EINVAL;
     *out = nullptr;
+    wmbus_runtime_init();                                   /* hardware queues for the contexts' streams, if HIP has not started yet */
     wmbus_batch *b = new wmbus_batch();
     b->cfg = *cfg;
     *out = b;                                               /* the caller reads the message, then closes */
@@ -168,12 +182,13 @@ int wmbus_batch_open(const wmbus_cfg *cfg, unsigned contexts, wmbus_batch **out)
         at += n;
     }
     b->slab[0].assign(nctx, nullptr); b->slab[1].assign(nctx, nullptr);
+    b->opened = true;
     return WMBUS_OK;
 }
 
 static int batch_locate(wmbus_batch *b, unsigned stream, unsigned *i)
 {
-    if (!b || stream >= b->cfg.n_streams) return WMBUS_EINVAL;
+    if (!b || !b->opened || stream >= b->cfg.n_streams) return WMBUS_EINVAL;      /* a handle whose open failed has no contexts */
     unsigned k = 0;
     while (k + 1 < b->ctx.size() && stream >= b->first[k + 1]) k++;
     *i = k;
@@ -185,7 +200,7 @@ int wmbus_batch_stage(wmbus_batch *b, unsigned stream, const uint8_t *cu8, size_
     unsigned i;
     if (batch_locate(b, stream, &i)) return WMBUS_EINVAL;
     const int rc = wmbus_stage(b->ctx[i], stream - b->first[i], cu8, nbytes);
-    if (rc) snprintf(b->err, sizeof b->err, "batch: context %u: %s", i, b->ctx[i]->err);
+    if (rc) { std::lock_guard<std::mutex> lk(b->err_lock); snprintf(b->err, sizeof b->err, "batch: context %u: %s", i, b->ctx[i]->err); }
     return rc;
 }
 
@@ -200,22 +215,11 @@ int wmbus_batch_run(wmbus_batch *b, const wmbus_batch_io *io, wmbus_batch_stats 
 {
     if (!b || !io) return WMBUS_EINVAL;
     if (stats) memset(stats, 0, sizeof *stats);
+    if (!b->opened) return WMBUS_EINVAL;                    /* wmbus_batch_open failed: the handle only carries its message */
     { std::lock_guard<std::mutex> lk(b->err_lock); b->rc = 0; b->err[0] = 0; }
     b->stop.store(false);
     if (!io->fill && (io->resident_bytes == 0 || io->resident_bytes > b->cfg.max_push_bytes || io->resident_bytes % WMBUS_BLOCK_BYTES))
         return batch_fail(b, WMBUS_EINVAL, "batch: resident_bytes must be a positive multiple of 4096 and <= max_push_bytes");
-    if (io->fill && !io->self_staged) {
-        if (b->cfg.input_windows != 2) return batch_fail(b, WMBUS_EINVAL, "batch: a host-sourced run needs cfg.input_windows = 2");
-        for (unsigned i = 0; i < b->ctx.size(); i++)
-            for (int k = 0; k < 2; k++)
-                if (!b->slab[k][i]) {
-                    hipSetDevice(b->cfg.device);
-                    if (hipHostMalloc((void **)&b->slab[k][i], (size_t)b->count[i] * b->cfg.max_push_bytes) != hipSuccess) {
-                        b->slab[k][i] = nullptr;
-                        return batch_fail(b, WMBUS_ENOMEM, "batch: cannot allocate %zu bytes of page-locked staging", (size_t)b->count[i] * b->cfg.max_push_bytes);
-                    }
-                }
-    }
     if (io->fill && b->cfg.input_windows != 2) return batch_fail(b, WMBUS_EINVAL, "batch: a host-sourced run needs cfg.input_windows = 2");
     BatchTotals tot;
     const double t0 = now_ms();

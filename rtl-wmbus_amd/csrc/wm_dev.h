@@ -19,8 +19,10 @@
 #define WM_HIST_BYTES   4096u      /* input history kept in front of each push (2048 samples) */
 #define WM_IN_SLACK     256u       /* readable slack behind the staged bytes                  */
 #define WM_K1_HALO      48         /* decimated-sample halo: 45 FIR + 1 discriminator, >= EMA warm-up */
+#ifndef WM_EMA_WARMUP
 #define WM_EMA_WARMUP   32         /* EMA warm-up before a lane's run: trajectories coalesce bitwise within 23
                                       samples (measured); an uncertified hand-off is repaired exactly, not an error */
+#endif
 #define WM_K1_TILE2     976        /* K1 tile: tile + halo = 1024 = 256 threads x 4           */
 #ifndef WM_CLK_WPB
 #define WM_CLK_WPB      4          /* clock kernel: independent waves per block (see k2_clock) */

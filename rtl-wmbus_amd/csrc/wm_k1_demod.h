@@ -200,8 +200,9 @@ __device__ __forceinline__ void k1_stage_b(const K1Args &a, const int tid, const
          * signal: the true state decays through 90 more samples while a warm-up from zero is already
          * at zero).  One lane per chain runs the whole tile sequentially from the predecessor's exact
          * tail -- slow, exact, and only for the listed tiles. */
-        if (chT) k1_fir_t(a, yDrT, tid, stream, ts, tn);
-        if (chS) k1_fir_s(a, yDrS, tid, stream, ts, tn);
+        /* the soft symbols of the tile stay as the first pass wrote them: a repair concerns the RSSI filter only (and in
+         * tolerance mode a re-computed tile would mix the exact arithmetic of this kernel into the FMA low-pass's output:
+         * which tiles are repaired depends on the push size, the soft symbols must not -- ADVICE r3) */
         if (on && e == 0) {
             const float *mrow = ch ? yMgS : yMgT;
             float ema = tile ? a.ema_tail[ti - rows] : a.ema_carry[row];

@@ -259,6 +259,9 @@ __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t bloc
 #ifndef WM_CLK_EARLY_EXIT
 #define WM_CLK_EARLY_EXIT 1        /* 0: always eight trips through the chip loops of a block (the round-1 form; A/B) */
 #endif
+#ifndef WM_CLK_SR_WINDOW
+#define WM_CLK_SR_WINDOW 1024     /* 0: shift-register upkeep over the whole warm-up (the r03 form; A/B) */
+#endif
 #ifndef WM_CLK_PREFETCH
 #define WM_CLK_PREFETCH 2          /* blocks of loads in flight per lane; 1 = build-time experiment (32 VGPRs fewer) */
 #endif
@@ -294,7 +297,11 @@ __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t bloc
         uint32_t bitw, smask;
         if (LEAN) clk_block32_lean<DC>(s, c, xrow, bitw, smask); else clk_block32<DC>(s, c, xrow, bitw, smask);
         /* shift-register upkeep: at most 8 chips per block, oldest first; the wave stops as soon as none of its lanes
-         * has a chip left (T1/C1 lanes meet 4 per block, S1 lanes 1.3: half the trips of the fixed eight) */
+         * has a chip left (T1/C1 lanes meet 4 per block, S1 lanes 1.3: half the trips of the fixed eight).  The register
+         * is a function of the last 16 / 24 chips only, so the upkeep starts WM_CLK_SR_WINDOW samples before the segment
+         * (>= 40 chips of either chain at their nominal rates; if a stretch of silence leaves fewer, the hand-off does not
+         * certify and the segment is re-run, as after any other uncertified start) */
+        if (WM_CLK_SR_WINDOW && mb - m > (uint32_t)WM_CLK_SR_WINDOW) smask = 0u;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const bool has = smask != 0u;

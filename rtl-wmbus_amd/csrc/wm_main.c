@@ -32,7 +32,10 @@
 #include "wm_reader.h"
 #include "wmbus_hip.h"
 
-#define VERSION "rtl_wmbus_hip 0.1 (MI355X/gfx950 back end)"
+#define VERSION "rtl_wmbus_hip 0.4 (MI355X/gfx950 back end)"
+#ifndef COMMIT
+#define COMMIT "unknown"          /* the Makefile passes the repository's HEAD, like the reference's does (Makefile:16,38) */
+#endif
 
 static void print_usage(const char *prog)
 {
@@ -199,7 +202,7 @@ static int run_sharded(wmbus_cfg cfg, int n, char **names, const int *devs, int 
     if (per_ctx < 1) per_ctx = 1;
     if (per_ctx > 16) per_ctx = 16;
     if (cfg.host_threads == 0 && n_devs > 1) cfg.host_threads = per_ctx;
-    for (int k = 0; k < n_devs; k++) { jobs[k].cfg = cfg; jobs[k].cfg.device = devs[k]; jobs[k].names = calloc((size_t)n, sizeof(char *)); jobs[k].stats = stats; jobs[k].fast_exit = 1; }
+    for (int k = 0; k < n_devs; k++) { jobs[k].cfg = cfg; jobs[k].cfg.device = devs[k]; jobs[k].names = calloc((size_t)n, sizeof(char *)); jobs[k].stats = stats; jobs[k].fast_exit = !getenv("WMBUS_SLOW_EXIT"); }
     for (int i = 0; i < n; i++) {
         const int k = shard_slot(i, n_devs);
         jobs[k].names[jobs[k].n++] = names[i];
@@ -233,6 +236,7 @@ static int run_sharded(wmbus_cfg cfg, int n, char **names, const int *devs, int 
 static void finish(int rc)
 {
     fflush(stdout); fflush(stderr);
+    if (getenv("WMBUS_SLOW_EXIT")) exit(rc);             /* tests / leak checkers: every batch has been closed (run_batch), the runtime's exit handlers run */
     _exit(rc);
 }
 
@@ -279,6 +283,7 @@ static int live_push(void *user, const unsigned char *buf, size_t n)
 int main(int argc, char **argv)
 {
     if (argc == 1 && isatty(0)) { print_usage(argv[0]); return 0; }
+    wmbus_runtime_init();                                    /* before the first HIP call, before any thread exists */
 
     wmbus_cfg cfg;
     wmbus_default_cfg(&cfg);
@@ -301,7 +306,7 @@ int main(int argc, char **argv)
         case 'd': cfg.decimation = (unsigned)strtoul(optarg, NULL, 10); break;
         case 's': cfg.simultaneous = 1; break;
         case 'v': cfg.show_algorithm = 1; break;
-        case 'V': fprintf(stdout, "rtl_wmbus: " VERSION "\n"); return EXIT_SUCCESS;
+        case 'V': fprintf(stdout, "rtl_wmbus: " VERSION "\n"); fprintf(stdout, COMMIT "\n"); return EXIT_SUCCESS;    /* two lines: version, commit (rtl_wmbus.c:886-890) */
         case 'B': cfg.max_push_bytes = (size_t)strtoull(optarg, NULL, 10) / WMBUS_BLOCK_BYTES * WMBUS_BLOCK_BYTES; break;
         case 'G':
             n_devs = parse_devices(optarg, devs, 64);
@@ -322,6 +327,15 @@ int main(int argc, char **argv)
         }
     }
     if (getenv("WMBUS_FIXED_TS")) cfg.fixed_timestamp = 1;
+    /* -d is taken unchecked like the reference takes it (rtl_wmbus.c:950).  There `-d 0` keeps every sample, exactly like
+     * `-d 1` (the counter test at :1350-1352 is `++index < rate`), so that is what it means here; with -s it indexes a
+     * zero-length table in the reference (undefined behaviour) and is refused.  Rates above 16 (12.8 MS/s) do not fit the
+     * demodulation kernel's staging and are refused with a message instead of the usage text. */
+    if (cfg.decimation == 0 && !cfg.simultaneous) cfg.decimation = 1;
+    if (cfg.decimation == 0 || cfg.decimation > 16) {
+        fprintf(stderr, "rtl_wmbus_hip: -d %u: this back end decimates by 1..16 (-d 0 without -s is -d 1)\n", cfg.decimation);
+        return EXIT_FAILURE;
+    }
 
     if (optind < argc) {
         /* batch mode: 8 MiB per file and push (the headline configuration's push; -B overrides) */

@@ -23,7 +23,11 @@ int wm_reader_run(const wm_reader_cfg *cfg, wm_reader_push_fn push, void *user)
     unsigned char *buf = malloc(cfg->max_push);
     if (!buf) return WM_READER_ERROR;
     size_t have = 0;
-    long long t_first = 0, t_data = now_ms();      /* arrival of the oldest staged byte / of the newest byte */
+    unsigned long long total = 0;                  /* bytes read so far */
+    /* t_first: arrival of the oldest staged byte.  t_data: completion of the last whole 4096-byte block -- the reference
+     * arms alarm(2) around the fread of ONE block (rtl_wmbus.c:1300-1302), so a source that dribbles single bytes trips
+     * -f as soon as a block takes longer than the time-out, however regularly the bytes come */
+    long long t_first = 0, t_data = now_ms();
     int rc = WM_READER_EOF;
 
 #define PUSH_WHOLE_BLOCKS() do { \
@@ -58,11 +62,13 @@ int wm_reader_run(const wm_reader_cfg *cfg, wm_reader_push_fn push, void *user)
         const ssize_t n = read(cfg->fd, buf + have, cfg->max_push - have);
         if (n < 0) { if (errno == EINTR || errno == EAGAIN) continue; rc = WM_READER_ERROR; break; }
         if (n == 0) { PUSH_WHOLE_BLOCKS(); break; }            /* end of input: the partial tail is dropped */
-        t_data = now_ms();
-        if (have == 0) t_first = t_data;
+        const long long t_now = now_ms();
+        if ((total + (unsigned long long)n) / WM_BLOCK != total / WM_BLOCK) t_data = t_now;     /* a block has been completed */
+        total += (unsigned long long)n;
+        if (have == 0) t_first = t_now;
         have += (size_t)n;
         if (have == cfg->max_push) PUSH_WHOLE_BLOCKS();
-        else if (cfg->max_latency_ms && have >= WM_BLOCK && t_data - t_first >= (long long)cfg->max_latency_ms) PUSH_WHOLE_BLOCKS();
+        else if (cfg->max_latency_ms && have >= WM_BLOCK && t_now - t_first >= (long long)cfg->max_latency_ms) PUSH_WHOLE_BLOCKS();
     }
 out:
     free(buf);

@@ -29,8 +29,8 @@ typedef struct wm_reader_cfg {
 
 enum { WM_READER_EOF = 0, WM_READER_FLOW_STOPPED = 1, WM_READER_ERROR = -1, WM_READER_PUSH_FAILED = -2 };
 
-/* Runs until end of input (WM_READER_EOF), until no byte has arrived for flow_timeout_ms (WM_READER_FLOW_STOPPED: the
- * staged blocks have been pushed first), or until an error. */
+/* Runs until end of input (WM_READER_EOF), until no whole 4096-byte block has been completed for flow_timeout_ms
+ * (WM_READER_FLOW_STOPPED: the staged blocks have been pushed first), or until an error. */
 int wm_reader_run(const wm_reader_cfg *cfg, wm_reader_push_fn push, void *user);
 
 #ifdef __cplusplus

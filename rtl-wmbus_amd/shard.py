@@ -47,9 +47,12 @@ class FileGroup:
     that concurrent jobs do not meet).  O(world) files per operation; meant for a handful of scalars per run."""
     backend = "none"
 
-    def __init__(self, rank, world, root=None, timeout_s=600.0):
+    def __init__(self, rank, world, root=None, timeout_s=600.0, tag=""):
         self.rank, self.world, self.timeout_s, self.seq = rank, world, timeout_s, 0
-        key = f"wmbus_group_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('WMBUS_GROUP_TAG', os.getppid())}"
+        # one directory per launch: the launcher's nonce (bench.py's own spawner sets WMBUS_GROUP_TAG, torchrun its run id) or,
+        # failing that, port + parent pid -- files a crashed run left behind are not met again
+        nonce = os.environ.get('WMBUS_GROUP_TAG') or f"{os.environ.get('TORCHELASTIC_RUN_ID', '')}{os.getppid()}"
+        key = f"wmbus_group{tag}_{os.environ.get('MASTER_PORT', '0')}_{nonce}"
         self.dir = os.path.join(root or ("/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()), key)
         os.makedirs(self.dir, exist_ok=True)
 
@@ -131,10 +134,18 @@ def init(world, local_rank, backend=None, rank=None, force=False):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         except Exception:                                    # no torch at all: files
             backend = "none"
+    # The ranks AGREE on the transport (decided rank by rank, one rank could sit in gloo while the others still
+    # waited in RCCL's 120 s all-reduce, or a mixed torch / file world could form): after every attempt each rank casts its
+    # result through a small file group -- which always works on one node -- and a backend is taken only if it came up on
+    # every rank; otherwise all of them tear it down and try the next one together.
+    votes = FileGroup(rank, world, tag="init") if world > 1 else None
     last = None
     for b in order.get(backend, [backend]):
         if b == "none":
+            if votes is not None:
+                votes.destroy()
             return FileGroup(rank, world)
+        ok, grp = True, None
         try:
             import datetime
             import torch
@@ -150,10 +161,21 @@ def init(world, local_rank, backend=None, rank=None, force=False):
                 torch.cuda.synchronize()
             else:
                 dist.init_process_group(b, timeout=datetime.timedelta(seconds=300))
-            return TorchGroup(dist, b)
+            grp = TorchGroup(dist, b)
         except Exception as e:                               # noqa: BLE001 -- any failure means "try the next transport"
-            last = e
+            ok, last = False, e
             print(f"shard.init: backend {b} failed on rank {rank} ({e!r}); falling back", file=sys.stderr, flush=True)
+        everyone = all(votes.all_gather(bool(ok))) if votes is not None else ok
+        if everyone:
+            if votes is not None:
+                votes.destroy()
+            return grp
+        if ok:                                               # it came up here but not everywhere: leave it together
+            try:
+                grp.destroy()
+            except Exception:                                # noqa: BLE001
+                pass
+            print(f"shard.init: backend {b} is up on rank {rank} but not on every rank; falling back with the others", file=sys.stderr, flush=True)
     raise RuntimeError(f"no process-group backend could be initialised: {last!r}")
 
 

@@ -58,9 +58,23 @@ def test_cli_usage_and_exit_codes(wm):
     p = subprocess.run([wm.CLI_PATH, "-h"], capture_output=True, text=True, stdin=subprocess.DEVNULL)
     assert p.returncode == 1 and "Usage" in p.stdout and "-p [T,S]" in p.stdout
     p = subprocess.run([wm.CLI_PATH, "-V"], capture_output=True, text=True, stdin=subprocess.DEVNULL)
-    assert p.returncode == 0 and p.stdout.startswith("rtl_wmbus:")
+    assert p.returncode == 0 and p.stdout.startswith("rtl_wmbus:") and len(p.stdout.splitlines()) == 2      # version, commit (rtl_wmbus.c:886-890)
+    p = subprocess.run([wm.CLI_PATH, "-d", "17"], capture_output=True, text=True, stdin=subprocess.DEVNULL)
+    assert p.returncode == 1 and "1..16" in p.stderr
+    p = subprocess.run([wm.CLI_PATH, "-d", "0", "-s"], capture_output=True, text=True, stdin=subprocess.DEVNULL)
+    assert p.returncode == 1
     p = subprocess.run([wm.CLI_PATH, "-r", "1"], capture_output=True, text=True, stdin=subprocess.DEVNULL)
     assert p.returncode == 1
+
+
+def test_loading_the_library_leaves_the_environment_alone(wm):
+    """no setenv behind the host application's back at dlopen; wmbus_runtime_init() is the explicit call."""
+    import subprocess, sys
+    code = ("import ctypes, os; os.environ.pop('GPU_MAX_HW_QUEUES', None); L = ctypes.CDLL(%r); "
+            "a = os.environ.get('GPU_MAX_HW_QUEUES'); g = ctypes.CDLL(None).getenv; g.restype = ctypes.c_char_p; b = g(b'GPU_MAX_HW_QUEUES'); "
+            "L.wmbus_runtime_init(); c = g(b'GPU_MAX_HW_QUEUES'); print(a, b, c)" % wm.LIB_PATH)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert p.stdout.split() == ["None", "None", "b'16'"], p.stdout + p.stderr
 
 
 def test_synth_is_deterministic(wm):

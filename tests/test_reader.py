@@ -100,6 +100,26 @@ def test_flow_timeout_pushes_the_staged_blocks_first(reader):
     assert 0.25 < got[-1][0] - t0 < 0.95
 
 
+def test_flow_timeout_counts_whole_blocks_not_bytes(reader):
+    """the reference arms alarm(2) around the fread of ONE 4096-byte block (rtl_wmbus.c:1300-1302), so a source
+    that dribbles single bytes -- never silent for long, never completing a block -- trips -f all the same."""
+    t0 = time.monotonic()
+
+    def feed(w):
+        os.write(w, os.urandom(4096 * 2))
+        try:
+            for _ in range(12):                                   # one byte every 100 ms: no 300 ms without data
+                time.sleep(0.1)
+                os.write(w, b"x")
+        except OSError:
+            pass
+        os.close(w)
+    rc, got = run(reader, feed, 1 << 20, 0, flow=300)
+    assert rc == 1
+    assert sum(len(b) for _, b in got) == 4096 * 2
+    assert 0.25 < got[-1][0] - t0 < 0.9
+
+
 def test_a_failing_push_stops_the_reader(reader):
     def feed(w):
         try:

@@ -28,8 +28,29 @@ def test_bench_dry_run_shards_and_reduces(backend, n):
     for a, b in zip(ranges, ranges[1:]):
         assert a[1] + 1 == b[0]                               # disjoint, contiguous: no capture twice, none skipped
     assert r["elapsed_s"] >= 0.01 * n                         # max over ranks of what each rank measured
+    # the parity sampling of a real run (bench.first_pass_picks / last_pass_picks): the node's oracle work does not grow with
+    # the rank count -- 1024 first-pass captures and >= 128 last-pass captures over ALL ranks, every context of every rank sampled
+    per_rank = r["parity_picks_per_rank"]
+    assert len(per_rank) == n and r["parity_picks_total"][0] in range(1024, 1024 + n) and all(c[0] in (1024 // n, 1024 // n + 1) for c in per_rank)
+    assert all(c[1] >= 16 for c in per_rank) and 128 <= r["parity_picks_total"][1] <= 16 * n + 128
+    assert r["generator_threads_per_rank"] * n <= max(os.cpu_count() or 1, n)
+    assert r["oracle_estimate_s"]["first_pass"] > 0 and r["oracle_estimate_s"]["last_pass"] > 0
     cpus = os.cpu_count() or 16
     assert n * r["contexts_per_gpu"] * r["host_threads_per_context"] <= max(cpus, n * r["contexts_per_gpu"])
+
+
+def test_parity_picks_cover_every_context():
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    plan = [(128 * i, 128) for i in range(8)]
+    one = bench.last_pass_picks(plan, 1)
+    assert len(one) == 128 and len(set(one)) == 128 and all(any(f <= s < f + c for s in one) for f, c in plan)
+    eight = bench.last_pass_picks(plan, 8)
+    assert len(eight) == 16 and all(sum(f <= s < f + c for s in eight) == 2 for f, c in plan)      # one per 64-capture wave
+    assert bench.last_pass_picks([(0, 1)], 1) == [0] and bench.last_pass_picks([(0, 70)], 1, per_wave=2) == [0, 63, 64, 69]
+    assert bench.first_pass_picks(1024, 0, 1) == list(range(1024))
+    got = sorted(s for r in range(8) for s in bench.first_pass_picks(1024, r, 8))
+    assert got == list(range(1024))                           # over the ranks every residue is taken once: 128 per rank
 
 
 def test_host_threads_stay_within_the_box():
