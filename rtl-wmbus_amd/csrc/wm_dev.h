@@ -4,9 +4,15 @@
  *
  * HBM layout (per context, S = n_streams, chain c in {T1C1, S1}, algo a in {RLA, T2A}):
  *   in     u8   [S][HIST_BYTES + max_push_bytes + SLACK]   cu8; HIST = tail of the previous push
- *   dphi   f32  [2][S][Mcap]      soft symbol (FIR output), one per decimated sample
- *   rssi   u8   [2][S][Mcap]      (unsigned) of the filtered magnitude
- *   bits   u32  [2][S][Mcap/32]   slicer output, bit j of word w = sample 32w+j
+ *   dphi   f32  [2][NG][Mcap/8][GW][8]   soft symbol (FIR output), one per decimated sample.  WAVE-TRANSPOSED: captures come
+ *                                 in groups of GW (64; fewer only when the batch has fewer), and the 8 samples (one 32-byte
+ *                                 sector) of the GW captures of a group at one time lie side by side -- the framer lanes of a
+ *                                 wave are GW consecutive captures at the SAME time, so a wave reads 2 KB in one piece with a
+ *                                 lane-private 32-byte load each (round 3: capture-major rows, cooperative line loads and a
+ *                                 transpose through 36 KB of LDS per block); K1 writes whole sectors (two lanes each)
+ *   rssi   u8   [2][S][Mcap]      (unsigned) of the filtered magnitude (capture-major: read per chip, by position)
+ *   bits   u32  [2][NG][Mcap/32][GW]     slicer output, bit j of word w = sample 32w+j; same grouping: one coalesced 256-byte
+ *                                 store / load per wave and 32 samples, no staging
  *   chips  u32  [2][2][S][nseg][cap_a]  per time segment; word = pos<<3 | value (bit, sync, reset); the RSSI of
  *                                       a chip is rssi[row][sample of the chip] (K3 / K4 insert it into bits 15:8)
  *   state arrays, burst arena (see structs below)
@@ -107,7 +113,35 @@ struct WmPush {
     uint32_t s1_span;        /* 2: an S1 clock lane covers two consecutive segments (its warm-up is twice T1/C1's, so at the
                                 same segment length it re-reads 75 % instead of 37 %); 0 / 1: one segment per lane */
     WmSpill sp;              /* run-length chips beyond cap[0]                        */
+    uint32_t GW, NG;         /* capture groups of the wave-transposed arrays (dphi, bits): GW captures each (a power of two
+                                <= 64), NG = ceil(S / GW) of them */
 };
+
+/* Group geometry for S captures: 64 per group, or the next power of two >= S for a smaller batch. */
+static inline void wm_group_geometry(uint32_t S, uint32_t *gw, uint32_t *ng)
+{
+    uint32_t w = 64u;
+    if (S < 64u) { w = 1u; while (w < S) w *= 2u; }
+    *gw = w; *ng = (S + w - 1u) / w;
+}
+/* Soft symbol t of capture s, chain ch (element index into dphi): sector (t / 8) of the capture's group, the capture's slot
+ * in it, sample t % 8.  The 8-sample sector of a capture at one time is contiguous; so are the GW sectors of a group. */
+#ifndef WM_HD
+#if defined(__HIPCC__)
+#define WM_HD __host__ __device__ __forceinline__
+#else
+#define WM_HD static inline
+#endif
+#endif
+WM_HD uint64_t wm_dphi_index(const WmPush &g, uint32_t ch, uint32_t s, uint32_t t)
+{
+    return ((((uint64_t)ch * g.NG + s / g.GW) * (g.Mcap / 8u) + t / 8u) * g.GW + s % g.GW) * 8u + t % 8u;
+}
+/* Slicer word w (samples 32 w .. 32 w + 31) of capture s, chain ch (element index into bits). */
+WM_HD uint64_t wm_bits_index(const WmPush &g, uint32_t ch, uint32_t s, uint32_t w)
+{
+    return (((uint64_t)ch * g.NG + s / g.GW) * (g.Mcap / 32u) + w) * g.GW + s % g.GW;
+}
 
 enum {
     WM_F_SHIFT = 1, WM_F_ACCURATE = 2, WM_F_DC = 4, WM_F_T1C1 = 8, WM_F_S1 = 16,
