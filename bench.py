@@ -186,15 +186,18 @@ def leg_c3_batch(wm, O, shard, S, n, device, steps):
         want = O.run_many([caps[s_] for s_ in picks], O.make_opts(decimation=5, simultaneous=1))
         bad = [s_ for s_, w in zip(picks, want) if "".join(per[s_]) != w]
         b.run_resident(2 * n, 2)
+        tims = []
         t0 = time.perf_counter()
-        b.run_resident(2 * n, steps)
+        b.run_resident(2 * n, steps, lambda _f, _c, _l, tm: tims.append(tm), want_lines=False)
         dt = time.perf_counter() - t0
         alone = []
         for rx, _f, _c in b.contexts:
             rx.process(2 * n); rx.collect(); alone.append(rx.timing()["demod_ms"])
         spl = S * n / len(b.contexts)
         k1 = sum(alone) / len(alone)
-        return {"workload": f"{S} captures x {n} IQ samples at 4.0 MS/s, -d 5 -s, T1 + C1 at +325 kHz and S1 at -325 kHz, HBM-resident",
+        mean = {k: round(sum(t[k] for t in tims) / max(1, len(tims)), 3) for k in ("turn_wait_ms", "demod_ms", "clock_ms", "rla_ms", "gather_ms", "gpu_total_ms", "host_decode_ms",
+                                                                                  "clock_reruns", "rla_reruns", "ema_retries", "slow_path")}
+        return {"stage_ms_mean_per_context_push": mean,"workload": f"{S} captures x {n} IQ samples at 4.0 MS/s, -d 5 -s, T1 + C1 at +325 kHz and S1 at -325 kHz, HBM-resident",
                 "value": round(S * n * steps / dt / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps,
                 "contexts_per_gpu": len(b.contexts), "kernel": "k1_demod2<5, true, false, false>", "k1_alone_ms": round(k1, 3),
                 "k1_hbm_frac": round(BYTES_PER_SAMPLE * spl / (k1 / 1e3) / 1e9 / HBM_PEAK_GBPS, 4),

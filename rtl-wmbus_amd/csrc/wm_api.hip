@@ -143,6 +143,7 @@ struct wmbus_ctx {
     size_t zero_words = 0;
     uint32_t *d_sync_seen[2] = {};                      /* per framer: [2][S][nseg_cap] access-code chip seen in region */
     uint32_t *d_spill = nullptr, *d_chain = nullptr, *d_nchain = nullptr; uint32_t spill_words = 0;   /* WmSpill (wm_dev.h) */
+    unsigned ema_rounds = 1, fr_rounds = 2;             /* hand-off rounds enqueued unattended, see WM_MAX_ROUNDS */
     bool poisoned = false, gpu_decode = true;                              /* an internal error left the carried state undefined */
     uint32_t *d_first_bad = nullptr;                    /* [2][S] first uncertified EMA tile of a row, or ~0 */
     uint32_t *d_ckpt = nullptr; uint32_t nck = 0;       /* clock kernel checkpoints [2][S][nseg_cap][nck][16] */
@@ -194,12 +195,16 @@ template <typename T> hipError_t dalloc(T **p, size_t n) { return hipMalloc((voi
  * with a fixed grid -> verify ..., each round with its own counter; the host only looks at the last counters when it
  * collects the push and finishes the (rare) leftovers round by round. */
 enum { WM_MAX_DEVICES = 64 };                    /* per-device tables (K1 order, kernel attributes); wmbus_open refuses ordinals beyond */
-enum { WM_EMA_ROUNDS = 1, WM_FR_ROUNDS = 2 };   /* bench workload: clock re-runs 1400, then < 10, then 0; run-length 2300, then 0 */
+/* How many: wmbus_ctx.ema_rounds / fr_rounds.  A batch of whole waves enqueues one RSSI round and two framer rounds (bench
+ * workload: clock re-runs 1400, then < 10, then 0; run-length 2300, then 0; a third costs every push 0.2 ms of empty launches).
+ * A small batch is bound by its chain of dependent launches and by every host round trip in it, and its short segments
+ * (wmbus_open) cascade further: it enqueues more rounds, so that the host-driven path (0.5 ms per round) stays the exception. */
+enum { WM_MAX_ROUNDS = 6 };                     /* counters per kind: rounds + 1 <= 8 (SC_* below) */
 /* debugging aid: WMBUS_OPT_ROUNDS=0 skips the unattended re-run launches (the counters of the rounds stay zero), so
  * that every hand-off failure is finished by the host-driven path */
 static const bool opt_rounds = !(getenv("WMBUS_OPT_ROUNDS") && atoi(getenv("WMBUS_OPT_ROUNDS")) == 0);
 enum { SC_ERR = 0, SC_NHITS = 1, SC_NHDR = 2, SC_NWORDS = 3, SC_NPKTS = 4, SC_NBYTES = 5, SC_SLOW = 6, SC_CHIPS = 8 /* [algo][chain] */,
-       SC_EMA = 16 /* [WM_EMA_ROUNDS + 1] */, SC_CLK = 24 /* [WM_FR_ROUNDS + 1] */, SC_RLA = 32 /* [WM_FR_ROUNDS + 1] */, SC_COUNT = 40 };
+       SC_EMA = 16 /* [ema_rounds + 1] */, SC_CLK = 24 /* [fr_rounds + 1] */, SC_RLA = 32 /* [fr_rounds + 1] */, SC_COUNT = 40 };
 
 /* 4096 bytes per capture from src + row * sstride + soff to dst + row * dstride (256 threads x 16 bytes).  The input
  * history: the last 4096 staged bytes of a push are put aside (d_hist) when the push is enqueued and placed in front of
@@ -419,6 +424,8 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
                (cfg->simultaneous ? WM_F_SHIFT : 0) | (cfg->accurate_atan ? WM_F_ACCURATE : 0) | (cfg->remove_dc ? WM_F_DC : 0) |
                (cfg->t1c1_enabled ? WM_F_T1C1 : 0) | (cfg->s1_enabled ? WM_F_S1 : 0) | (cfg->rla_enabled ? WM_F_RLA : 0) |
                (cfg->time2_enabled ? WM_F_T2A : 0);
+    if (c->S < 64u) { c->ema_rounds = 2; c->fr_rounds = 5; }
+    if (const char *r_ = getenv("WMBUS_FR_ROUNDS")) c->fr_rounds = std::min<unsigned>(std::max(1, atoi(r_)), WM_MAX_ROUNDS);      /* tuning aid */
     c->T = (uint32_t)WM_K1_TILE2;
     const uint32_t T = c->T;
     const uint64_t max_samples = cfg->max_push_bytes / 2;
@@ -438,7 +445,7 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
 
     const uint64_t rows = 2ull * c->S;
     wm_group_geometry(c->S, &c->GW, &c->NG);
-    const uint64_t trows = 2ull * c->NG * c->GW;          /* capture slots of the wave-transposed arrays (dphi, bits) */
+    const uint64_t trows = 2ull * c->NG * c->GW;          /* capture slots of the wave-transposed slicer words */
     hipError_t e = hipSuccess;
     auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
     A(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -463,7 +470,7 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
     }
     A(dalloc(&c->d_in, (size_t)c->in_stride * c->S * c->n_win));
     A(dalloc(&c->d_hist, (size_t)WM_HIST_BYTES * c->S));
-    A(dalloc(&c->d_dphi, (size_t)trows * c->Mcap));
+    A(dalloc(&c->d_dphi, (size_t)rows * c->Mcap));
     A(dalloc(&c->d_rssi, (size_t)rows * c->Mcap));
     A(dalloc(&c->d_bits, (size_t)trows * (c->Mcap / 32)));
     A(dalloc(&c->d_lut, (size_t)2 * 32 * WM_MAX_DECIM));
@@ -763,7 +770,7 @@ static int enqueue_front_impl(wmbus_ctx *c, size_t nbytes)
         const uint32_t T = c->T, ntiles = (g.M + T - 1) / T;
         c->ntiles = ntiles;
         c->k1a = K1Args{g, c->d_dphi, c->d_rssi, c->d_lut, c->d_lut + 32 * WM_MAX_DECIM, c->d_ema_head, c->d_ema_tail, ntiles, c->d_scalars + SC_ERR,
-                        nullptr, ema_carry(c, false), nullptr, (c->S % 4u) == 0u ? 2u : 0u};
+                        nullptr, ema_carry(c, false), nullptr};
         static const int turns = getenv("WMBUS_K1_TURNS") ? atoi(getenv("WMBUS_K1_TURNS")) : 1;      /* 0: no order (A/B) */
         static const int k1_shared = getenv("WMBUS_K1_STREAM") ? atoi(getenv("WMBUS_K1_STREAM")) : 0;   /* 1: one shared stream carries every context's K1 (r04 A/B: -13 %) */
         int rc;
@@ -776,7 +783,7 @@ static int enqueue_front_impl(wmbus_ctx *c, size_t nbytes)
                 HIPCHK(c, hipEventRecord(c->ev_ready, c->stream));
                 HIPCHK(c, hipStreamWaitEvent(kc.stream, c->ev_ready, 0));
                 HIPCHK(c, hipEventRecord(c->ev[3], kc.stream));
-                rc = launch_k1_any(c, c->k1a, dim3(ntiles << c->k1a.sx, c->S >> c->k1a.sx), kc.stream);
+                rc = launch_k1_any(c, c->k1a, dim3(ntiles, c->S), kc.stream);
                 if (rc) return rc;
                 HIPCHK(c, hipEventRecord(c->ev[4], kc.stream));
                 HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev[4], 0));
@@ -784,7 +791,7 @@ static int enqueue_front_impl(wmbus_ctx *c, size_t nbytes)
             } else {
                 if (turns && kc.last && kc.owner != c) HIPCHK(c, hipStreamWaitEvent(c->stream, kc.last, 0));
                 HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-                rc = launch_k1_any(c, c->k1a, dim3(ntiles << c->k1a.sx, c->S >> c->k1a.sx));
+                rc = launch_k1_any(c, c->k1a, dim3(ntiles, c->S));
                 if (rc) return rc;
                 HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
                 if (turns) { kc.last = c->ev[4]; kc.owner = c; }
@@ -793,12 +800,12 @@ static int enqueue_front_impl(wmbus_ctx *c, size_t nbytes)
         /* Everything behind K1 is enqueued while it runs -- no step of a push waits for the host any more:
          * hand-off verification makes its first rounds on the device (counters per round), K3 reads its item
          * count there, the results land in pinned host memory.  wmbus_collect looks at the last counters. */
-        for (unsigned r = 0; r < WM_EMA_ROUNDS && opt_rounds; r++) {
+        for (unsigned r = 0; r < c->ema_rounds && opt_rounds; r++) {
             ema_verify(c, SC_EMA + r);
             rc = ema_repair(c, SC_EMA + r);
             if (rc) return rc;
         }
-        ema_verify(c, SC_EMA + WM_EMA_ROUNDS);
+        ema_verify(c, SC_EMA + c->ema_rounds);
         ema_commit(c);
 
         /* K2: clock recovery + time2 framer (also produces the slicer bits the RLA needs) */
@@ -827,23 +834,23 @@ static int enqueue_front_impl(wmbus_ctx *c, size_t nbytes)
             HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
             HIPCHK(c, hipEventRecord(c->ev[9], c->side_stream));
             fr_launch(c, WMBUS_ALGO_RLA, 0xFFFFFFFFu, c->side_stream);
-            for (unsigned r = 1; r < WM_FR_ROUNDS && opt_rounds; r++) { fr_verify(c, WMBUS_ALGO_RLA, SC_RLA + r, c->side_stream); fr_launch(c, WMBUS_ALGO_RLA, SC_RLA + r, c->side_stream); }
+            for (unsigned r = 1; r < c->fr_rounds && opt_rounds; r++) { fr_verify(c, WMBUS_ALGO_RLA, SC_RLA + r, c->side_stream); fr_launch(c, WMBUS_ALGO_RLA, SC_RLA + r, c->side_stream); }
             HIPCHK(c, hipEventRecord(c->ev[10], c->side_stream));
             HIPCHK(c, hipEventRecord(c->ev_join, c->side_stream));
-            for (unsigned r = 0; r < WM_FR_ROUNDS && opt_rounds; r++) { fr_verify(c, WMBUS_ALGO_T2A, SC_CLK + r); fr_launch(c, WMBUS_ALGO_T2A, SC_CLK + r); }
+            for (unsigned r = 0; r < c->fr_rounds && opt_rounds; r++) { fr_verify(c, WMBUS_ALGO_T2A, SC_CLK + r); fr_launch(c, WMBUS_ALGO_T2A, SC_CLK + r); }
             HIPCHK(c, hipEventRecord(c->ev[8], c->stream));
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
             c->forked = true;
         } else {
-            for (unsigned r = 0; r < WM_FR_ROUNDS && opt_rounds; r++) { fr_verify(c, WMBUS_ALGO_T2A, SC_CLK + r); fr_launch(c, WMBUS_ALGO_T2A, SC_CLK + r); }
+            for (unsigned r = 0; r < c->fr_rounds && opt_rounds; r++) { fr_verify(c, WMBUS_ALGO_T2A, SC_CLK + r); fr_launch(c, WMBUS_ALGO_T2A, SC_CLK + r); }
             HIPCHK(c, hipEventRecord(c->ev[8], c->stream));
             if (rla) {
                 fr_launch(c, WMBUS_ALGO_RLA, 0xFFFFFFFFu);
-                for (unsigned r = 1; r < WM_FR_ROUNDS && opt_rounds; r++) { fr_verify(c, WMBUS_ALGO_RLA, SC_RLA + r); fr_launch(c, WMBUS_ALGO_RLA, SC_RLA + r); }
+                for (unsigned r = 1; r < c->fr_rounds && opt_rounds; r++) { fr_verify(c, WMBUS_ALGO_RLA, SC_RLA + r); fr_launch(c, WMBUS_ALGO_RLA, SC_RLA + r); }
             } else HIPCHK(c, hipMemsetAsync(c->d_counts[0], 0, (size_t)2 * c->S * c->nseg_cap[0] * sizeof(uint32_t), c->stream));
         }
-        fr_verify(c, WMBUS_ALGO_T2A, SC_CLK + WM_FR_ROUNDS);
-        if (rla) fr_verify(c, WMBUS_ALGO_RLA, SC_RLA + WM_FR_ROUNDS);
+        fr_verify(c, WMBUS_ALGO_T2A, SC_CLK + c->fr_rounds);
+        if (rla) fr_verify(c, WMBUS_ALGO_RLA, SC_RLA + c->fr_rounds);
         HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
         fr_carry(c);
         c->committed = true;
@@ -915,7 +922,7 @@ static int finish_slowly(wmbus_ctx *c, bool ema_left, bool clk_left, bool rla_le
     };
     const uint32_t max_rounds = std::max({c->ntiles, c->last.nseg[0], c->last.nseg[1]}) + 4;
     if (ema_left) {
-        uint32_t cnt = SC_EMA + WM_EMA_ROUNDS, n = 0;          /* the list of the last verify is still in d_list_ema */
+        uint32_t cnt = SC_EMA + c->ema_rounds, n = 0;          /* the list of the last verify is still in d_list_ema */
         for (uint32_t round = 0;; round++) {
             c->tim.ema_retries += c->h_scalars[cnt];
             int rc = ema_repair(c, cnt);
@@ -931,7 +938,7 @@ static int finish_slowly(wmbus_ctx *c, bool ema_left, bool clk_left, bool rla_le
     }
     for (int algo = 1; algo >= 0; algo--) {                    /* clock first: with -o the slicer words depend on it */
         if (!(algo ? clk_left : rla_left)) continue;
-        uint32_t cnt = (algo ? SC_CLK : SC_RLA) + WM_FR_ROUNDS, n = 0;
+        uint32_t cnt = (algo ? SC_CLK : SC_RLA) + c->fr_rounds, n = 0;
         for (uint32_t round = 0;; round++) {
             (algo ? c->tim.clock_reruns : c->tim.rla_reruns) += c->h_scalars[cnt];
             fr_launch(c, algo, cnt);
@@ -946,11 +953,11 @@ static int finish_slowly(wmbus_ctx *c, bool ema_left, bool clk_left, bool rla_le
         if (algo == 1 && (c->flags & WM_F_DC) && (c->flags & WM_F_RLA)) {
             /* the run-length framer ran on slicer words that the clock re-runs have just replaced: all of it again */
             fr_launch(c, WMBUS_ALGO_RLA, 0xFFFFFFFFu);
-            hipLaunchKernelGGL(k_copy_word, dim3(1), dim3(1), 0, c->stream, c->d_scalars + SC_RLA + WM_FR_ROUNDS, 0u);
-            fr_verify(c, WMBUS_ALGO_RLA, SC_RLA + WM_FR_ROUNDS);
+            hipLaunchKernelGGL(k_copy_word, dim3(1), dim3(1), 0, c->stream, c->d_scalars + SC_RLA + c->fr_rounds, 0u);
+            fr_verify(c, WMBUS_ALGO_RLA, SC_RLA + c->fr_rounds);
             HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, SC_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
-            rla_left = c->h_scalars[SC_RLA + WM_FR_ROUNDS] != 0;
+            rla_left = c->h_scalars[SC_RLA + c->fr_rounds] != 0;
         }
     }
     fr_carry(c);
@@ -1086,9 +1093,9 @@ static int wait_gpu(wmbus_ctx *c)
         hipEventElapsedTime(&ms, c->ev[6], c->ev[7]); c->tim.d2h_ms = ms;
         hipEventElapsedTime(&ms, c->ev[2], c->ev[7]); c->tim.gpu_total_ms = ms;
         const uint32_t *hs = c->h_scalars;
-        for (unsigned r = 0; r < WM_EMA_ROUNDS; r++) c->tim.ema_retries += hs[SC_EMA + r];
-        for (unsigned r = 0; r < WM_FR_ROUNDS; r++) { c->tim.clock_reruns += hs[SC_CLK + r]; c->tim.rla_reruns += hs[SC_RLA + r]; }
-        const bool ema_left = hs[SC_EMA + WM_EMA_ROUNDS], clk_left = hs[SC_CLK + WM_FR_ROUNDS], rla_left = hs[SC_RLA + WM_FR_ROUNDS];
+        for (unsigned r = 0; r < c->ema_rounds; r++) c->tim.ema_retries += hs[SC_EMA + r];
+        for (unsigned r = 0; r < c->fr_rounds; r++) { c->tim.clock_reruns += hs[SC_CLK + r]; c->tim.rla_reruns += hs[SC_RLA + r]; }
+        const bool ema_left = hs[SC_EMA + c->ema_rounds], clk_left = hs[SC_CLK + c->fr_rounds], rla_left = hs[SC_RLA + c->fr_rounds];
         static const bool dbg_rounds = getenv("WMBUS_DEBUG_ROUNDS") != nullptr;
         if (dbg_rounds)
             fprintf(stderr, "rounds: ema %u %u | clock %u %u %u %u | rla %u %u %u %u\n", hs[SC_EMA], hs[SC_EMA + 1], hs[SC_CLK], hs[SC_CLK + 1], hs[SC_CLK + 2],
@@ -1239,11 +1246,7 @@ long wmbus_read_tap(wmbus_ctx *c, const char *what, int chain, unsigned stream, 
     const size_t n = std::min<size_t>(max_elems, c->last.M);
     const size_t row = (size_t)chain * c->S + stream;
     if (!strcmp(what, "dphi")) {
-        /* wave-transposed (wm_dphi_index): the capture's 32-byte sectors lie GW sectors apart */
-        std::vector<float> tmp((n + 7) / 8 * 8);
-        if (hipMemcpy2D(tmp.data(), 32, c->d_dphi + wm_dphi_index(c->last, (uint32_t)chain, stream, 0u), (size_t)c->GW * 32, 32, tmp.size() / 8, hipMemcpyDeviceToHost) != hipSuccess)
-            return WMBUS_EDEVICE;
-        memcpy(dst, tmp.data(), n * sizeof(float));
+        if (hipMemcpy(dst, c->d_dphi + wm_dphi_index(c->last, (uint32_t)chain, stream, 0u), n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return WMBUS_EDEVICE;
     } else if (!strcmp(what, "rssi")) {
         if (hipMemcpy(dst, c->d_rssi + row * c->Mcap, n, hipMemcpyDeviceToHost) != hipSuccess) return WMBUS_EDEVICE;
     } else if (!strcmp(what, "bits")) {

@@ -4,15 +4,15 @@
  *
  * HBM layout (per context, S = n_streams, chain c in {T1C1, S1}, algo a in {RLA, T2A}):
  *   in     u8   [S][HIST_BYTES + max_push_bytes + SLACK]   cu8; HIST = tail of the previous push
- *   dphi   f32  [2][NG][Mcap/8][GW][8]   soft symbol (FIR output), one per decimated sample.  WAVE-TRANSPOSED: captures come
- *                                 in groups of GW (64; fewer only when the batch has fewer), and the 8 samples (one 32-byte
- *                                 sector) of the GW captures of a group at one time lie side by side -- the framer lanes of a
- *                                 wave are GW consecutive captures at the SAME time, so a wave reads 2 KB in one piece with a
- *                                 lane-private 32-byte load each (round 3: capture-major rows, cooperative line loads and a
- *                                 transpose through 36 KB of LDS per block); K1 writes whole sectors (two lanes each)
+ *   dphi   f32  [2][S][Mcap]      soft symbol (FIR output), one per decimated sample; capture-major rows (K1 writes whole
+ *                                 128-byte lines; a framer lane reads its own row, 32 bytes at a time)
  *   rssi   u8   [2][S][Mcap]      (unsigned) of the filtered magnitude (capture-major: read per chip, by position)
- *   bits   u32  [2][NG][Mcap/32][GW]     slicer output, bit j of word w = sample 32w+j; same grouping: one coalesced 256-byte
- *                                 store / load per wave and 32 samples, no staging
+ *   bits   u32  [2][NG][Mcap/32][GW]     slicer output, bit j of word w = sample 32w+j.  WAVE-TRANSPOSED: captures come in groups
+ *                                 of GW (64; fewer only when the batch has fewer) and the words of a group's captures at one time
+ *                                 lie side by side -- the framer lanes of a wave are GW consecutive captures at the SAME time, so
+ *                                 a wave stores / loads one 256-byte piece per 32 samples, without staging.  (Round 4 tried the
+ *                                 same for the soft symbols, [t/8][capture][8]: the framers liked it, but K1 then writes 32-byte
+ *                                 sectors 2 KB apart and ran 8 % slower alone, 25 % with 1024 captures per launch.)
  *   chips  u32  [2][2][S][nseg][cap_a]  per time segment; word = pos<<3 | value (bit, sync, reset); the RSSI of
  *                                       a chip is rssi[row][sample of the chip] (K3 / K4 insert it into bits 15:8)
  *   state arrays, burst arena (see structs below)
@@ -113,8 +113,8 @@ struct WmPush {
     uint32_t s1_span;        /* 2: an S1 clock lane covers two consecutive segments (its warm-up is twice T1/C1's, so at the
                                 same segment length it re-reads 75 % instead of 37 %); 0 / 1: one segment per lane */
     WmSpill sp;              /* run-length chips beyond cap[0]                        */
-    uint32_t GW, NG;         /* capture groups of the wave-transposed arrays (dphi, bits): GW captures each (a power of two
-                                <= 64), NG = ceil(S / GW) of them */
+    uint32_t GW, NG;         /* capture groups of the wave-transposed slicer words: GW captures each (a power of two <= 64),
+                                NG = ceil(S / GW) of them */
 };
 
 /* Group geometry for S captures: 64 per group, or the next power of two >= S for a smaller batch. */
@@ -124,8 +124,6 @@ static inline void wm_group_geometry(uint32_t S, uint32_t *gw, uint32_t *ng)
     if (S < 64u) { w = 1u; while (w < S) w *= 2u; }
     *gw = w; *ng = (S + w - 1u) / w;
 }
-/* Soft symbol t of capture s, chain ch (element index into dphi): sector (t / 8) of the capture's group, the capture's slot
- * in it, sample t % 8.  The 8-sample sector of a capture at one time is contiguous; so are the GW sectors of a group. */
 #ifndef WM_HD
 #if defined(__HIPCC__)
 #define WM_HD __host__ __device__ __forceinline__
@@ -133,9 +131,10 @@ static inline void wm_group_geometry(uint32_t S, uint32_t *gw, uint32_t *ng)
 #define WM_HD static inline
 #endif
 #endif
+/* Soft symbol t of capture s, chain ch (element index into dphi). */
 WM_HD uint64_t wm_dphi_index(const WmPush &g, uint32_t ch, uint32_t s, uint32_t t)
 {
-    return ((((uint64_t)ch * g.NG + s / g.GW) * (g.Mcap / 8u) + t / 8u) * g.GW + s % g.GW) * 8u + t % 8u;
+    return ((uint64_t)ch * g.S + s) * g.Mcap + t;
 }
 /* Slicer word w (samples 32 w .. 32 w + 31) of capture s, chain ch (element index into bits). */
 WM_HD uint64_t wm_bits_index(const WmPush &g, uint32_t ch, uint32_t s, uint32_t w)

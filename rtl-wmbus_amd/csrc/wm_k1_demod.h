@@ -28,7 +28,7 @@ __device__ static constexpr float FIR_S[46] = {
  * ===========================================================================================*/
 struct K1Args {
     WmPush g;
-    float *dphi;             /* wave-transposed, see wm_dphi_index (wm_dev.h) */
+    float *dphi;             /* [2][S][Mcap] */
     uint8_t *rssi;           /* [2][S][Mcap] */
     const float *lut_cos;    /* [lut_n]  cosf table, built on the host with the host libm */
     const float *lut_msin;   /* [lut_n]  -sinf table                                      */
@@ -41,10 +41,6 @@ struct K1Args {
     const uint32_t *relist;
     const float *ema_carry;  /* [2][S] exact EMA carried in from the previous push */
     const uint32_t *n_relist;/* repair launches: entries in `relist` (on the device: k1_collect has just written it) */
-    /* first pass: grid = (ntiles << sx, S >> sx); block x works on tile x >> sx of capture (y << sx) + (x & ((1 << sx) - 1)).
-     * With sx = 2 the same tile of four neighbouring captures is in flight together: their soft-symbol sectors share 128-byte
-     * lines (wm_dphi_index), which then leave L2 whole instead of a quarter at a time. */
-    uint32_t sx;
 };
 
 /* =============================================================================================
@@ -143,7 +139,6 @@ __device__ __forceinline__ void k1_fir_t(const K1Args &a, const float *yDrT, con
         for (int k = 0; k < 11; k++) s = FAST ? __builtin_fmaf(FIR_T[k], w[12 + j - k], s) : wm_add(s, wm_mul(FIR_T[k], w[12 + j - k]));
         acc[j] = s;
     }
-    /* half a 32-byte sector per lane; the neighbouring lane writes the other half in the same instruction */
     *(float4 *)(a.dphi + wm_dphi_index(g, 0u, (uint32_t)stream, (uint32_t)(ts + m0l))) = make_float4(acc[0], acc[1], acc[2], acc[3]);
 }
 
@@ -418,10 +413,7 @@ __global__ __launch_bounds__(256, GEN ? 1 : 8) void k1_demod2(K1Args a)         
      * launches, per-thread addresses kept across tiles -- and the whole job 10 % slower: the framer kernels of the other
      * contexts get onto a CU when demodulation blocks retire, and blocks that live twice as long halve their chances; r03
      * A/B in DESIGN.md section 10.) */
-    if (!GEN || a.relist == nullptr) {
-        k1_tile<D, SHIFT, GEN, FAST>(a, (int)(blockIdx.x >> a.sx), (int)((blockIdx.y << a.sx) + (blockIdx.x & ((1u << a.sx) - 1u))), (int)threadIdx.x);
-        return;
-    }
+    if (!GEN || a.relist == nullptr) { k1_tile<D, SHIFT, GEN, FAST>(a, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x); return; }
     /* repair launch: a fixed grid walks the list k1_collect has just written (no host round trip in between) */
     const uint32_t n = *a.n_relist;
     for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
@@ -539,7 +531,7 @@ __device__ __forceinline__ void k1_tile_ppf(const K1Args &a, const int tile, con
 
 __global__ __launch_bounds__(256) void k1_demod_ppf(K1Args a)
 {
-    if (a.relist == nullptr) { k1_tile_ppf(a, (int)(blockIdx.x >> a.sx), (int)((blockIdx.y << a.sx) + (blockIdx.x & ((1u << a.sx) - 1u)))); return; }
+    if (a.relist == nullptr) { k1_tile_ppf(a, (int)blockIdx.x, (int)blockIdx.y); return; }
     const uint32_t n = *a.n_relist;
     for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
         k1_tile_ppf(a, (int)(a.relist[e] % a.ntiles), (int)(a.relist[e] / a.ntiles));

@@ -74,8 +74,8 @@ __device__ __forceinline__ bool clk_step(WmClkState &s, const IirCoef &c, bool d
  * drains at the end of the block: the lane state at block boundaries is the plain sequential
  * state.  Every value is produced by exactly the operations of iir.h:57-74 / rtl_wmbus.c:497-515.
  *
- * Input: X[0..7] = the lane's 32 soft symbols as eight float4, in REGISTERS (round 4: the wave-transposed layout of wm_dev.h lets every
- * lane load its own 32-byte sectors with the wave's access still one contiguous 2 KB piece).  The registers double as the
+ * Input: X[0..7] = the lane's 32 soft symbols as eight float4, in REGISTERS: every lane loads from its own capture's row
+ * (round 3 fetched the 64 rows' lines cooperatively, 8 lanes per line, and transposed them through 36 KB of LDS per block).  The registers double as the
  * prefetch queue: sample t is consumed at tick t only, so right after tick 8 j + 7 `refill(j)` issues the two 16-byte loads
  * of the NEXT block's samples 8 j .. 8 j + 7 into the eight registers that have just been retired -- every load has 32 ticks
  * (about 5 us) to arrive, with 32 registers in flight instead of round 3's 64 + an LDS round trip per block.  The fences
@@ -169,10 +169,11 @@ __device__ __forceinline__ void clk_block32(WmClkState &s, const IirCoef &c, wm_
  * levels at n-3..n are L,H,H,H" (checked exhaustively over all level sequences);
  * the lane state keeps the last three levels.
  *
- * Memory: a lane walks its own capture's soft symbols in the wave-transposed array, 32 bytes (8 samples, one sector) at a
- * time; the 64 lanes of a first-pass wave are the 64 captures of one group at the same time, so the wave's access is one
- * contiguous 2 KB piece.  Slicer words go out the same way (one coalesced 256-byte store per wave and block).  A re-run
- * lane (any capture, any segment) uses the same addresses on its own. */
+ * Memory: a lane walks its own capture's row of soft symbols, 32 bytes (8 samples, one sector) at a time: a 128-byte line
+ * per 32-sample block, asked for in four pieces 8 ticks apart (the line stays in L2 meanwhile).  Slicer words go to the
+ * wave-transposed array of wm_dev.h: the 64 lanes of a first-pass wave are the 64 captures of one group at the same time,
+ * one coalesced 256-byte store per wave and block, no staging.  A re-run lane (any capture, any segment) uses the same
+ * addresses on its own. */
 template <int W> struct ClkLds {         /* per block: W independent waves */
     uint32_t chip[W][64 * WM_CLK_CROW];
 };
@@ -240,9 +241,9 @@ __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t bloc
     WM_SETTLED12(s);
     const IirCoef c = iir_coef(ch);
     const bool t2a = g.flags & WM_F_T2A;
-    /* this capture's sector 0 in the wave-transposed array; sector q (samples 8 q .. 8 q + 7) lies q * gs floats further */
+    /* this capture's row of soft symbols; sector q (samples 8 q .. 8 q + 7, 32 bytes) lies q * gs floats further */
     const float *x = a.dphi + wm_dphi_index(g, ch, stream, 0u);
-    const uint64_t gs = 8ull * g.GW;
+    constexpr uint64_t gs = 8;
     const uint32_t syncw = ch ? WM_SYNC_S1 : WM_SYNC_T1C1, syncm = ch ? WM_SYNC_S1_MASK : WM_SYNC_T1C1_MASK;
     uint32_t *out = a.chips + sidx * g.cap[1];            /* region pitch (cap_t2 may be two regions) */
     uint32_t *bw = a.bits + wm_bits_index(g, ch, stream, 0u);    /* word w of this capture at bw[w * GW] */

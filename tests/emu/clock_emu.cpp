@@ -57,7 +57,7 @@ long wm_emu_clock(const float *dphi_rows, uint32_t S, uint32_t M, uint32_t Mcap,
     g.seg_len[1] = seg_len; g.nseg[1] = (M + seg_len - 1) / seg_len; g.nseg_cap[1] = g.nseg[1]; g.cap[1] = cap;
     g.warm[0] = warm0; g.warm[1] = warm1; g.s1_span = (uint32_t)wm_emu_s1_span;
     wm_group_geometry(S, &g.GW, &g.NG);
-    std::vector<float> dphi_t((size_t)2 * g.NG * g.GW * Mcap, 0.0f);
+    std::vector<float> dphi_t((size_t)2 * S * Mcap, 0.0f);
     std::vector<uint32_t> bits_t((size_t)2 * g.NG * g.GW * (Mcap / 32), 0u);
     for (uint32_t ch = 0; ch < 2; ch++)
         for (uint32_t st = 0; st < S; st++)

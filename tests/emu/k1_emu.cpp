@@ -80,7 +80,7 @@ long wm_emu_k1(const uint8_t *in, uint64_t in_stride, uint32_t S, uint32_t d, ui
     if (g.M == 0) return 0;
     /* the kernel writes soft symbols wave-transposed (wm_dev.h); the tests get them capture-major */
     wm_group_geometry(S, &g.GW, &g.NG);
-    std::vector<float> dphi_t((size_t)2 * g.NG * g.GW * Mcap, 0.0f);
+    std::vector<float> dphi_t((size_t)2 * S * Mcap, 0.0f);
     float *dphi = dphi_t.data();
     const uint32_t T = WM_K1_TILE2, ntiles = (g.M + T - 1) / T, rows = 2 * S;
     std::vector<float> lut(2 * 32 * WM_MAX_DECIM, 0.f), head((size_t)ntiles * rows), tail((size_t)ntiles * rows);
@@ -93,14 +93,12 @@ long wm_emu_k1(const uint8_t *in, uint64_t in_stride, uint32_t S, uint32_t d, ui
     }
     std::vector<uint32_t> first_bad(rows, 0xFFFFFFFFu), relist((size_t)rows * ntiles + 1);
     uint32_t err = 0, n_relist = 0;
-    K1Args a{g, dphi, rssi, lut.data(), lut.data() + 32 * WM_MAX_DECIM, head.data(), tail.data(), ntiles, &err, nullptr, ema_carry, nullptr, 0u};
+    K1Args a{g, dphi, rssi, lut.data(), lut.data() + 32 * WM_MAX_DECIM, head.data(), tail.data(), ntiles, &err, nullptr, ema_carry, nullptr};
     const bool sh = flags & WM_F_SHIFT;
     auto launch = [&](uint32_t n_list) {
         a.relist = n_list ? relist.data() : nullptr;
         a.n_relist = &n_relist;                                             /* repair launches: a fixed grid walks the list (3 blocks here) */
-        /* first pass: four neighbouring captures' tiles interleaved in x when the batch allows it (K1Args.sx, as wm_api.hip launches it) */
-        a.sx = (!n_list && S % 4u == 0u) ? 2u : 0u;
-        const uint32_t gx = n_list ? 3u : ntiles << a.sx, gy = n_list ? 1 : S >> a.sx;
+        const uint32_t gx = n_list ? 3u : ntiles, gy = n_list ? 1 : S;
         gridDim = {gx, gy, 1};
         if (polyphase) {                                                    /* ppf.h pre-filter (d = 2, no shift) */
             for (uint32_t y = 0; y < gy; y++)

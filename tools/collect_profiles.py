@@ -10,7 +10,13 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+# which source the numbers belong to: the commit whose build was measured (argument 2), else HEAD of this checkout
+import subprocess
+try:
+    COLLECTED_AT = sys.argv[2] if len(sys.argv) > 2 else subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, check=True).stdout.strip()
+except Exception:
+    COLLECTED_AT = "unknown"
 
 COPIES = [("trace/bench_kernel_stats.csv", "bench_kernel_stats.csv"),
           ("trace/bench_domain_stats.csv", "bench_domain_stats.csv"),
@@ -92,7 +98,8 @@ if os.path.exists(sqp):
         if r["counter"] == "SQ_INSTS_VALU":
             d["launches"] += int(r["launches"]); d["avg_ms_under_pmc"] = max(d["avg_ms_under_pmc"], float(r["avg_ms_under_pmc"]))
     steps = 2                                  # bench.py --steps 1 --warmup 0: the timed step + the un-overlapped calibration pass
-    valu = {"run": f"bench.py --contexts 1 --steps 1 --warmup 0: {S} captures x 2^22 IQ samples per launch, {steps} passes",
+    valu = {"collected_at": COLLECTED_AT, "profiles_tag": tag,
+            "run": f"bench.py --contexts 1 --steps 1 --warmup 0: {S} captures x 2^22 IQ samples per launch, {steps} passes",
             "peak_T_wave_instr_per_s": 1.2288,
             "peak_how": "1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md: SIMD-32, v_fma_f32 2 cyc)",
             "kernels": {}}
@@ -118,6 +125,7 @@ if n_k1:
     fetch_b = 2.0 * f_k1 * 1024 / n_k1          # FETCH_SIZE reports half of wide coalesced reads on gfx950
     write_b = w_k1 * 1024 / n_k1
     traffic = {
+        "collected_at": COLLECTED_AT, "profiles_tag": tag,
         "kernel": "k1_demod2<2,false>",
         "launch": f"{S} captures x 2^22 IQ samples in one launch (bench.py --contexts 1 --steps 1 --warmup 0: the timed step "
                   f"plus the un-overlapped calibration pass = {n_k1} launches)",
@@ -133,5 +141,7 @@ if n_k1:
     for pre in ("k2_clock", "k2_clock_rla", "k2_rla", "k3_scan", "k3_bursts"):
         traffic["other_kernels_KB_per_step_as_reported"][pre + "_fetch"] = round(pick(fetch, pre)[1] / 2, 1)   # two passes per run
         traffic["other_kernels_KB_per_step_as_reported"][pre + "_write"] = round(pick(write, pre)[1] / 2, 1)
+    o = traffic["other_kernels_KB_per_step_as_reported"]
+    traffic["job_hbm_bytes_per_step"] = fetch_b + write_b + 1024.0 * sum((2.0 if k.endswith("_fetch") else 1.0) * v for k, v in o.items())
     json.dump(traffic, open(os.path.join(DST, "traffic.json"), "w"), indent=1)
     print(json.dumps(traffic, indent=1))
