@@ -663,16 +663,18 @@ static void fr_launch(wmbus_ctx *c, int algo, uint32_t cnt, hipStream_t st = nul
     const bool all = cnt == 0xFFFFFFFFu;
     a.list = all ? nullptr : (algo == WMBUS_ALGO_RLA ? c->d_list2 : c->d_list);
     a.n_lanes = lanes; a.n_ptr = all ? nullptr : c->d_scalars + cnt;
-    /* list launches: blocks for 3/16 of the lanes (a re-run list is a few percent of them; the blocks walk whatever is more) */
-    /* the clock kernel's first pass: one wave per (chain, segment, group of 64 captures), see clock_lanes */
-    const uint32_t clk_waves = 2u * a.g.nseg[1] * ((a.g.S + 63u) / 64u);
-    const uint32_t B = 64 * (algo == WMBUS_ALGO_RLA ? WM_RLA_WPB : WM_CLK_WPB);
-    const uint32_t grid = !all ? std::max(16u, (lanes / B) * 3u / 16u) : algo == WMBUS_ALGO_RLA ? (lanes + B - 1) / B : (clk_waves + WM_CLK_WPB - 1) / WM_CLK_WPB;
+    /* First pass of a batch of whole waves: the uniform kernels, one wave per (chain, segment, group of 64 captures).  Any other
+     * batch, and every re-run list: the list kernels, whose blocks walk densely packed lanes (a.list == nullptr: all of them);
+     * list launches get blocks for 3/16 of the lanes (a re-run list is a few percent of them; the blocks walk whatever is more). */
+    const bool whole = all && (a.g.S % 64u) == 0u;
+    const uint32_t wpb = algo == WMBUS_ALGO_RLA ? WM_RLA_WPB : WM_CLK_WPB, B = 64 * wpb;
+    const uint32_t waves = 2u * a.g.nseg[algo] * (a.g.S / 64u);
+    const uint32_t grid = whole ? (waves + wpb - 1) / wpb : all ? (lanes + B - 1) / B : std::max(16u, (lanes / B) * 3u / 16u);
     if (algo == WMBUS_ALGO_RLA) {
-        if (all) hipLaunchKernelGGL(k2_rla, dim3(grid), dim3(B), 0, st, a);
+        if (whole) hipLaunchKernelGGL(k2_rla, dim3(grid), dim3(B), 0, st, a);
         else hipLaunchKernelGGL(k2_rla_list, dim3(grid), dim3(B), 0, st, a);
     }
-    else if (all) {
+    else if (whole) {
         if (c->flags & WM_F_DC) hipLaunchKernelGGL(k2_clock<true>, dim3(grid), dim3(B), 0, st, a);
         else hipLaunchKernelGGL(k2_clock<false>, dim3(grid), dim3(B), 0, st, a);
     } else if (c->flags & WM_F_DC) hipLaunchKernelGGL(k2_clock_list<true>, dim3(grid), dim3(B), 0, st, a);

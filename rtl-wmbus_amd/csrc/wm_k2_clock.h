@@ -10,10 +10,7 @@ typedef float wm_f4 __attribute__((ext_vector_type(4)));     /* a native 4-vecto
 struct wm_f4 { float x, y, z, w; };
 #endif
 
-/* a value that is the same in every lane of the wave, moved to a scalar register (so that what is computed from it, and the
- * branches taken on it, are uniform); the host emulation runs one lane at a time */
 #if defined(__HIP_DEVICE_COMPILE__)
-#define WM_UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 /* "these twelve words are in registers NOW" (an empty asm that takes them in and hands them back): the compiler waits for
  * their loads here and no longer counts them as in flight afterwards */
 #define WM_SETTLED12(st) do { uint32_t *w_ = (uint32_t *)&(st); \
@@ -21,7 +18,6 @@ struct wm_f4 { float x, y, z, w; };
                       "+v"(w_[8]), "+v"(w_[9]), "+v"(w_[10]), "+v"(w_[11])); } while (0)
 #define WM_CLAIM2(a, b) asm volatile("" : "+v"(a), "+v"(b))
 #else
-#define WM_UNI(x) ((uint32_t)(x))
 #define WM_SETTLED12(st) do { } while (0)
 #define WM_CLAIM2(a, b) do { } while (0)
 #endif
@@ -76,10 +72,11 @@ __device__ __forceinline__ bool clk_step(WmClkState &s, const IirCoef &c, bool d
  *
  * Input: X[0..7] = the lane's 32 soft symbols as eight float4, in REGISTERS: every lane loads from its own capture's row
  * (round 3 fetched the 64 rows' lines cooperatively, 8 lanes per line, and transposed them through 36 KB of LDS per block).  The registers double as the
- * prefetch queue: sample t is consumed at tick t only, so right after tick 8 j + 7 `refill(j)` issues the two 16-byte loads
- * of the NEXT block's samples 8 j .. 8 j + 7 into the eight registers that have just been retired -- every load has 32 ticks
- * (about 5 us) to arrive, with 32 registers in flight instead of round 3's 64 + an LDS round trip per block.  The fences
- * keep the loads where they are written (the scheduler would sink them to their uses, one block later).
+ * prefetch queue: at tick 8 j samples 8 j .. 8 j + 7 move to two working tuples and `refill(j)` issues the two 16-byte loads
+ * of the NEXT block's samples 8 j .. 8 j + 7 into the eight registers just vacated -- every load has a whole block (34
+ * ticks) to arrive, with 32 + 8 registers instead of round 3's 64 + an LDS round trip per block (tools/clkbench.hip: at
+ * 1024 waves 1.7 us per block against 1.66 for the arithmetic alone; refilling only after tick 8 j + 7, 26 ticks of lead,
+ * cost 2.13).  The fences keep the loads where they are written (the scheduler would sink them to their uses).
  *
  * Bits: the slicer output (soft >= 0, rtl_wmbus.c:1059) is the inverted sign bit -- a soft symbol
  * is never -0 (the FIR accumulates from +0, and +0 + -0 = +0; the DC remover's x - x_old is never
@@ -94,15 +91,22 @@ __device__ __forceinline__ void clk_block32(WmClkState &s, const IirCoef &c, wm_
     float soft = 0.0f;                                     /* DC stage output waiting for section 0 */
     uint32_t sgn = 0, low = 0;                             /* MSB-first: sample n ends up in bit 31 - n */
     const float al = 0.999f, kk = wm_div(wm_add(1.0f, al), 2.0f);
+    wm_f4 W[2] = {};                                       /* the eight samples in work */
 #pragma unroll
     for (int t = 0; t < 32 + P + 2; t++) {
         float m1[3], m2[3], p1[3], p2[3], tt[3], h0[3], u[3], o[3];
         float d1 = 0.0f, d2 = 0.0f, d3 = 0.0f;
         /* the two 16-byte loads of samples t .. t + 7 are claimed HERE, as whole register tuples (an empty asm that takes
          * them in and hands them back): the wait for them is placed at this tick, and the values cross the loop's back edge
-         * as the tuples the loads wrote -- split into 32 scalars they got a second register set and a copy per block */
-        if (t < 32 && (t & 7) == 0) WM_CLAIM2(X[t >> 2], X[(t >> 2) + 1]);
-        const wm_f4 &xq = X[(t < 32 ? t : 31) >> 2];
+         * as the tuples the loads wrote -- split into 32 scalars they got a second register set and a copy per block.  They
+         * move into two working tuples, and the loads of the NEXT block's samples t .. t + 7 are issued at once into the
+         * registers just vacated: a whole block (34 ticks) of lead for 32 + 8 registers. */
+        if (t < 32 && (t & 7) == 0) {
+            WM_CLAIM2(X[t >> 2], X[(t >> 2) + 1]);
+            W[0] = X[t >> 2]; W[1] = X[(t >> 2) + 1];
+            refill(t >> 3);
+        }
+        const wm_f4 &xq = W[(t >> 2) & 1];
         const float xt = t >= 32 ? 0.0f : (t & 3) == 0 ? xq.x : (t & 3) == 1 ? xq.y : (t & 3) == 2 ? xq.z : xq.w;   /* sample t */
         /* level 1: every product that only needs last tick's state */
         if (DC && t < 32) { d1 = wm_sub(xt, dcx); d2 = wm_mul(al, dcy); }
@@ -149,7 +153,6 @@ __device__ __forceinline__ void clk_block32(WmClkState &s, const IirCoef &c, wm_
                 else low = wm_shift_in_level_low(low, wm_f2u(o[2]));
             }
         }
-        if (t < 32 && (t & 7) == 7) refill(t >> 3);            /* X[t - 7 .. t] retired: the next block's samples take their place */
         __builtin_amdgcn_sched_barrier(0);
     }
     s.h[0] = h1[0]; s.h[1] = h2[0]; s.h[2] = h1[1]; s.h[3] = h2[1]; s.h[4] = h1[2]; s.h[5] = h2[2];
@@ -183,8 +186,9 @@ template <int W> struct ClkLds {         /* per block: W independent waves */
  * long-running wave on ONE SIMD slows every 4-wave K1 block of that CU down to the pace of the K1
  * wave that shares the SIMD with it (measured: two clock launches in flight, one wave per CU, cost
  * K1 60 %). */
-/* PASS: 0 = the speculative first pass only (a.list == nullptr), 1 = a re-run list only, 2 = either (host emulation): each kind of launch has its own
- * kernel, so the first pass carries neither the list walk nor the checkpoint comparison. */
+/* PASS: 0 = the speculative first pass of a batch of whole waves (uniform loops, see below), 1 = a re-run list only, 2 = a
+ * re-run list (a.list set) or a first pass with densely packed lanes (any batch size): each kind of launch has its own kernel,
+ * so the uniform first pass carries neither the list walk nor the checkpoint comparison. */
 template <bool DC, int W, int PASS = 2>
 __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t block, ClkLds<W> &lds)
 {
@@ -194,20 +198,24 @@ __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t bloc
     const bool rerun = PASS == 2 ? a.list != nullptr : PASS == 1;
     const WmPush &g = a.g;
     uint32_t ch, stream, seg;
-    if (!rerun) {
-        /* FIRST PASS: a wave is one (chain, segment) and 64 consecutive captures -- never a mixture, whatever the batch size
-         * (a last, partly filled group leaves lanes idle).  Everything that steers the lane's loops (segment bounds, block
-         * counter) is then the same in all 64 lanes and is kept in scalar registers: the loops are UNIFORM.  That is what lets
-         * the soft-symbol registers be refilled in place while a block is in work (clk_block32): values that live across a
-         * divergent loop get a second register set and a copy -- and a wait for everything in flight -- at every trip. */
-        const uint32_t w = WM_UNI(block * (uint32_t)W + wv), ngrp = (g.S + 63u) / 64u;
+    if (PASS == 0) {
+        /* FIRST PASS of a batch of whole waves (S a multiple of 64): a wave is one (chain, segment) and 64 consecutive
+         * captures.  Everything that steers the lane's loop (segment bounds, block counter) is then the same in all 64
+         * lanes and is kept in scalar registers: the loop is UNIFORM.  That is what lets the soft-symbol registers be
+         * refilled in place while a block is in work (clk_block32): values that live across a divergent loop get a second
+         * register set and a copy -- and a wait for everything in flight -- at every trip. */
+        const uint32_t w = WM_UNI(block * (uint32_t)W + wv), ngrp = g.S / 64u;
         const uint32_t r = w / ngrp;
         seg = r % g.nseg[1]; ch = r / g.nseg[1]; stream = (w % ngrp) * 64u + ln;
-        if (ch >= 2u || stream >= g.S) return;
+        if (ch >= 2u) return;
     } else {
+        /* a re-run list, or the first pass of any other batch: lanes are (chain, capture, segment) in any mixture, packed
+         * densely -- a wave with most of its lanes idle runs several times slower PER INSTRUCTION on gfx950
+         * (tools/clkbench.hip: 7.7 us per block with one active lane against 1.6 with 64), so a small batch spreads its
+         * segments over the lanes of few waves instead of giving every segment a wave of its own */
         uint32_t lane = (block * W + wv) * 64 + ln;
         if (lane >= k2_lane_count(a)) return;
-        lane = a.list[lane];
+        if (rerun) lane = a.list[lane];
         lane_decode(g, 1, lane, ch, stream, seg);
     }
     if (!(g.flags & (ch ? WM_F_S1 : WM_F_T1C1))) return;
@@ -234,7 +242,7 @@ __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t bloc
         const uint32_t w = g.warm[ch];
         if (mb <= w) { s = stC[row]; m = 0; }            /* exact: run from the push start  */
         else { s = WmClkState{}; m = mb - w; }           /* speculative cold start          */
-        m = WM_UNI(m);
+        if (PASS == 0) m = WM_UNI(m);
     }
     /* the state is complete before the first soft symbol is asked for, on every path: otherwise the block loop's (static)
      * waits also have to cover the state's loads of the first trip, and wait for too much on every later one */
@@ -439,12 +447,12 @@ __global__ __launch_bounds__(64 * WM_CLK_WPB, WM_CLK_WAVES_PER_SIMD) void k2_clo
 }
 
 template <bool DC>
-__global__ __launch_bounds__(64 * WM_CLK_WPB, WM_CLK_WAVES_PER_SIMD) void k2_clock_list(K2Args a)            /* re-run list: a fixed grid whose blocks walk the list */
+__global__ __launch_bounds__(64 * WM_CLK_WPB, WM_CLK_WAVES_PER_SIMD) void k2_clock_list(K2Args a)            /* a fixed grid whose blocks walk a re-run list, or (a.list == nullptr) every lane of a batch that is not whole waves */
 {
     wm_framer_prio();
     __shared__ __attribute__((aligned(16))) ClkLds<WM_CLK_WPB> lds;
     const uint32_t n = k2_lane_count(a);
-    for (uint32_t b = blockIdx.x; (uint64_t)b * (64u * WM_CLK_WPB) < n; b += gridDim.x) clock_lanes<DC, WM_CLK_WPB, 1>(a, b, lds);
+    for (uint32_t b = blockIdx.x; (uint64_t)b * (64u * WM_CLK_WPB) < n; b += gridDim.x) clock_lanes<DC, WM_CLK_WPB, 2>(a, b, lds);
 }
 
 #endif /* WM_K2_CLOCK_H */

@@ -58,19 +58,28 @@ __device__ __forceinline__ uint32_t deglitch_word(uint32_t W, bool s1)
  * from the masked history.  WmRlaState.raw keeps the last five raw bits in time order. */
 struct RlaLds { uint32_t chip[64 * WM_RLA_WPB * WM_RLA_CROW]; };     /* lane-private staging; the block's waves are independent */
 
-/* PASS: 0 = first pass only (a.list == nullptr), 1 = re-run list only, 2 = either (the fused launch): like the clock kernel,
- * each kind of launch has its own kernel (the main pass then carries no list walk: 78 instead of 97 VGPRs). */
+/* PASS: 0 = first pass of a batch of whole waves (uniform), 1 = re-run list only, 2 = re-run list or a densely packed first pass
+ * of any batch: like the clock kernel, each kind of launch has its own kernel (the uniform first pass: 62 VGPRs). */
 template <int PASS = 2>
 __device__ __forceinline__ void rla_lanes(const K2Args &a, const uint32_t block_id, RlaLds &lds)
 {
     uint32_t *s_chip = lds.chip;
-    uint32_t lane = block_id * (64 * WM_RLA_WPB) + threadIdx.x;
-    if (lane >= k2_lane_count(a)) return;
     const bool rerun = PASS == 2 ? a.list != nullptr : PASS == 1;
-    if (rerun) lane = a.list[lane];
     const WmPush &g = a.g;
     uint32_t ch, stream, seg;
-    lane_decode(g, 0, lane, ch, stream, seg);
+    if (PASS == 0) {
+        /* FIRST PASS of a batch of whole waves: a wave is one (chain, segment) and 64 consecutive captures (see clock_lanes):
+         * segment bounds and the step counter are the same in all 64 lanes and live in scalar registers */
+        const uint32_t w = WM_UNI(block_id * (uint32_t)WM_RLA_WPB + (threadIdx.x >> 6)), ngrp = g.S / 64u;
+        const uint32_t r = w / ngrp;
+        seg = r % g.nseg[0]; ch = r / g.nseg[0]; stream = (w % ngrp) * 64u + (threadIdx.x & 63u);
+        if (ch >= 2u) return;
+    } else {
+        uint32_t lane = block_id * (64 * WM_RLA_WPB) + threadIdx.x;
+        if (lane >= k2_lane_count(a)) return;
+        if (rerun) lane = a.list[lane];
+        lane_decode(g, 0, lane, ch, stream, seg);
+    }
     if (!(g.flags & (ch ? WM_F_S1 : WM_F_T1C1))) return;
 
     const uint64_t row = (uint64_t)ch * g.S + stream;
@@ -85,6 +94,7 @@ __device__ __forceinline__ void rla_lanes(const K2Args &a, const uint32_t block_
     if (rerun) { s = seg ? stF[sidx - 1] : stC[row]; m = mb; }
     else if (mb <= g.lookback) { s = stC[row]; m = 0; }
     else { s = reset; m = (mb - g.lookback) & ~63u; }     /* whole 64-sample steps (segments are multiples of 1024) */
+    if (PASS == 0) m = WM_UNI(m);
 
     const uint32_t *bw = a.bits + wm_bits_index(g, ch, stream, 0u);     /* word w of this capture at bw[w * GW] (wm_dev.h) */
     const uint64_t bstep = g.GW;
@@ -250,7 +260,7 @@ __global__ __launch_bounds__(64 * WM_RLA_WPB, WM_RLA_WAVES_PER_SIMD) void k2_rla
     wm_framer_prio();
     __shared__ RlaLds lds;
     const uint32_t n = k2_lane_count(a);
-    for (uint32_t b = blockIdx.x; (uint64_t)b * (64u * WM_RLA_WPB) < n; b += gridDim.x) rla_lanes<1>(a, b, lds);
+    for (uint32_t b = blockIdx.x; (uint64_t)b * (64u * WM_RLA_WPB) < n; b += gridDim.x) rla_lanes<2>(a, b, lds);
 }
 
 #endif /* WM_K2_RLA_H */

@@ -81,14 +81,15 @@ long wm_emu_clock(const float *dphi_rows, uint32_t S, uint32_t M, uint32_t Mcap,
          * end state BEFORE that predecessor's own re-run (same launch) has replaced it -- which is what
          * makes cascading rounds.  Lanes in descending order reproduce that; ascending order is the
          * other extreme (every lane already sees its predecessor's new state). */
-        if (lst == nullptr) {
-            /* first pass: one wave per (chain, segment, group of 64 captures), see clock_lanes; the wave's lanes meet in the
-             * chip loops' ballots, so they run together, one coroutine each, on the block emulator */
-            const uint32_t waves = 2u * nseg * ((S + 63u) / 64u);
+        if (lst == nullptr && S % 64u == 0u) {
+            /* first pass of a batch of whole waves: the UNIFORM kernel (PASS = 0), one wave per (chain, segment, group of 64
+             * captures); the wave's lanes meet in the chip loops' ballots, so they run together, one coroutine each */
+            const uint32_t waves = 2u * nseg * (S / 64u);
             for (uint32_t b = 0; b < waves; b++)
-                block_emu::run_block(64, [&] { if (dc) clock_lanes<true, 1>(a, b, lds); else clock_lanes<false, 1>(a, b, lds); });
+                block_emu::run_block(64, [&] { if (dc) clock_lanes<true, 1, 0>(a, b, lds); else clock_lanes<false, 1, 0>(a, b, lds); });
             return;
         }
+        /* any other first pass, and every re-run list: the list kernel's densely packed lanes (PASS = 2), one at a time */
         for (uint32_t i = 0; i < n; i++) {
             const uint32_t l = wm_emu_descending ? n - 1 - i : i;
             threadIdx.x = l & 63u;

@@ -78,10 +78,11 @@ long wm_emu_rla(const uint32_t *bits_rows, uint32_t S, uint32_t M, uint32_t Mcap
         a.list = lst; a.n_lanes = n;
         /* descending lane order: a re-run lane reads its predecessor's end state before that predecessor's
          * own re-run of the same launch replaces it, as it mostly happens on the GPU (cascading rounds) */
+        const bool whole = lst == nullptr && S % 64u == 0u;             /* the uniform first-pass kernel (PASS = 0): one wave per (chain, segment, 64 captures) */
         for (uint32_t i = 0; i < n; i++) {
             const uint32_t l = wm_emu_descending ? n - 1 - i : i;
             threadIdx.x = l % B;
-            rla_lanes(a, l / B, lds);
+            if (whole) rla_lanes<0>(a, l / B, lds); else rla_lanes<2>(a, l / B, lds);
         }
     };
     launch(nullptr, lanes);

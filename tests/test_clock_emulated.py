@@ -114,9 +114,10 @@ def test_device_source_on_host_matches_oracle_randomised(emu, oracle, wm):
 
 
 def test_cooperative_first_pass_of_a_whole_wave_on_the_block_emulator(emu, oracle, wm):
-    """64 captures = one wave per (chain, segment): the first pass fetches the rows cooperatively (8 lanes per
-    row, one 128-byte line each) and transposes the block through LDS between wave barriers.  The 64 lanes run
-    as coroutines on the block emulator; re-runs take the lane-private path."""
+    """64 captures = one wave per (chain, segment): the first pass takes the UNIFORM variant of the lane code
+    (clock_lanes<.., PASS = 0>: segment bounds and block counter in scalar registers, soft-symbol registers refilled
+    in place).  The 64 lanes run as coroutines on the block emulator (they meet in the chip loops' ballots); re-runs
+    take the list variant."""
     S, seg_len, warm = 64, 8192, (1024, 2048)
     refs = []
     for s in range(S):
