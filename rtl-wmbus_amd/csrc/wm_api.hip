@@ -670,13 +670,17 @@ static void fr_launch(wmbus_ctx *c, int algo, uint32_t cnt, hipStream_t st = nul
     const uint32_t wpb = algo == WMBUS_ALGO_RLA ? WM_RLA_WPB : WM_CLK_WPB, B = 64 * wpb;
     const uint32_t waves = 2u * a.g.nseg[algo] * (a.g.S / 64u);
     const uint32_t grid = whole ? (waves + wpb - 1) / wpb : all ? (lanes + B - 1) / B : std::max(16u, (lanes / B) * 3u / 16u);
+    /* LDS a first-pass block asks for beyond what it uses (bytes): how many blocks of a framer launch the dispatcher may put on
+     * one CU is bounded by their LDS and registers, and latency-bound waves that share a SIMD slow each other down (tuning aid) */
+    static const unsigned pad_clk = getenv("WMBUS_CLK_PAD") ? (unsigned)atoi(getenv("WMBUS_CLK_PAD")) : 0u;
+    static const unsigned pad_rla = getenv("WMBUS_RLA_PAD") ? (unsigned)atoi(getenv("WMBUS_RLA_PAD")) : 0u;
     if (algo == WMBUS_ALGO_RLA) {
-        if (whole) hipLaunchKernelGGL(k2_rla, dim3(grid), dim3(B), 0, st, a);
+        if (whole) hipLaunchKernelGGL(k2_rla, dim3(grid), dim3(B), pad_rla, st, a);
         else hipLaunchKernelGGL(k2_rla_list, dim3(grid), dim3(B), 0, st, a);
     }
     else if (whole) {
-        if (c->flags & WM_F_DC) hipLaunchKernelGGL(k2_clock<true>, dim3(grid), dim3(B), 0, st, a);
-        else hipLaunchKernelGGL(k2_clock<false>, dim3(grid), dim3(B), 0, st, a);
+        if (c->flags & WM_F_DC) hipLaunchKernelGGL(k2_clock<true>, dim3(grid), dim3(B), pad_clk, st, a);
+        else hipLaunchKernelGGL(k2_clock<false>, dim3(grid), dim3(B), pad_clk, st, a);
     } else if (c->flags & WM_F_DC) hipLaunchKernelGGL(k2_clock_list<true>, dim3(grid), dim3(B), 0, st, a);
     else hipLaunchKernelGGL(k2_clock_list<false>, dim3(grid), dim3(B), 0, st, a);
 }
