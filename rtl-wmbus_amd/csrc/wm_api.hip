@@ -118,7 +118,7 @@ struct wmbus_ctx {
     uint32_t n_win = 1, fill = 0;                      /* input windows (cfg.input_windows) and the one wmbus_stage fills now */
     /* geometry */
     uint32_t d = 2, S = 1, C[2] = {8192, 32768}, Mcap = 0, nseg_cap[2] = {0, 0}, ntiles_cap = 0, T = WM_K1_TILE2;
-    uint32_t cap[2] = {0, 0}, flags = 0, GW = 1, NG = 1;   /* capture groups of the wave-transposed arrays (wm_dev.h) */
+    uint32_t cap[2] = {0, 0}, flags = 0;
     uint64_t in_stride = 0, n0 = 0;
     size_t staged = 0;
     /* device buffers */
@@ -157,7 +157,7 @@ struct wmbus_ctx {
     WmPkt *h_pkts = nullptr; uint8_t *h_bytes = nullptr;
     void *dv_hdr = nullptr, *dv_words = nullptr, *dv_pkts = nullptr, *dv_bytes = nullptr;    /* their device views */
     uint32_t n_hdr = 0, n_words = 0, n_pkts = 0;
-    K1Args k1a{}; K2Args k2clk{}, k2rla{}; uint32_t ntiles = 0; bool forked = false;    /* this push's launch arguments (collect's slow path re-uses them) */
+    K1Args k1a{}; K2Args k2clk{}, k2rla{}; uint32_t ntiles = 0; bool fused = false, forked = false;    /* this push's launch arguments (collect's slow path re-uses them) */
     std::vector<HostDecoder> decs;                      /* [stream][chain][algo] */
     std::vector<wm_twin> twins;                         /* [stream][chain][2]: the last lines printed (cfg.dedup_twins) */
     std::unique_ptr<WorkerPool> pool;                   /* packet-decoder workers, created on first use */
@@ -444,8 +444,6 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
     c->in_stride = (WM_HIST_BYTES + cfg->max_push_bytes + 2ull * (WM_K1_TILE2 + WM_K1_HALO + 16) * WM_MAX_DECIM + WM_IN_SLACK + 255) / 256 * 256;
 
     const uint64_t rows = 2ull * c->S;
-    wm_group_geometry(c->S, &c->GW, &c->NG);
-    const uint64_t trows = 2ull * c->NG * c->GW;          /* capture slots of the wave-transposed slicer words */
     hipError_t e = hipSuccess;
     auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
     A(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -472,7 +470,7 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
     A(dalloc(&c->d_hist, (size_t)WM_HIST_BYTES * c->S));
     A(dalloc(&c->d_dphi, (size_t)rows * c->Mcap));
     A(dalloc(&c->d_rssi, (size_t)rows * c->Mcap));
-    A(dalloc(&c->d_bits, (size_t)trows * (c->Mcap / 32)));
+    A(dalloc(&c->d_bits, (size_t)rows * (c->Mcap / 32)));
     A(dalloc(&c->d_lut, (size_t)2 * 32 * WM_MAX_DECIM));
     A(dalloc(&c->d_ema_head, (size_t)rows * c->ntiles_cap));
     A(dalloc(&c->d_ema_tail, (size_t)rows * c->ntiles_cap));
@@ -663,26 +661,31 @@ static void fr_launch(wmbus_ctx *c, int algo, uint32_t cnt, hipStream_t st = nul
     const bool all = cnt == 0xFFFFFFFFu;
     a.list = all ? nullptr : (algo == WMBUS_ALGO_RLA ? c->d_list2 : c->d_list);
     a.n_lanes = lanes; a.n_ptr = all ? nullptr : c->d_scalars + cnt;
-    /* First pass of a batch of whole waves: the uniform kernels, one wave per (chain, segment, group of 64 captures).  Any other
-     * batch, and every re-run list: the list kernels, whose blocks walk densely packed lanes (a.list == nullptr: all of them);
-     * list launches get blocks for 3/16 of the lanes (a re-run list is a few percent of them; the blocks walk whatever is more). */
-    const bool whole = all && (a.g.S % 64u) == 0u;
-    const uint32_t wpb = algo == WMBUS_ALGO_RLA ? WM_RLA_WPB : WM_CLK_WPB, B = 64 * wpb;
-    const uint32_t waves = 2u * a.g.nseg[algo] * (a.g.S / 64u);
-    const uint32_t grid = whole ? (waves + wpb - 1) / wpb : all ? (lanes + B - 1) / B : std::max(16u, (lanes / B) * 3u / 16u);
-    /* LDS a first-pass block asks for beyond what it uses (bytes): how many blocks of a framer launch the dispatcher may put on
-     * one CU is bounded by their LDS and registers, and latency-bound waves that share a SIMD slow each other down (tuning aid) */
-    static const unsigned pad_clk = getenv("WMBUS_CLK_PAD") ? (unsigned)atoi(getenv("WMBUS_CLK_PAD")) : 0u;
-    static const unsigned pad_rla = getenv("WMBUS_RLA_PAD") ? (unsigned)atoi(getenv("WMBUS_RLA_PAD")) : 0u;
+    /* list launches: blocks for 3/16 of the lanes (a re-run list is a few percent of them; the blocks walk whatever is more) */
+    const uint32_t B = 64 * (algo == WMBUS_ALGO_RLA ? WM_RLA_WPB : WM_CLK_WPB), grid = all ? (lanes + B - 1) / B : std::max(16u, (lanes / B) * 3u / 16u);
     if (algo == WMBUS_ALGO_RLA) {
-        if (whole) hipLaunchKernelGGL(k2_rla, dim3(grid), dim3(B), pad_rla, st, a);
+        if (all) hipLaunchKernelGGL(k2_rla, dim3(grid), dim3(B), 0, st, a);
         else hipLaunchKernelGGL(k2_rla_list, dim3(grid), dim3(B), 0, st, a);
     }
-    else if (whole) {
-        if (c->flags & WM_F_DC) hipLaunchKernelGGL(k2_clock<true>, dim3(grid), dim3(B), pad_clk, st, a);
-        else hipLaunchKernelGGL(k2_clock<false>, dim3(grid), dim3(B), pad_clk, st, a);
+    else if (all) {
+        if (c->flags & WM_F_DC) hipLaunchKernelGGL(k2_clock<true>, dim3(grid), dim3(B), 0, st, a);
+        else hipLaunchKernelGGL(k2_clock<false>, dim3(grid), dim3(B), 0, st, a);
     } else if (c->flags & WM_F_DC) hipLaunchKernelGGL(k2_clock_list<true>, dim3(grid), dim3(B), 0, st, a);
     else hipLaunchKernelGGL(k2_clock_list<false>, dim3(grid), dim3(B), 0, st, a);
+}
+
+/* the fused launch: clock re-run list (scalar cnt_c) + run-length framer, all lanes (cnt_r == ~0) or its list */
+static void fr_launch_fused(wmbus_ctx *c, uint32_t cnt_c, uint32_t cnt_r)
+{
+    K2Args ca = c->k2clk, ra = c->k2rla;
+    ca.list = c->d_list; ca.n_ptr = c->d_scalars + cnt_c; ca.n_lanes = 0;
+    const uint32_t lanes_r = 2u * ra.g.nseg[0] * ra.g.S, Br = 64 * WM_RLA_WPB;
+    const bool all = cnt_r == 0xFFFFFFFFu;
+    ra.list = all ? nullptr : c->d_list2; ra.n_lanes = lanes_r; ra.n_ptr = all ? nullptr : c->d_scalars + cnt_r;
+    const uint32_t lanes_c = 2u * ca.g.nseg[1] * ca.g.S;
+    const uint32_t cb = std::max(32u, (lanes_c / 64u) * 3u / 16u);           /* one clock wave per block here; blocks for 3/16 of the lanes */
+    const uint32_t rb = all ? (lanes_r + Br - 1) / Br : std::max(16u, (lanes_r / Br) * 3u / 16u);
+    hipLaunchKernelGGL(k2_clock_rla, dim3(cb + rb), dim3(Br), 0, c->stream, ca, ra, cb);
 }
 
 static void fr_carry(wmbus_ctx *c)
@@ -756,7 +759,6 @@ static int enqueue_front_impl(wmbus_ctx *c, size_t nbytes)
     g.warm[0] = c->cfg.warmup_t1c1; g.warm[1] = c->cfg.warmup_s1; g.lookback = c->cfg.rla_lookback;
     static const uint32_t s1_span = getenv("WMBUS_S1_SPAN") ? (uint32_t)atoi(getenv("WMBUS_S1_SPAN")) : 1u;    /* tuning aid, see WmPush.s1_span */
     g.s1_span = s1_span;
-    g.GW = c->GW; g.NG = c->NG;
     g.sp.arena = c->d_spill; g.sp.arena_words = c->spill_words; g.sp.chain = c->d_chain; g.sp.nchain = c->d_nchain;
     g.sp.used = c->d_nchain + (size_t)2 * c->S * c->nseg_cap[0];
     c->last = g; c->have_last = true;
@@ -827,11 +829,25 @@ static int enqueue_front_impl(wmbus_ctx *c, size_t nbytes)
         kr.algo = WMBUS_ALGO_RLA;
         kr.chips = c->d_chips[0]; kr.counts = c->d_counts[0]; kr.sync_seen = c->d_sync_seen[0];
         kr.st_start = c->d_st_start[0]; kr.st_final = c->d_st_final[0]; kr.st_carry = st_carry(c, 0, false);
+        /* fused framer launches (clock re-run lanes + run-length framer in one launch) were worth 4 ms of a context's
+         * dependent chain while every round cost a host round trip; with the rounds enqueued unattended the plain
+         * sequence is 6 % faster for the whole job (r02 sweep: 144.6 / 140.8 against 135.2 / 133.6 Gsamples/s) */
+        static const bool fuse = getenv("WMBUS_FUSE_FRAMERS") && atoi(getenv("WMBUS_FUSE_FRAMERS")) != 0;   /* tuning aid */
         const bool rla = c->flags & WM_F_RLA;
+        c->fused = rla && !(c->flags & WM_F_DC) && fuse;
         c->forked = false;
         HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
         fr_launch(c, WMBUS_ALGO_T2A, 0xFFFFFFFFu);                 /* the clock kernel's first pass */
-        if (rla && c->side_stream && !(c->flags & WM_F_DC)) {
+        if (c->fused) {
+            /* Without the DC remover the slicer words are final after the clock kernel's FIRST pass, so the run-length
+             * framer (main pass, then its own re-run lists) rides in the launches that carry the clock re-run lanes. */
+            for (unsigned r = 0; r < (opt_rounds ? (unsigned)c->fr_rounds : 1u); r++) {     /* round 0 carries the run-length framer's main pass */
+                fr_verify(c, WMBUS_ALGO_T2A, SC_CLK + r);
+                if (r) fr_verify(c, WMBUS_ALGO_RLA, SC_RLA + r);
+                fr_launch_fused(c, SC_CLK + r, r ? SC_RLA + r : 0xFFFFFFFFu);
+            }
+            HIPCHK(c, hipEventRecord(c->ev[8], c->stream));
+        } else if (rla && c->side_stream && !(c->flags & WM_F_DC)) {
             /* Without the DC remover the slicer words are final after the clock kernel's FIRST pass (the sign of a soft
              * symbol carries no state), so the run-length framer and its re-run round need not wait for the clock
              * kernel's re-run rounds: they run beside them on the context's side stream, 4-5 ms off the context's chain
@@ -1092,7 +1108,7 @@ static int wait_gpu(wmbus_ctx *c)
         float ms = 0;
         hipEventElapsedTime(&ms, c->ev[3], c->ev[4]); c->tim.demod_ms = ms;
         hipEventElapsedTime(&ms, c->ev[2], c->ev[3]); c->tim.turn_wait_ms = ms;  /* on the GPU: behind the other contexts' demodulation kernels */
-        hipEventElapsedTime(&ms, c->ev[0], c->ev[8]); c->tim.clock_ms = ms;      /* the clock kernel's launches */
+        hipEventElapsedTime(&ms, c->ev[0], c->ev[8]); c->tim.clock_ms = ms;      /* fused: every framer launch; else the clock kernel's */
         if (c->forked) { hipEventElapsedTime(&ms, c->ev[9], c->ev[10]); c->tim.rla_ms = ms; }   /* side stream: beside the clock kernel's re-run rounds */
         else { hipEventElapsedTime(&ms, c->ev[8], c->ev[1]); c->tim.rla_ms = ms; }                /* un-fused: the run-length framer's launches */
         hipEventElapsedTime(&ms, c->ev[5], c->ev[6]); c->tim.gather_ms = ms;
@@ -1252,13 +1268,12 @@ long wmbus_read_tap(wmbus_ctx *c, const char *what, int chain, unsigned stream, 
     const size_t n = std::min<size_t>(max_elems, c->last.M);
     const size_t row = (size_t)chain * c->S + stream;
     if (!strcmp(what, "dphi")) {
-        if (hipMemcpy(dst, c->d_dphi + wm_dphi_index(c->last, (uint32_t)chain, stream, 0u), n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return WMBUS_EDEVICE;
+        if (hipMemcpy(dst, c->d_dphi + row * c->Mcap, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return WMBUS_EDEVICE;
     } else if (!strcmp(what, "rssi")) {
         if (hipMemcpy(dst, c->d_rssi + row * c->Mcap, n, hipMemcpyDeviceToHost) != hipSuccess) return WMBUS_EDEVICE;
     } else if (!strcmp(what, "bits")) {
         std::vector<uint32_t> w((n + 31) / 32);
-        if (hipMemcpy2D(w.data(), 4, c->d_bits + wm_bits_index(c->last, (uint32_t)chain, stream, 0u), (size_t)c->GW * 4, 4, w.size(), hipMemcpyDeviceToHost) != hipSuccess)
-            return WMBUS_EDEVICE;
+        if (hipMemcpy(w.data(), c->d_bits + row * (c->Mcap / 32), w.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return WMBUS_EDEVICE;
         for (size_t k = 0; k < n; k++) ((uint8_t *)dst)[k] = (w[k >> 5] >> (k & 31)) & 1u;
     } else return WMBUS_EINVAL;
     return (long)n;

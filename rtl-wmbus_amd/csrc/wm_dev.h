@@ -4,15 +4,9 @@
  *
  * HBM layout (per context, S = n_streams, chain c in {T1C1, S1}, algo a in {RLA, T2A}):
  *   in     u8   [S][HIST_BYTES + max_push_bytes + SLACK]   cu8; HIST = tail of the previous push
- *   dphi   f32  [2][S][Mcap]      soft symbol (FIR output), one per decimated sample; capture-major rows (K1 writes whole
- *                                 128-byte lines; a framer lane reads its own row, 32 bytes at a time)
- *   rssi   u8   [2][S][Mcap]      (unsigned) of the filtered magnitude (capture-major: read per chip, by position)
- *   bits   u32  [2][NG][Mcap/32][GW]     slicer output, bit j of word w = sample 32w+j.  WAVE-TRANSPOSED: captures come in groups
- *                                 of GW (64; fewer only when the batch has fewer) and the words of a group's captures at one time
- *                                 lie side by side -- the framer lanes of a wave are GW consecutive captures at the SAME time, so
- *                                 a wave stores / loads one 256-byte piece per 32 samples, without staging.  (Round 4 tried the
- *                                 same for the soft symbols, [t/8][capture][8]: the framers liked it, but K1 then writes 32-byte
- *                                 sectors 2 KB apart and ran 8 % slower alone, 25 % with 1024 captures per launch.)
+ *   dphi   f32  [2][S][Mcap]      soft symbol (FIR output), one per decimated sample
+ *   rssi   u8   [2][S][Mcap]      (unsigned) of the filtered magnitude
+ *   bits   u32  [2][S][Mcap/32]   slicer output, bit j of word w = sample 32w+j
  *   chips  u32  [2][2][S][nseg][cap_a]  per time segment; word = pos<<3 | value (bit, sync, reset); the RSSI of
  *                                       a chip is rssi[row][sample of the chip] (K3 / K4 insert it into bits 15:8)
  *   state arrays, burst arena (see structs below)
@@ -113,34 +107,7 @@ struct WmPush {
     uint32_t s1_span;        /* 2: an S1 clock lane covers two consecutive segments (its warm-up is twice T1/C1's, so at the
                                 same segment length it re-reads 75 % instead of 37 %); 0 / 1: one segment per lane */
     WmSpill sp;              /* run-length chips beyond cap[0]                        */
-    uint32_t GW, NG;         /* capture groups of the wave-transposed slicer words: GW captures each (a power of two <= 64),
-                                NG = ceil(S / GW) of them */
 };
-
-/* Group geometry for S captures: 64 per group, or the next power of two >= S for a smaller batch. */
-static inline void wm_group_geometry(uint32_t S, uint32_t *gw, uint32_t *ng)
-{
-    uint32_t w = 64u;
-    if (S < 64u) { w = 1u; while (w < S) w *= 2u; }
-    *gw = w; *ng = (S + w - 1u) / w;
-}
-#ifndef WM_HD
-#if defined(__HIPCC__)
-#define WM_HD __host__ __device__ __forceinline__
-#else
-#define WM_HD static inline
-#endif
-#endif
-/* Soft symbol t of capture s, chain ch (element index into dphi). */
-WM_HD uint64_t wm_dphi_index(const WmPush &g, uint32_t ch, uint32_t s, uint32_t t)
-{
-    return ((uint64_t)ch * g.S + s) * g.Mcap + t;
-}
-/* Slicer word w (samples 32 w .. 32 w + 31) of capture s, chain ch (element index into bits). */
-WM_HD uint64_t wm_bits_index(const WmPush &g, uint32_t ch, uint32_t s, uint32_t w)
-{
-    return (((uint64_t)ch * g.NG + s / g.GW) * (g.Mcap / 32u) + w) * g.GW + s % g.GW;
-}
 
 enum {
     WM_F_SHIFT = 1, WM_F_ACCURATE = 2, WM_F_DC = 4, WM_F_T1C1 = 8, WM_F_S1 = 16,

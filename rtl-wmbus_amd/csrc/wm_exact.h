@@ -19,12 +19,10 @@
 #include <stdint.h>
 #include <string.h>
 
-#ifndef WM_HD
 #if defined(__HIPCC__)
 #define WM_HD __host__ __device__ __forceinline__
 #else
 #define WM_HD static inline
-#endif
 #endif
 
 WM_HD uint32_t wm_f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }

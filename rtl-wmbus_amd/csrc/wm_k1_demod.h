@@ -139,7 +139,7 @@ __device__ __forceinline__ void k1_fir_t(const K1Args &a, const float *yDrT, con
         for (int k = 0; k < 11; k++) s = FAST ? __builtin_fmaf(FIR_T[k], w[12 + j - k], s) : wm_add(s, wm_mul(FIR_T[k], w[12 + j - k]));
         acc[j] = s;
     }
-    *(float4 *)(a.dphi + wm_dphi_index(g, 0u, (uint32_t)stream, (uint32_t)(ts + m0l))) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    *(float4 *)(a.dphi + (uint64_t)stream * g.Mcap + (uint64_t)ts + m0l) = make_float4(acc[0], acc[1], acc[2], acc[3]);
 }
 
 template <bool FAST = false>
@@ -162,7 +162,7 @@ __device__ __forceinline__ void k1_fir_s(const K1Args &a, const float *yDrS, con
         for (int k = 0; k < 46; k++) s = FAST ? __builtin_fmaf(FIR_S[k], w[48 + j - k], s) : wm_add(s, wm_mul(FIR_S[k], w[48 + j - k]));
         acc[j] = s;
     }
-    *(float4 *)(a.dphi + wm_dphi_index(g, 1u, (uint32_t)stream, (uint32_t)(ts + m0l))) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    *(float4 *)(a.dphi + ((uint64_t)g.S + stream) * g.Mcap + (uint64_t)ts + m0l) = make_float4(acc[0], acc[1], acc[2], acc[3]);
 }
 
 /* Stages B1 (FIR low-pass, y[n] = sum_k b[k] x[n-k], k ascending, fir.h:48-72) and B2 (RSSI EMA,

@@ -4,23 +4,6 @@
 #define WM_K2_CLOCK_H
 
 struct IirCoef { float a1[3], a2[3], b1[3], b2[3]; };
-#if defined(__HIP_DEVICE_COMPILE__) || defined(__clang__)
-typedef float wm_f4 __attribute__((ext_vector_type(4)));     /* a native 4-vector: one 128-bit register tuple */
-#else
-struct wm_f4 { float x, y, z, w; };
-#endif
-
-#if defined(__HIP_DEVICE_COMPILE__)
-/* "these twelve words are in registers NOW" (an empty asm that takes them in and hands them back): the compiler waits for
- * their loads here and no longer counts them as in flight afterwards */
-#define WM_SETTLED12(st) do { uint32_t *w_ = (uint32_t *)&(st); \
-    asm volatile("" : "+v"(w_[0]), "+v"(w_[1]), "+v"(w_[2]), "+v"(w_[3]), "+v"(w_[4]), "+v"(w_[5]), "+v"(w_[6]), "+v"(w_[7]), \
-                      "+v"(w_[8]), "+v"(w_[9]), "+v"(w_[10]), "+v"(w_[11])); } while (0)
-#define WM_CLAIM2(a, b) asm volatile("" : "+v"(a), "+v"(b))
-#else
-#define WM_SETTLED12(st) do { } while (0)
-#define WM_CLAIM2(a, b) do { } while (0)
-#endif
 
 __device__ __forceinline__ IirCoef iir_coef(uint32_t ch)
 {
@@ -59,7 +42,10 @@ __device__ __forceinline__ bool clk_step(WmClkState &s, const IirCoef &c, bool d
     return wm_mul(v, 1.874981046e-06f) >= 0.0f;
 }
 
-#define WM_CLK_CROW 17           /* words per lane in the clock kernel's chip staging (16 + 1: conflict-free) */
+#define WM_CLK_XROW 36           /* words per lane in the clock kernel's soft-symbol buffer: 32 + 4 (rows stay 16-byte
+                                    aligned; a lane's 8 ds_read_b128 are bank-conflict free: 9 L mod 16 is a permutation) */
+#define WM_CLK_CROW 17           /* words per lane in its chip staging (16 + 1) */
+#define WM_CLK_BROW 9            /* words per lane in its slicer-word staging (8 + 1) */
 
 /* 32 samples through [DC remover] -> x^2 -> 3 biquads -> clock level, SOFTWARE-PIPELINED across the
  * filter sections: at tick t section k works on sample t - k, so the three (four with -o) recurrences
@@ -70,20 +56,15 @@ __device__ __forceinline__ bool clk_step(WmClkState &s, const IirCoef &c, bool d
  * drains at the end of the block: the lane state at block boundaries is the plain sequential
  * state.  Every value is produced by exactly the operations of iir.h:57-74 / rtl_wmbus.c:497-515.
  *
- * Input: X[0..7] = the lane's 32 soft symbols as eight float4, in REGISTERS: every lane loads from its own capture's row
- * (round 3 fetched the 64 rows' lines cooperatively, 8 lanes per line, and transposed them through 36 KB of LDS per block).  The registers double as the
- * prefetch queue: at tick 8 j samples 8 j .. 8 j + 7 move to two working tuples and `refill(j)` issues the two 16-byte loads
- * of the NEXT block's samples 8 j .. 8 j + 7 into the eight registers just vacated -- every load has a whole block (34
- * ticks) to arrive, with 32 + 8 registers instead of round 3's 64 + an LDS round trip per block (tools/clkbench.hip: at
- * 1024 waves 1.7 us per block against 1.66 for the arithmetic alone; refilling only after tick 8 j + 7, 26 ticks of lead,
- * cost 2.13).  The fences keep the loads where they are written (the scheduler would sink them to their uses).
- *
  * Bits: the slicer output (soft >= 0, rtl_wmbus.c:1059) is the inverted sign bit -- a soft symbol
  * is never -0 (the FIR accumulates from +0, and +0 + -0 = +0; the DC remover's x - x_old is never
  * -0 either) -- shifted into a word with one v_alignbit; clock levels via WM_LEVEL_CARRY. */
-template <bool DC, typename Refill>
-__device__ __forceinline__ void clk_block32(WmClkState &s, const IirCoef &c, wm_f4 (&X)[8], Refill &&refill, uint32_t &bitw, uint32_t &smask)
+template <bool DC>
+__device__ __forceinline__ void clk_block32(WmClkState &s, const IirCoef &c, const float *xrow, uint32_t &bitw, uint32_t &smask)
 {
+    /* xrow: this lane's 32 soft symbols in LDS; four are fetched every fourth tick, so the block in
+     * flight and the one after it can stay in registers (two blocks of loads outstanding per lane) */
+    float4 xq = {0.0f, 0.0f, 0.0f, 0.0f};
     constexpr int P = DC ? 1 : 0;                          /* pipeline depth before the first biquad */
     float h1[3] = {s.h[0], s.h[2], s.h[4]}, h2[3] = {s.h[1], s.h[3], s.h[5]};
     float dcx = s.dc_x, dcy = s.dc_y;
@@ -91,23 +72,12 @@ __device__ __forceinline__ void clk_block32(WmClkState &s, const IirCoef &c, wm_
     float soft = 0.0f;                                     /* DC stage output waiting for section 0 */
     uint32_t sgn = 0, low = 0;                             /* MSB-first: sample n ends up in bit 31 - n */
     const float al = 0.999f, kk = wm_div(wm_add(1.0f, al), 2.0f);
-    wm_f4 W[2] = {};                                       /* the eight samples in work */
 #pragma unroll
     for (int t = 0; t < 32 + P + 2; t++) {
         float m1[3], m2[3], p1[3], p2[3], tt[3], h0[3], u[3], o[3];
         float d1 = 0.0f, d2 = 0.0f, d3 = 0.0f;
-        /* the two 16-byte loads of samples t .. t + 7 are claimed HERE, as whole register tuples (an empty asm that takes
-         * them in and hands them back): the wait for them is placed at this tick, and the values cross the loop's back edge
-         * as the tuples the loads wrote -- split into 32 scalars they got a second register set and a copy per block.  They
-         * move into two working tuples, and the loads of the NEXT block's samples t .. t + 7 are issued at once into the
-         * registers just vacated: a whole block (34 ticks) of lead for 32 + 8 registers. */
-        if (t < 32 && (t & 7) == 0) {
-            WM_CLAIM2(X[t >> 2], X[(t >> 2) + 1]);
-            W[0] = X[t >> 2]; W[1] = X[(t >> 2) + 1];
-            refill(t >> 3);
-        }
-        const wm_f4 &xq = W[(t >> 2) & 1];
-        const float xt = t >= 32 ? 0.0f : (t & 3) == 0 ? xq.x : (t & 3) == 1 ? xq.y : (t & 3) == 2 ? xq.z : xq.w;   /* sample t */
+        if (t < 32 && (t & 3) == 0) xq = *(const float4 *)(xrow + t);
+        const float xt = (t & 3) == 0 ? xq.x : (t & 3) == 1 ? xq.y : (t & 3) == 2 ? xq.z : xq.w;   /* sample t (t < 32) */
         /* level 1: every product that only needs last tick's state */
         if (DC && t < 32) { d1 = wm_sub(xt, dcx); d2 = wm_mul(al, dcy); }
         {   /* section 0's input: the (DC-filtered) soft symbol, squared */
@@ -172,13 +142,37 @@ __device__ __forceinline__ void clk_block32(WmClkState &s, const IirCoef &c, wm_
  * levels at n-3..n are L,H,H,H" (checked exhaustively over all level sequences);
  * the lane state keeps the last three levels.
  *
- * Memory: a lane walks its own capture's row of soft symbols, 32 bytes (8 samples, one sector) at a time: a 128-byte line
- * per 32-sample block, asked for in four pieces 8 ticks apart (the line stays in L2 meanwhile).  Slicer words go to the
- * wave-transposed array of wm_dev.h: the 64 lanes of a first-pass wave are the 64 captures of one group at the same time,
- * one coalesced 256-byte store per wave and block, no staging.  A re-run lane (any capture, any segment) uses the same
- * addresses on its own. */
+ * Memory: a lane walks its own row (stream, chain) of soft symbols, 128 bytes per 32-sample block.
+ * When the 64 lanes of the wave are 64 consecutive streams of one (chain, segment) -- n_streams a
+ * multiple of 64, first pass -- the wave fetches the 64 rows' blocks COOPERATIVELY: 8 lanes per
+ * row read one whole 128-byte line, and the block is transposed through LDS (conflict-free, see
+ * WM_CLK_XROW).  Lane-private 16-byte loads of the same data touch 64 lines per instruction and
+ * re-fetch each line from L2 several times.  Re-run launches and odd stream counts take the
+ * lane-private path. */
+/* The same block, one sample after the other (clk_step): a 36-deep dependent chain per sample instead
+ * of three interleaved ones, but a fraction of the registers.  Candidate for the few re-run lanes of the
+ * fused launch (k2_clock_rla), whose register need is also what its thousand run-length waves are
+ * charged; selected with WM_FUSED_LEAN_CLOCK (off: not measured yet).  Host-emulated against the oracle. */
+template <bool DC>
+__device__ __forceinline__ void clk_block32_lean(WmClkState &s, const IirCoef &c, const float *xrow, uint32_t &bitw, uint32_t &smask)
+{
+    uint32_t bw = 0, sm = 0, hist = s.clk;
+#pragma unroll 1
+    for (uint32_t k = 0; k < 32u; k++) {
+        float soft;
+        const uint32_t high = clk_step(s, c, DC, xrow[k], soft);
+        hist = ((hist << 1) | high) & 0xFu;
+        bw |= (uint32_t)(soft >= 0.0f) << k;
+        sm |= (uint32_t)(hist == 7u) << k;
+    }
+    s.clk = hist & 7u;
+    bitw = bw; smask = sm;
+}
+
 template <int W> struct ClkLds {         /* per block: W independent waves */
+    float x[W][64 * WM_CLK_XROW];
     uint32_t chip[W][64 * WM_CLK_CROW];
+    uint32_t bits[W][64 * WM_CLK_BROW];
 };
 
 /* WM_CLK_WPB independent waves per block (no block-wide barrier anywhere): a block's waves land on
@@ -186,38 +180,24 @@ template <int W> struct ClkLds {         /* per block: W independent waves */
  * long-running wave on ONE SIMD slows every 4-wave K1 block of that CU down to the pace of the K1
  * wave that shares the SIMD with it (measured: two clock launches in flight, one wave per CU, cost
  * K1 60 %). */
-/* PASS: 0 = the speculative first pass of a batch of whole waves (uniform loops, see below), 1 = a re-run list only, 2 = a
- * re-run list (a.list set) or a first pass with densely packed lanes (any batch size): each kind of launch has its own kernel,
- * so the uniform first pass carries neither the list walk nor the checkpoint comparison. */
-template <bool DC, int W, int PASS = 2>
+/* PASS: 0 = the speculative first pass only (a.list == nullptr), 1 = a re-run list only, 2 = either (host emulation): each kind of launch has its own
+ * kernel, so the first pass carries neither the list walk nor the checkpoint comparison (with both in one kernel behind
+ * a grid-stride loop the first pass needed 254 VGPRs + 16 AGPRs and ran at one wave per SIMD, round 2). */
+template <bool DC, int W, bool LEAN = false, int PASS = 2>
 __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t block, ClkLds<W> &lds)
 {
     const uint32_t ln = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    if (wv >= (uint32_t)W) return;
-    uint32_t *s_chip = lds.chip[wv];
+    if (wv >= (uint32_t)W) return;           /* W < waves of the block: the fused launch (see k2_clock_rla) */
+    float *s_x = lds.x[wv];
+    uint32_t *s_chip = lds.chip[wv], *s_bits = lds.bits[wv];
+    uint32_t lane = (block * W + wv) * 64 + ln;
     const bool rerun = PASS == 2 ? a.list != nullptr : PASS == 1;
     const WmPush &g = a.g;
+    const bool coop = !rerun && (g.S % 64u) == 0u;         /* wave = 64 consecutive streams, lock step */
+    if (lane >= k2_lane_count(a)) return;
+    if (rerun) lane = a.list[lane];
     uint32_t ch, stream, seg;
-    if (PASS == 0) {
-        /* FIRST PASS of a batch of whole waves (S a multiple of 64): a wave is one (chain, segment) and 64 consecutive
-         * captures.  Everything that steers the lane's loop (segment bounds, block counter) is then the same in all 64
-         * lanes and is kept in scalar registers: the loop is UNIFORM.  That is what lets the soft-symbol registers be
-         * refilled in place while a block is in work (clk_block32): values that live across a divergent loop get a second
-         * register set and a copy -- and a wait for everything in flight -- at every trip. */
-        const uint32_t w = WM_UNI(block * (uint32_t)W + wv), ngrp = g.S / 64u;
-        const uint32_t r = w / ngrp;
-        seg = r % g.nseg[1]; ch = r / g.nseg[1]; stream = (w % ngrp) * 64u + ln;
-        if (ch >= 2u) return;
-    } else {
-        /* a re-run list, or the first pass of any other batch: lanes are (chain, capture, segment) in any mixture, packed
-         * densely -- a wave with most of its lanes idle runs several times slower PER INSTRUCTION on gfx950
-         * (tools/clkbench.hip: 7.7 us per block with one active lane against 1.6 with 64), so a small batch spreads its
-         * segments over the lanes of few waves instead of giving every segment a wave of its own */
-        uint32_t lane = (block * W + wv) * 64 + ln;
-        if (lane >= k2_lane_count(a)) return;
-        if (rerun) lane = a.list[lane];
-        lane_decode(g, 1, lane, ch, stream, seg);
-    }
+    lane_decode(g, 1, lane, ch, stream, seg);
     if (!(g.flags & (ch ? WM_F_S1 : WM_F_T1C1))) return;
 
     /* S1 lanes may span two segments (WmPush.s1_span): the odd segment rides with its even predecessor.  The lane then
@@ -228,7 +208,7 @@ __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t bloc
     if (seg % span) return;
     const uint64_t row = (uint64_t)ch * g.S + stream;
     const uint64_t sidx = row * g.nseg_cap[1] + seg;
-    const uint32_t mb = seg * g.seg_len[1], me = min(g.M, mb + span * g.seg_len[1]);      /* wave-uniform in the first pass (seg is) */
+    const uint32_t mb = seg * g.seg_len[1], me = min(g.M, mb + span * g.seg_len[1]);
     const uint32_t covered = (me - mb + g.seg_len[1] - 1u) / g.seg_len[1];          /* segments this lane really covers: 1 or 2 */
     const uint32_t cap_t2 = covered * g.cap[1];
     const uint32_t nck = covered == 2u ? 2u * a.nck : a.nck;                          /* checkpoint slots (one interior point of a pair has none) */
@@ -242,19 +222,18 @@ __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t bloc
         const uint32_t w = g.warm[ch];
         if (mb <= w) { s = stC[row]; m = 0; }            /* exact: run from the push start  */
         else { s = WmClkState{}; m = mb - w; }           /* speculative cold start          */
-        if (PASS == 0) m = WM_UNI(m);
     }
-    /* the state is complete before the first soft symbol is asked for, on every path: otherwise the block loop's (static)
-     * waits also have to cover the state's loads of the first trip, and wait for too much on every later one */
-    WM_SETTLED12(s);
     const IirCoef c = iir_coef(ch);
     const bool t2a = g.flags & WM_F_T2A;
-    /* this capture's row of soft symbols; sector q (samples 8 q .. 8 q + 7, 32 bytes) lies q * gs floats further */
-    const float *x = a.dphi + wm_dphi_index(g, ch, stream, 0u);
-    constexpr uint64_t gs = 8;
+    const float *x = a.dphi + row * g.Mcap;
+    /* cooperative view: lane ln fetches piece ln%8 of row (8 i + ln/8), i = 0..7; rows of the wave
+     * are consecutive */
+    const uint64_t row0 = row - ln;
+    const float *xc = a.dphi + (row0 + (ln >> 3)) * g.Mcap + 4u * (ln & 7u);
+    const uint64_t xc_step = 8ull * g.Mcap;
     const uint32_t syncw = ch ? WM_SYNC_S1 : WM_SYNC_T1C1, syncm = ch ? WM_SYNC_S1_MASK : WM_SYNC_T1C1_MASK;
     uint32_t *out = a.chips + sidx * g.cap[1];            /* region pitch (cap_t2 may be two regions) */
-    uint32_t *bw = a.bits + wm_bits_index(g, ch, stream, 0u);    /* word w of this capture at bw[w * GW] */
+    uint32_t *bw = a.bits + row * (g.Mcap / 32);
     uint32_t n_out = 0, saw_sync = 0;
 
     /* chips of one 32-sample block: walk the set bits of the sample mask (ragged tail, shift
@@ -275,32 +254,80 @@ __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t bloc
     };
 
     const uint32_t me_full = mb + ((me - mb) & ~31u);
+    /* Two blocks of loads are kept in flight per lane (register sets A and B, used alternately):
+     * with one, the kernel ran at the latency of a single 10 KB request per wave (2.8 TB/s). */
 #ifndef WM_CLK_EARLY_EXIT
 #define WM_CLK_EARLY_EXIT 1        /* 0: always eight trips through the chip loops of a block (the round-1 form; A/B) */
 #endif
 #ifndef WM_CLK_SR_WINDOW
 #define WM_CLK_SR_WINDOW 1024     /* 0: shift-register upkeep over the whole warm-up (the r03 form; A/B) */
 #endif
-    const uint32_t m_last = me_full >= 32u ? me_full - 32u : 0u;      /* clamp for prefetches past the end */
-    wm_f4 X[8];                                                       /* the block in work; its retired registers take the next block */
-    const float *pn = x;                                              /* sector 0 of the block being prefetched */
-    auto refill = [&](int j) {
-        X[2 * j] = *(const wm_f4 *)(pn + (uint64_t)j * gs);
-        X[2 * j + 1] = *(const wm_f4 *)(pn + (uint64_t)j * gs + 4);
-    };
-    auto aim = [&](uint32_t mm) { pn = x + (uint64_t)(mm >> 3) * gs; };   /* mm: a multiple of 32 */
-
-    /* ONE loop over the lane's 32-sample blocks, warm-up and segment proper alike (which of the two a block is, is a uniform
-     * question in the first pass): the soft-symbol registers then have a single loop to live across, and the compiler keeps
-     * them in place -- with a loop per phase, or the checkpoints as an outer loop, it gave the loads a second register set
-     * and copied 32 registers per block behind a wait for everything in flight. */
-    if (m < me_full) {
-        aim(m);
-        /* in the order the block consumes them, fenced: the waits in the loop are counted ("all but the three youngest
-         * pairs"), and one wait instruction has to be right for the first trip and for every later one */
+#ifndef WM_CLK_PREFETCH
+#define WM_CLK_PREFETCH 2          /* blocks of loads in flight per lane; 1 = build-time experiment (32 VGPRs fewer) */
+#endif
+    constexpr uint32_t AHEAD = 32u * WM_CLK_PREFETCH;
+    float4 gxA[8], gxB[8];
+    auto fetch_x = [&](float4 (&gx)[8], uint32_t mm) {
+        if (coop) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) { refill(j); __builtin_amdgcn_sched_barrier(0); }
+            for (int i = 0; i < 8; i++) gx[i] = *(const float4 *)(xc + i * xc_step + mm);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) gx[i] = *(const float4 *)(x + mm + 4 * i);
+        }
+    };
+    /* registers -> LDS rows (coop: the pieces I fetched for other lanes' rows; else my own row) */
+    const uint32_t xw = coop ? (ln >> 3) * WM_CLK_XROW + 4u * (ln & 7u) : ln * WM_CLK_XROW;
+    const uint32_t xw_step = coop ? 8u * WM_CLK_XROW : 4u;
+    const float *xrow = s_x + ln * WM_CLK_XROW;
+    auto put_x = [&](const float4 (&gx)[8]) {
+        __builtin_amdgcn_wave_barrier();                     /* the previous block's reads are done */
+#pragma unroll
+        for (int i = 0; i < 8; i++) *(float4 *)(s_x + xw + i * xw_step) = gx[i];
+        __builtin_amdgcn_wave_barrier();
+    };
+    const uint32_t m_last = me_full >= 32u ? me_full - 32u : 0u;      /* clamp for prefetches past the end */
+
+    /* ---- phase 1: warm-up blocks [m, mb): soft symbols only; no store is issued in this loop, so
+     * waiting for a block in flight never waits for anything else (gfx950's vmcnt counts loads
+     * and stores in one in-order queue) --------------------------------------------------------- */
+    auto warm_block = [&](float4 (&gx)[8]) {
+        put_x(gx);
+        fetch_x(gx, min(m + AHEAD, m_last));
+        uint32_t bitw, smask;
+        if (LEAN) clk_block32_lean<DC>(s, c, xrow, bitw, smask); else clk_block32<DC>(s, c, xrow, bitw, smask);
+        /* shift-register upkeep: at most 8 chips per block, oldest first; the wave stops as soon as none of its lanes
+         * has a chip left (T1/C1 lanes meet 4 per block, S1 lanes 1.3: half the trips of the fixed eight).  The register
+         * is a function of the last 16 / 24 chips only, so the upkeep starts WM_CLK_SR_WINDOW samples before the segment
+         * (>= 40 chips of either chain at their nominal rates; if a stretch of silence leaves fewer, the hand-off does not
+         * certify and the segment is re-run, as after any other uncertified start) */
+        if (WM_CLK_SR_WINDOW && mb - m > (uint32_t)WM_CLK_SR_WINDOW) smask = 0u;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const bool has = smask != 0u;
+            if (WM_CLK_EARLY_EXIT && __ballot(has) == 0ull) break;
+            const uint32_t k = has ? (uint32_t)__ffs((int)smask) - 1u : 0u;
+            smask &= smask - 1u;
+            const uint32_t sr_new = ((s.sr << 1) | ((bitw >> k) & 1u)) & syncm;
+            s.sr = has ? sr_new : s.sr;
+        }
+        m += 32;
+    };
+    if (m < me_full) { fetch_x(gxA, m); if (WM_CLK_PREFETCH == 2) fetch_x(gxB, min(m + 32u, m_last)); }
+    while (m < mb) {
+        warm_block(gxA);
+        if (WM_CLK_PREFETCH == 1) continue;
+        if (m < mb) warm_block(gxB);
+        else {                                               /* keep "A = next block" for phase 2 */
+#pragma unroll
+            for (int i = 0; i < 8; i++) { const float4 t = gxA[i]; gxA[i] = gxB[i]; gxB[i] = t; }
+        }
     }
+    stS[sidx] = s;                                       /* state the main loop starts from */
+    /* ---- phase 2: blocks of the segment proper.  Exactly three stores per block (slicer word and
+     * two 16-byte chip stores; a block holds at most 8 chips because the lock pattern L,H,H,H needs 4
+     * samples, and slots beyond the block's chips are overwritten by the next block), so the
+     * compiler can wait for a prefetched block with a counted vmcnt instead of draining the stores. */
     /* chips leave in whole, 32-byte aligned groups of 8 (see k2_rla: partial-sector stores from
      * 131 072 lanes with private output regions become read-modify-write traffic) */
     uint32_t *my_chip = s_chip + ln * WM_CLK_CROW;
@@ -315,38 +342,13 @@ __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t bloc
         for (int i = 0; i < 8; i++) { const uint32_t v = my_chip[8 + i]; if (8u + i < pend) my_chip[i] = v; }
         n_fl += 8u; pend = pend > 8u ? pend - 8u : 0u;
     };
-    uint32_t *ck = a.ckpt + sidx * (uint64_t)a.nck * 16u;
-    uint32_t ckj = 0;                                    /* next interior checkpoint */
-    if (m >= mb) stS[sidx] = s;                          /* no warm-up: the state the segment starts from */
-    while (m < me_full) {
-        aim(min(m + 32u, m_last));
+    /* slicer words leave in aligned groups of 8 as well (one word per 32 samples and lane) */
+    uint32_t *my_bits = s_bits + ln * WM_CLK_BROW;
+    auto main_block = [&](float4 (&gx)[8]) {
+        put_x(gx);
+        fetch_x(gx, min(m + AHEAD, m_last));
         uint32_t bitw, smask;
-        clk_block32<DC>(s, c, X, refill, bitw, smask);
-        if (m < mb) {
-            /* ---- warm-up block: soft symbols only, no store (waiting for a load in flight never waits for anything else:
-             * gfx950's vmcnt counts loads and stores in one in-order queue).  Shift-register upkeep: at most 8 chips per
-             * block, oldest first; the wave stops as soon as none of its lanes has a chip left (T1/C1 lanes meet 4 per
-             * block, S1 lanes 1.3).  The register is a function of the last 16 / 24 chips only, so the upkeep starts
-             * WM_CLK_SR_WINDOW samples before the segment (>= 40 chips of either chain at their nominal rates; if a stretch
-             * of silence leaves fewer, the hand-off does not certify and the segment is re-run, as after any other
-             * uncertified start) */
-            if (WM_CLK_SR_WINDOW && mb - m > (uint32_t)WM_CLK_SR_WINDOW) smask = 0u;
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const bool has = smask != 0u;
-                if (WM_CLK_EARLY_EXIT && __ballot(has) == 0ull) break;
-                const uint32_t k = has ? (uint32_t)__ffs((int)smask) - 1u : 0u;
-                smask &= smask - 1u;
-                const uint32_t sr_new = ((s.sr << 1) | ((bitw >> k) & 1u)) & syncm;
-                s.sr = has ? sr_new : s.sr;
-            }
-            m += 32;
-            if (m == mb) stS[sidx] = s;                  /* state the segment proper starts from */
-            continue;
-        }
-        /* ---- block of the segment proper.  Stores: the slicer word (always) and two 16-byte chip stores when eight chips
-         * have gathered (a block holds at most 8 chips because the lock pattern L,H,H,H needs 4 samples, and slots beyond
-         * the block's chips are overwritten by the next block). */
+        if (LEAN) clk_block32_lean<DC>(s, c, xrow, bitw, smask); else clk_block32<DC>(s, c, xrow, bitw, smask);
         uint32_t cnt = 0;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
@@ -363,12 +365,27 @@ __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t bloc
             cnt += has;
         }
         pend += t2a ? cnt : 0u;
-        bw[(uint64_t)(m >> 5) * g.GW] = bitw;                                 /* the wave's 64 words are one 256-byte piece */
+        const uint32_t bi = m >> 5;
+        my_bits[bi & 7u] = bitw;
+        if ((bi & 7u) == 7u) {
+            uint32_t w[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) w[i] = my_bits[i];
+            *(uint4 *)(bw + (bi - 7u)) = make_uint4(w[0], w[1], w[2], w[3]);
+            *(uint4 *)(bw + (bi - 3u)) = make_uint4(w[4], w[5], w[6], w[7]);
+        }
         if (pend >= 8u) flush8();
         m += 32;
-        if (((m - mb) & (uint32_t)(WM_CK_SAMPLES - 1)) == 0u && m < me_full && ckj < nck) {      /* interior checkpoint ckj */
-            uint32_t *q = ck + 16u * ckj;
-            const uint32_t j = ckj++;
+    };
+    uint32_t *ck = a.ckpt + sidx * (uint64_t)a.nck * 16u;
+    for (uint32_t j = 0; m < me_full; j++) {
+        const uint32_t stop = min(me_full, m + (uint32_t)WM_CK_SAMPLES);     /* an even number of blocks, or the end */
+        while (m < stop) {
+            main_block(gxA);
+            if (WM_CLK_PREFETCH == 2 && m < stop) main_block(gxB);
+        }
+        if (m < me_full && j < nck) {                    /* interior checkpoint j */
+            uint32_t *q = ck + 16u * j;
             const uint32_t *sw = (const uint32_t *)&s;
             if (!rerun) {
                 *(uint4 *)(q) = make_uint4(sw[0], sw[1], sw[2], sw[3]);
@@ -412,20 +429,20 @@ __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t bloc
             }
         }
     }
+    for (uint32_t bi = (m >> 5) & ~7u; bi < (m >> 5); bi++) bw[bi] = my_bits[bi & 7u];   /* incomplete last group */
     n_out = n_fl + pend;
     if (pend) flush8();                                  /* last group; slots beyond n_out are never read */
     if (m < me) {                                        /* ragged tail of the last segment */
         uint32_t bitw = 0, smask = 0, hist = s.clk;
         for (uint32_t k = 0; m + k < me; k++) {
             float soft;
-            const uint32_t mm = m + k;
-            const uint32_t high = clk_step(s, c, DC, x[(uint64_t)(mm >> 3) * gs + (mm & 7u)], soft);
+            const uint32_t high = clk_step(s, c, DC, x[m + k], soft);
             hist = ((hist << 1) | high) & 0xFu;
             bitw |= (uint32_t)(soft >= 0.0f) << k;
             smask |= (uint32_t)(hist == 7u) << k;
         }
         s.clk = hist & 7u;
-        bw[(uint64_t)(m >> 5) * g.GW] = bitw;
+        bw[m >> 5] = bitw;
         emit_block(m, smask, bitw, true);
     }
     stF[sidxF] = s;
@@ -435,24 +452,21 @@ __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t bloc
     if (n_out > cap_t2) atomicOr(a.err, WM_ERR_CHIP_OVERFLOW);       /* cannot happen: the lock pattern takes >= 4 samples per chip */
 }
 
-#ifndef WM_CLK_WAVES_PER_SIMD
-#define WM_CLK_WAVES_PER_SIMD 1        /* build-time experiment: 4 = at most 128 VGPRs */
-#endif
 template <bool DC>
-__global__ __launch_bounds__(64 * WM_CLK_WPB, WM_CLK_WAVES_PER_SIMD) void k2_clock(K2Args a)                 /* first pass: one block per 64 * WM_CLK_WPB lanes */
+__global__ __launch_bounds__(64 * WM_CLK_WPB) void k2_clock(K2Args a)                 /* first pass: one block per 64 * WM_CLK_WPB lanes */
 {
     wm_framer_prio();
     __shared__ __attribute__((aligned(16))) ClkLds<WM_CLK_WPB> lds;
-    clock_lanes<DC, WM_CLK_WPB, 0>(a, blockIdx.x, lds);
+    clock_lanes<DC, WM_CLK_WPB, false, 0>(a, blockIdx.x, lds);
 }
 
 template <bool DC>
-__global__ __launch_bounds__(64 * WM_CLK_WPB, WM_CLK_WAVES_PER_SIMD) void k2_clock_list(K2Args a)            /* a fixed grid whose blocks walk a re-run list, or (a.list == nullptr) every lane of a batch that is not whole waves */
+__global__ __launch_bounds__(64 * WM_CLK_WPB) void k2_clock_list(K2Args a)            /* re-run list: a fixed grid whose blocks walk the list */
 {
     wm_framer_prio();
     __shared__ __attribute__((aligned(16))) ClkLds<WM_CLK_WPB> lds;
     const uint32_t n = k2_lane_count(a);
-    for (uint32_t b = blockIdx.x; (uint64_t)b * (64u * WM_CLK_WPB) < n; b += gridDim.x) clock_lanes<DC, WM_CLK_WPB, 2>(a, b, lds);
+    for (uint32_t b = blockIdx.x; (uint64_t)b * (64u * WM_CLK_WPB) < n; b += gridDim.x) clock_lanes<DC, WM_CLK_WPB, false, 1>(a, b, lds);
 }
 
 #endif /* WM_K2_CLOCK_H */

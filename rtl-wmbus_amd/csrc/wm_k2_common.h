@@ -41,14 +41,6 @@ __device__ __forceinline__ void wm_framer_prio() { __builtin_amdgcn_s_setprio(WM
 __device__ __forceinline__ void wm_framer_prio() {}
 #endif
 
-/* a value that is the same in every lane of the wave, moved to a scalar register (so that what is computed from it, and the
- * branches taken on it, are uniform); the host emulation runs one lane at a time */
-#if defined(__HIP_DEVICE_COMPILE__)
-#define WM_UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
-#else
-#define WM_UNI(x) ((uint32_t)(x))
-#endif
-
 __device__ __forceinline__ uint32_t k2_lane_count(const K2Args &a) { return a.n_ptr ? *a.n_ptr : a.n_lanes; }
 
 __device__ __forceinline__ void lane_decode(const WmPush &g, uint32_t algo, uint32_t lane, uint32_t &ch, uint32_t &stream, uint32_t &seg)

@@ -58,28 +58,19 @@ __device__ __forceinline__ uint32_t deglitch_word(uint32_t W, bool s1)
  * from the masked history.  WmRlaState.raw keeps the last five raw bits in time order. */
 struct RlaLds { uint32_t chip[64 * WM_RLA_WPB * WM_RLA_CROW]; };     /* lane-private staging; the block's waves are independent */
 
-/* PASS: 0 = first pass of a batch of whole waves (uniform), 1 = re-run list only, 2 = re-run list or a densely packed first pass
- * of any batch: like the clock kernel, each kind of launch has its own kernel (the uniform first pass: 62 VGPRs). */
+/* PASS: 0 = first pass only (a.list == nullptr), 1 = re-run list only, 2 = either (the fused launch): like the clock kernel,
+ * each kind of launch has its own kernel (the main pass then carries no list walk: 78 instead of 97 VGPRs). */
 template <int PASS = 2>
 __device__ __forceinline__ void rla_lanes(const K2Args &a, const uint32_t block_id, RlaLds &lds)
 {
     uint32_t *s_chip = lds.chip;
+    uint32_t lane = block_id * (64 * WM_RLA_WPB) + threadIdx.x;
+    if (lane >= k2_lane_count(a)) return;
     const bool rerun = PASS == 2 ? a.list != nullptr : PASS == 1;
+    if (rerun) lane = a.list[lane];
     const WmPush &g = a.g;
     uint32_t ch, stream, seg;
-    if (PASS == 0) {
-        /* FIRST PASS of a batch of whole waves: a wave is one (chain, segment) and 64 consecutive captures (see clock_lanes):
-         * segment bounds and the step counter are the same in all 64 lanes and live in scalar registers */
-        const uint32_t w = WM_UNI(block_id * (uint32_t)WM_RLA_WPB + (threadIdx.x >> 6)), ngrp = g.S / 64u;
-        const uint32_t r = w / ngrp;
-        seg = r % g.nseg[0]; ch = r / g.nseg[0]; stream = (w % ngrp) * 64u + (threadIdx.x & 63u);
-        if (ch >= 2u) return;
-    } else {
-        uint32_t lane = block_id * (64 * WM_RLA_WPB) + threadIdx.x;
-        if (lane >= k2_lane_count(a)) return;
-        if (rerun) lane = a.list[lane];
-        lane_decode(g, 0, lane, ch, stream, seg);
-    }
+    lane_decode(g, 0, lane, ch, stream, seg);
     if (!(g.flags & (ch ? WM_F_S1 : WM_F_T1C1))) return;
 
     const uint64_t row = (uint64_t)ch * g.S + stream;
@@ -94,10 +85,8 @@ __device__ __forceinline__ void rla_lanes(const K2Args &a, const uint32_t block_
     if (rerun) { s = seg ? stF[sidx - 1] : stC[row]; m = mb; }
     else if (mb <= g.lookback) { s = stC[row]; m = 0; }
     else { s = reset; m = (mb - g.lookback) & ~63u; }     /* whole 64-sample steps (segments are multiples of 1024) */
-    if (PASS == 0) m = WM_UNI(m);
 
-    const uint32_t *bw = a.bits + wm_bits_index(g, ch, stream, 0u);     /* word w of this capture at bw[w * GW] (wm_dev.h) */
-    const uint64_t bstep = g.GW;
+    const uint32_t *bw = a.bits + row * (g.Mcap / 32);
     uint32_t *out = a.chips + sidx * cap_rl;
     const bool s1 = ch != 0;
     const uint32_t syncw = s1 ? WM_SYNC_S1 : WM_SYNC_T1C1, syncm = s1 ? WM_SYNC_S1_MASK : WM_SYNC_T1C1_MASK;
@@ -143,23 +132,24 @@ __device__ __forceinline__ void rla_lanes(const K2Args &a, const uint32_t block_
         n_fl += 8u; pend = pend > 8u ? pend - 8u : 0u;
     };
 
-    /* slicer words: two per 64-sample step, straight from the wave-transposed array (the wave's 64 lanes are the 64 captures
-     * of a group at one time: each load is one 256-byte piece); the next step's pair is in flight while this one is used.
-     * (Round 3 read capture-major rows eight words at a time -- a sector per lane -- and kept 16 registers of them.) */
-    const uint32_t n_words = g.Mcap / 32u;                   /* rows hold whole words up to Mcap */
-    auto load_pair = [&](uint32_t mm, uint32_t &lo, uint32_t &hi) {
-        const uint32_t w = mm >> 5;
-        lo = w < n_words ? bw[(uint64_t)w * bstep] : 0u;
-        hi = w + 1u < n_words ? bw[(uint64_t)(w + 1u) * bstep] : 0u;
+    /* slicer words arrive 8 at a time (one aligned 32-byte sector per lane and 256 samples; single
+     * words cost a sector of HBM traffic each); the next group is in flight while this one is used */
+    uint32_t grp = m >> 8;                                   /* group (256 samples) the lane is in */
+    uint4 wq0 = *(const uint4 *)(bw + 8u * grp), wq1 = *(const uint4 *)(bw + 8u * grp + 4), nq0 = {}, nq1 = {};
+    auto fetch_group = [&](uint32_t gq) {                    /* rows hold whole groups (Mcap is a multiple of 256) */
+        if (gq * 256u < g.Mcap) { nq0 = *(const uint4 *)(bw + 8u * gq); nq1 = *(const uint4 *)(bw + 8u * gq + 4); }
     };
-    uint32_t w_lo, w_hi, nx_lo, nx_hi;
-    load_pair(m, w_lo, w_hi);
-    load_pair(m + 64u, nx_lo, nx_hi);
+    fetch_group(grp + 1u);
     /* One step = 64 samples (two slicer words).  The wave walks its 64 lanes' edges in lock step, so a
      * step costs the wave the LARGEST edge count among its lanes; over 64 samples that maximum is
      * relatively smaller than over 32 (T1/C1 on the bench workload, measured on the host emulation with 64
      * captures as the lanes: 8.4 edges per 64 samples on average, 18.9 for the unluckiest of 64 lanes). */
     auto block = [&](const bool emit) {
+        const uint32_t sub = (m >> 6) & 3u;                  /* word pair within the group of 8 */
+        const uint32_t lo4[4] = {wq0.x, wq0.z, wq1.x, wq1.z}, hi4[4] = {wq0.y, wq0.w, wq1.y, wq1.w};
+        uint32_t w_lo = lo4[0], w_hi = hi4[0];
+#pragma unroll
+        for (int i = 1; i < 4; i++) { w_lo = sub == (uint32_t)i ? lo4[i] : w_lo; w_hi = sub == (uint32_t)i ? hi4[i] : w_hi; }
         const uint32_t kend = min(64u, me - m);
         const uint64_t valid = kend == 64u ? ~0ull : ((1ull << kend) - 1ull);
         uint64_t R = (((uint64_t)w_hi << 32) | w_lo) & valid;    /* raw slicer bits, bit j = sample j of the step */
@@ -229,8 +219,7 @@ __device__ __forceinline__ void rla_lanes(const K2Args &a, const uint32_t block_
         }
         /* the five newest raw bits, time order (a ragged last step may be shorter than five samples) */
         s.raw = (kend >= 5u ? (uint32_t)(R >> (kend - 5u)) : (((uint32_t)R << (5u - kend)) | (hist >> kend))) & 0x1Fu & hist_mask;
-        w_lo = nx_lo; w_hi = nx_hi;
-        load_pair(m + 128u, nx_lo, nx_hi);
+        if (sub == 3u) { wq0 = nq0; wq1 = nq1; grp++; fetch_group(grp + 1u); }
         if (emit && pend >= 8u) flush8();
         m += 64;
     };
@@ -260,7 +249,7 @@ __global__ __launch_bounds__(64 * WM_RLA_WPB, WM_RLA_WAVES_PER_SIMD) void k2_rla
     wm_framer_prio();
     __shared__ RlaLds lds;
     const uint32_t n = k2_lane_count(a);
-    for (uint32_t b = blockIdx.x; (uint64_t)b * (64u * WM_RLA_WPB) < n; b += gridDim.x) rla_lanes<2>(a, b, lds);
+    for (uint32_t b = blockIdx.x; (uint64_t)b * (64u * WM_RLA_WPB) < n; b += gridDim.x) rla_lanes<1>(a, b, lds);
 }
 
 #endif /* WM_K2_RLA_H */

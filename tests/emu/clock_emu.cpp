@@ -1,7 +1,9 @@
 /* clock_emu.cpp -- TEST INFRASTRUCTURE: the clock-recovery / time2 framer lanes (device source
  * rtl-wmbus_amd/csrc/wm_k2_clock.h) compiled for the host and executed lane by lane, with the
  * speculative-start / verify / re-run rounds of wm_api.hip around them, checkpoints and early exit
- * included. */
+ * included.  Only the lane-private load path is emulated (what the kernel takes for batches that are
+ * not a multiple of 64 captures, and for every re-run); the cooperative path differs in how a block
+ * of soft symbols reaches LDS, not in what is computed from it. */
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
@@ -43,27 +45,19 @@ extern "C" {
 int wm_emu_descending = 1;
 int wm_emu_s1_span = 0;                   /* WmPush.s1_span of the next calls */
 uint32_t *wm_emu_seen_out = nullptr;      /* optional: receives the per-region "access-code chip seen" flags */
+int wm_emu_lean_reruns = 0;
 
-/* One push of M decimated samples for S captures.  dphi: [2][S][Mcap] soft symbols (capture-major, as the tests hold
- * them: re-arranged here into the kernels' wave-transposed layout, wm_dev.h); carry: [2][S] WmClkState in/out; bits:
- * [2][S][Mcap/32] out (capture-major again); chips: [2][S][nseg][cap]; counts: [2][S][nseg].
+/* One push of M decimated samples for S captures.  dphi: [2][S][Mcap] soft symbols; carry: [2][S]
+ * WmClkState in/out; bits: [2][S][Mcap/32] out; chips: [2][S][nseg][cap]; counts: [2][S][nseg].
  * Returns the number of re-run lanes over all rounds, -1 if verification did not converge. */
-long wm_emu_clock(const float *dphi_rows, uint32_t S, uint32_t M, uint32_t Mcap, uint32_t flags, uint32_t seg_len, uint32_t warm0,
-                  uint32_t warm1, uint32_t cap, void *carry, uint32_t *bits_rows, uint32_t *chips, uint32_t *counts, uint32_t *err_out,
+long wm_emu_clock(const float *dphi, uint32_t S, uint32_t M, uint32_t Mcap, uint32_t flags, uint32_t seg_len, uint32_t warm0,
+                  uint32_t warm1, uint32_t cap, void *carry, uint32_t *bits, uint32_t *chips, uint32_t *counts, uint32_t *err_out,
                   uint32_t *rounds_out)
 {
     WmPush g{};
     g.M = M; g.Mcap = Mcap; g.S = S; g.flags = flags; g.d = 2;
     g.seg_len[1] = seg_len; g.nseg[1] = (M + seg_len - 1) / seg_len; g.nseg_cap[1] = g.nseg[1]; g.cap[1] = cap;
     g.warm[0] = warm0; g.warm[1] = warm1; g.s1_span = (uint32_t)wm_emu_s1_span;
-    wm_group_geometry(S, &g.GW, &g.NG);
-    std::vector<float> dphi_t((size_t)2 * S * Mcap, 0.0f);
-    std::vector<uint32_t> bits_t((size_t)2 * g.NG * g.GW * (Mcap / 32), 0u);
-    for (uint32_t ch = 0; ch < 2; ch++)
-        for (uint32_t st = 0; st < S; st++)
-            for (uint32_t t = 0; t < Mcap; t++) dphi_t[wm_dphi_index(g, ch, st, t)] = dphi_rows[((size_t)ch * S + st) * Mcap + t];
-    const float *dphi = dphi_t.data();
-    uint32_t *bits = bits_t.data();
     const uint32_t rows = 2 * S, nseg = g.nseg[1], lanes = rows * nseg;
     const uint32_t nck = seg_len / WM_CK_SAMPLES ? seg_len / WM_CK_SAMPLES - 1 : 0;
     std::vector<WmClkState> st_start((size_t)rows * nseg), st_final((size_t)rows * nseg);
@@ -82,18 +76,20 @@ long wm_emu_clock(const float *dphi_rows, uint32_t S, uint32_t M, uint32_t Mcap,
          * makes cascading rounds.  Lanes in descending order reproduce that; ascending order is the
          * other extreme (every lane already sees its predecessor's new state). */
         if (lst == nullptr && S % 64u == 0u) {
-            /* first pass of a batch of whole waves: the UNIFORM kernel (PASS = 0), one wave per (chain, segment, group of 64
-             * captures); the wave's lanes meet in the chip loops' ballots, so they run together, one coroutine each */
-            const uint32_t waves = 2u * nseg * (S / 64u);
-            for (uint32_t b = 0; b < waves; b++)
-                block_emu::run_block(64, [&] { if (dc) clock_lanes<true, 1, 0>(a, b, lds); else clock_lanes<false, 1, 0>(a, b, lds); });
+            /* first pass of a batch of whole waves: the kernel loads COOPERATIVELY (8 lanes fetch one row's
+             * line, the block is transposed through LDS between wave barriers) -- the 64 lanes of a wave
+             * really have to run together: one coroutine each on the block emulator */
+            for (uint32_t b = 0; b < n / 64; b++)
+                block_emu::run_block(64, [&] { if (dc) clock_lanes<true, 1>(a, b, lds); else clock_lanes<false, 1>(a, b, lds); });
             return;
         }
-        /* any other first pass, and every re-run list: the list kernel's densely packed lanes (PASS = 2), one at a time */
         for (uint32_t i = 0; i < n; i++) {
             const uint32_t l = wm_emu_descending ? n - 1 - i : i;
             threadIdx.x = l & 63u;
-            if (dc) clock_lanes<true, 1>(a, l >> 6, lds); else clock_lanes<false, 1>(a, l >> 6, lds);
+            /* re-run launches may use the lean per-sample block (candidate for the fused launch) */
+            const bool lean = wm_emu_lean_reruns && lst != nullptr;
+            if (dc) { if (lean) clock_lanes<true, 1, true>(a, l >> 6, lds); else clock_lanes<true, 1>(a, l >> 6, lds); }
+            else { if (lean) clock_lanes<false, 1, true>(a, l >> 6, lds); else clock_lanes<false, 1>(a, l >> 6, lds); }
         }
     };
     launch(nullptr, lanes);
@@ -113,9 +109,6 @@ long wm_emu_clock(const float *dphi_rows, uint32_t S, uint32_t M, uint32_t Mcap,
         reruns += (long)list.size();
         launch(list.data(), (uint32_t)list.size());
     }
-    for (uint32_t ch = 0; ch < 2; ch++)
-        for (uint32_t st = 0; st < S; st++)
-            for (uint32_t w = 0; w < Mcap / 32; w++) bits_rows[((size_t)ch * S + st) * (Mcap / 32) + w] = bits_t[wm_bits_index(g, ch, st, w)];
     WmClkState *c = (WmClkState *)carry;                                 /* k_carry */
     for (uint32_t r = 0; r < rows; r++) c[r] = st_final[(size_t)r * nseg + nseg - 1];
     if (wm_emu_seen_out) std::memcpy(wm_emu_seen_out, seen.data(), seen.size() * sizeof(uint32_t));

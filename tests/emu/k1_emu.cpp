@@ -71,17 +71,13 @@ extern "C" {
 /* One push.  in: S rows of in_stride bytes (4096 history bytes first); dphi: [2][S][Mcap]; rssi:
  * [2][S][Mcap]; ema_carry: [2][S] in/out.  Returns the number of repaired tiles, -1 on no convergence. */
 long wm_emu_k1(const uint8_t *in, uint64_t in_stride, uint32_t S, uint32_t d, uint32_t flags, uint64_t n0, uint32_t n_new,
-               uint32_t Mcap, float *dphi_rows, uint8_t *rssi, float *ema_carry, uint32_t *err_out, int polyphase)
+               uint32_t Mcap, float *dphi, uint8_t *rssi, float *ema_carry, uint32_t *err_out, int polyphase)
 {
     WmPush g{};
     g.in = in; g.in_stride = in_stride; g.n0 = n0; g.m0 = n0 / d; g.n_new = n_new;
     g.M = (uint32_t)((n0 + n_new) / d - g.m0); g.Mcap = Mcap; g.d = d; g.S = S; g.lut_n = 32 * d;
     g.lut_phase0 = (uint32_t)((13ull * (n0 % g.lut_n)) % g.lut_n); g.flags = flags;
     if (g.M == 0) return 0;
-    /* the kernel writes soft symbols wave-transposed (wm_dev.h); the tests get them capture-major */
-    wm_group_geometry(S, &g.GW, &g.NG);
-    std::vector<float> dphi_t((size_t)2 * S * Mcap, 0.0f);
-    float *dphi = dphi_t.data();
     const uint32_t T = WM_K1_TILE2, ntiles = (g.M + T - 1) / T, rows = 2 * S;
     std::vector<float> lut(2 * 32 * WM_MAX_DECIM, 0.f), head((size_t)ntiles * rows), tail((size_t)ntiles * rows);
     {   /* wm_api.hip wmbus_open: rtl_wmbus.c:974-993 */
@@ -93,7 +89,7 @@ long wm_emu_k1(const uint8_t *in, uint64_t in_stride, uint32_t S, uint32_t d, ui
     }
     std::vector<uint32_t> first_bad(rows, 0xFFFFFFFFu), relist((size_t)rows * ntiles + 1);
     uint32_t err = 0, n_relist = 0;
-    K1Args a{g, dphi, rssi, lut.data(), lut.data() + 32 * WM_MAX_DECIM, head.data(), tail.data(), ntiles, &err, nullptr, ema_carry, nullptr};
+    K1Args a{g, dphi, rssi, lut.data(), lut.data() + 32 * WM_MAX_DECIM, head.data(), tail.data(), ntiles, &err, nullptr, ema_carry};
     const bool sh = flags & WM_F_SHIFT;
     auto launch = [&](uint32_t n_list) {
         a.relist = n_list ? relist.data() : nullptr;
@@ -127,9 +123,6 @@ long wm_emu_k1(const uint8_t *in, uint64_t in_stride, uint32_t S, uint32_t d, ui
         launch(n_relist);
     }
     for (uint32_t r = 0; r < rows; r++) { blockIdx = {r / 64, 0, 0}; threadIdx = {r % 64, 0, 0}; k1_commit(tail.data(), ema_carry, ntiles, rows); }
-    for (uint32_t ch = 0; ch < 2; ch++)
-        for (uint32_t st = 0; st < S; st++)
-            for (uint32_t t = 0; t < g.M; t++) dphi_rows[((size_t)ch * S + st) * Mcap + t] = dphi_t[wm_dphi_index(g, ch, st, t)];
     if (err_out) *err_out = err;
     return repaired;
 }

@@ -49,7 +49,7 @@ uint32_t *wm_emu_seen_out = nullptr;      /* optional: receives the per-region "
  * [2][S] WmRlaState in/out (zero-initialised = the reset state is NOT implied: pass what
  * wmbus_open would, see rla_reset_state).  chips: [2][S][nseg][cap], counts: [2][S][nseg].
  * Returns the number of re-run lanes (all rounds), or -1 if verification did not converge. */
-long wm_emu_rla(const uint32_t *bits_rows, uint32_t S, uint32_t M, uint32_t Mcap, uint32_t flags, uint32_t seg_len,
+long wm_emu_rla(const uint32_t *bits, uint32_t S, uint32_t M, uint32_t Mcap, uint32_t flags, uint32_t seg_len,
                 uint32_t lookback, uint32_t cap, void *carry, uint32_t *chips, uint32_t *counts, uint32_t *err_out)
 {
     WmPush g{};
@@ -57,13 +57,6 @@ long wm_emu_rla(const uint32_t *bits_rows, uint32_t S, uint32_t M, uint32_t Mcap
     g.seg_len[0] = seg_len; g.nseg[0] = (M + seg_len - 1) / seg_len; g.nseg_cap[0] = g.nseg[0]; g.cap[0] = cap;
     g.lookback = lookback;
     g.sp = emu_spill;
-    /* the tests hold slicer words capture-major; the kernel reads the wave-transposed array (wm_dev.h) */
-    wm_group_geometry(S, &g.GW, &g.NG);
-    std::vector<uint32_t> bits_t((size_t)2 * g.NG * g.GW * (Mcap / 32), 0u);
-    for (uint32_t ch = 0; ch < 2; ch++)
-        for (uint32_t st = 0; st < S; st++)
-            for (uint32_t w = 0; w < Mcap / 32; w++) bits_t[wm_bits_index(g, ch, st, w)] = bits_rows[((size_t)ch * S + st) * (Mcap / 32) + w];
-    const uint32_t *bits = bits_t.data();
     const uint32_t rows = 2 * S, nseg = g.nseg[0], lanes = rows * nseg;
     std::vector<WmRlaState> st_start((size_t)rows * nseg), st_final((size_t)rows * nseg);
     std::vector<uint32_t> seen((size_t)rows * nseg, 0), list;
@@ -78,11 +71,10 @@ long wm_emu_rla(const uint32_t *bits_rows, uint32_t S, uint32_t M, uint32_t Mcap
         a.list = lst; a.n_lanes = n;
         /* descending lane order: a re-run lane reads its predecessor's end state before that predecessor's
          * own re-run of the same launch replaces it, as it mostly happens on the GPU (cascading rounds) */
-        const bool whole = lst == nullptr && S % 64u == 0u;             /* the uniform first-pass kernel (PASS = 0): one wave per (chain, segment, 64 captures) */
         for (uint32_t i = 0; i < n; i++) {
             const uint32_t l = wm_emu_descending ? n - 1 - i : i;
             threadIdx.x = l % B;
-            if (whole) rla_lanes<0>(a, l / B, lds); else rla_lanes<2>(a, l / B, lds);
+            rla_lanes(a, l / B, lds);
         }
     };
     launch(nullptr, lanes);

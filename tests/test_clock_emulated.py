@@ -31,9 +31,10 @@ def emu():
     return L
 
 
-def run_emulated(emu, soft_rows, pushes, seg_len, warm, dc=False, descending=True, s1_span=None):
+def run_emulated(emu, soft_rows, pushes, seg_len, warm, dc=False, descending=True, lean_reruns=False, s1_span=None):
     """soft_rows: [2][M] float32 FIR outputs of one capture; pushes: decimated samples per push."""
     ctypes.c_int.in_dll(emu, "wm_emu_descending").value = int(descending)   # see clock_emu.cpp: launch semantics
+    ctypes.c_int.in_dll(emu, "wm_emu_lean_reruns").value = int(lean_reruns)  # per-sample block in re-run launches (WM_FUSED_LEAN_CLOCK)
     ctypes.c_int.in_dll(emu, "wm_emu_s1_span").value = int(s1_span or 0)     # WmPush.s1_span: S1 lanes cover two segments
     sb = emu.wm_emu_clock_state_bytes()
     carry = np.zeros(2 * sb, np.uint8)                     # a fresh context starts from the all-zero state
@@ -104,7 +105,7 @@ def test_device_source_on_host_matches_oracle_randomised(emu, oracle, wm):
         if os.environ.get("WMBUS_EMU_STRESS"):               # bug hunts: many checkpoints per segment, hopeless warm-ups
             seg_len = int(rng.choice([4096, 8192, 16384]))
             warm = (int(rng.choice([32, 64, 256])), int(rng.choice([32, 64, 256])))
-        chips, bits, reruns, rounds = run_emulated(emu, ref["dphi_fir"], pushes, seg_len, warm, dc=dc, descending=bool(k % 5),
+        chips, bits, reruns, rounds = run_emulated(emu, ref["dphi_fir"], pushes, seg_len, warm, dc=dc, descending=bool(k % 5), lean_reruns=bool(k % 2),
                                                    s1_span=1 + (k // 2) % 2)
         multi += rounds > 1
         for ch in (0, 1):
@@ -114,10 +115,9 @@ def test_device_source_on_host_matches_oracle_randomised(emu, oracle, wm):
 
 
 def test_cooperative_first_pass_of_a_whole_wave_on_the_block_emulator(emu, oracle, wm):
-    """64 captures = one wave per (chain, segment): the first pass takes the UNIFORM variant of the lane code
-    (clock_lanes<.., PASS = 0>: segment bounds and block counter in scalar registers, soft-symbol registers refilled
-    in place).  The 64 lanes run as coroutines on the block emulator (they meet in the chip loops' ballots); re-runs
-    take the list variant."""
+    """64 captures = one wave per (chain, segment): the first pass fetches the rows cooperatively (8 lanes per
+    row, one 128-byte line each) and transposes the block through LDS between wave barriers.  The 64 lanes run
+    as coroutines on the block emulator; re-runs take the lane-private path."""
     S, seg_len, warm = 64, 8192, (1024, 2048)
     refs = []
     for s in range(S):

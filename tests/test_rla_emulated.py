@@ -151,36 +151,6 @@ def interferer_capture(wm):
     return cu8
 
 
-def test_first_pass_of_a_whole_wave_takes_the_uniform_kernel(emu, oracle, wm):
-    """64 captures = one wave per (chain, segment) in the first pass: the UNIFORM variant of the lane code (rla_lanes<0>:
-    segment bounds and the step counter in scalar registers), slicer words read from the wave-transposed array; re-runs go
-    through the list variant.  Every capture's chips against the oracle."""
-    S, seg_len, lookback = 64, 2048, 64
-    refs = [oracle.run(wm.synth_capture(seed=8100 + s, n_samples=1 << 15, kinds=15, frames_per_s=400.0, amplitude=60.0)[0],
-                       flags_to_oracle_opts(oracle, ["-v"]), taps=True, chips=True) for s in range(S)]
-    M = refs[0]["m"]; Mcap = (M + 255) // 256 * 256
-    words = np.zeros((2, S, Mcap // 32), np.uint32)
-    for s in range(S):
-        for ch in range(2):
-            b = np.zeros(Mcap, np.uint8); b[:M] = refs[s]["bit"][ch]
-            words[ch, s] = np.packbits(b.reshape(-1, 32), axis=1, bitorder="little").view(np.uint32).ravel()
-    nseg, cap = (M + seg_len - 1) // seg_len, 8 * seg_len + 8 + 8192
-    chips = np.zeros((2, S, nseg, cap), np.uint32); counts = np.zeros((2, S, nseg), np.uint32)
-    sb = emu.wm_emu_rla_state_bytes()
-    carry = np.zeros(2 * S * sb, np.uint8)
-    for r in range(2 * S):
-        emu.wm_emu_rla_reset_state(carry[r * sb:].ctypes.data)
-    emu.wm_emu_rla_set_spill(None, 0, None, None, None)
-    err = ctypes.c_uint(0)
-    r = emu.wm_emu_rla(words.ctypes.data, S, M, Mcap, F_T1C1 | F_S1, seg_len, lookback, cap, carry.ctypes.data, chips.ctypes.data, counts.ctypes.data, ctypes.byref(err))
-    assert r > 0 and err.value == 0                           # a short look-back: the re-run path ran too
-    for s in range(S):
-        for ch in range(2):
-            got = np.concatenate([np.stack([g * seg_len + (chips[ch, s, g, :counts[ch, s, g]] >> 3), chips[ch, s, g, :counts[ch, s, g]] & 7], axis=1)
-                                  for g in range(nseg)])
-            assert np.array_equal(got, truncate_runs(oracle_rla_chips(refs[s], ch))), (s, ch)
-
-
 def test_chip_flood_continues_in_the_spill_arena(emu, oracle, wm):
     """The reference's chip loop never gives up (rtl_wmbus.c:765-779); a segment that outgrows its primary region (the
     product's half a chip per sample) continues in chunks of the spill arena, re-runs reuse the segment's chain, and the
