@@ -72,6 +72,8 @@ def parse():
     ap.add_argument("--no-tolerance-leg", action="store_true", help="skip the informational tolerance-mode leg behind the main measurement")
     ap.add_argument("--seed-offset", type=int, default=0, help="other synthetic captures than the headline batch (capture s gets seed 0xC0FFEE + offset + s); evidence runs only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rla", action="store_true", help="evidence runs only (with --quick): -r 0, the run-length framer off")
+    ap.add_argument("--no-time2", action="store_true", help="evidence runs only (with --quick): -t 0, the time2 framer off (clock recovery still runs)")
     ap.add_argument("--no-legs", action="store_true", help="skip the informational legs behind the main measurement (configs[1] / configs[2], the CLI's own rate)")
     ap.add_argument("--quick", action="store_true", help="A/B runs: --no-check --no-cpu-baseline --no-legs --no-tolerance-leg")
     ap.add_argument("--no-check", action="store_true")
@@ -337,7 +339,8 @@ def main():
     host_threads = a.host_threads or shard.host_threads_per_context(world, nctx_guess)
     batch = wm.Batch(n_streams=S, contexts=nctx_req, max_push_bytes=push_bytes, device=local, seg_len=a.seg_len, rla_seg_len=a.rla_seg_len,
                      warmup_s1=a.warmup_s1, warmup_t1c1=a.warmup_t1c1, rla_lookback=a.rla_lookback, show_algorithm=True, fixed_timestamp=True,
-                     host_threads=host_threads, input_windows=2 if a.from_host else 1, tolerance_mode=int(a.tolerance_mode))
+                     host_threads=host_threads, input_windows=2 if a.from_host else 1, tolerance_mode=int(a.tolerance_mode),
+                     rla=not a.no_rla, time2=not a.no_time2)
     nctx = len(batch.contexts)
     per_ctx = [cnt for _, _, cnt in batch.contexts]
     for s in range(S):

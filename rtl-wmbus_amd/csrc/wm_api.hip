@@ -114,6 +114,7 @@ struct wmbus_ctx {
     hipStream_t side_stream = nullptr;                 /* run-length framer beside the clock kernel's re-run rounds (see enqueue_front_impl); nullptr: one stream */
     hipEvent_t ev[11] = {};                            /* [9], [10]: side-stream interval (timing) */
     hipEvent_t ev_staged = nullptr;                    /* recorded on copy_stream at process(): the push's input is in HBM */
+    hipEvent_t ev_turn = nullptr;                       /* behind the main part of this context's K1: the next context's K1 waits for it */
     hipEvent_t ev_ready = nullptr, ev_fork = nullptr, ev_join = nullptr;   /* cross-stream order only (no timing): input ready for K1; fork / join of the side stream */
     uint32_t n_win = 1, fill = 0;                      /* input windows (cfg.input_windows) and the one wmbus_stage fills now */
     /* geometry */
@@ -143,7 +144,9 @@ struct wmbus_ctx {
     size_t zero_words = 0;
     uint32_t *d_sync_seen[2] = {};                      /* per framer: [2][S][nseg_cap] access-code chip seen in region */
     uint32_t *d_spill = nullptr, *d_chain = nullptr, *d_nchain = nullptr; uint32_t spill_words = 0;   /* WmSpill (wm_dev.h) */
-    unsigned ema_rounds = 1, fr_rounds = 2;             /* hand-off rounds enqueued unattended, see WM_MAX_ROUNDS */
+    unsigned ema_rounds = 1, fr_rounds = 2, rla_rounds = 3;   /* hand-off rounds enqueued unattended, see WM_MAX_ROUNDS; the run-length framer's
+                                                          counters start at index 1 (its list rounds: 1 .. rla_rounds - 1) */
+    unsigned rla_fin = 3;                               /* this push: index of the run-length framer's last (unattended) verification */
     bool poisoned = false, gpu_decode = true;                              /* an internal error left the carried state undefined */
     uint32_t *d_first_bad = nullptr;                    /* [2][S] first uncertified EMA tile of a row, or ~0 */
     uint32_t *d_ckpt = nullptr; uint32_t nck = 0;       /* clock kernel checkpoints [2][S][nseg_cap][nck][16] */
@@ -204,7 +207,7 @@ enum { WM_MAX_ROUNDS = 6 };                     /* counters per kind: rounds + 1
  * that every hand-off failure is finished by the host-driven path */
 static const bool opt_rounds = !(getenv("WMBUS_OPT_ROUNDS") && atoi(getenv("WMBUS_OPT_ROUNDS")) == 0);
 enum { SC_ERR = 0, SC_NHITS = 1, SC_NHDR = 2, SC_NWORDS = 3, SC_NPKTS = 4, SC_NBYTES = 5, SC_SLOW = 6, SC_CHIPS = 8 /* [algo][chain] */,
-       SC_EMA = 16 /* [ema_rounds + 1] */, SC_CLK = 24 /* [fr_rounds + 1] */, SC_RLA = 32 /* [fr_rounds + 1] */, SC_COUNT = 40 };
+       SC_EMA = 16 /* [ema_rounds + 1] */, SC_CLK = 24 /* [fr_rounds + 1] */, SC_RLA = 32 /* [rla_rounds + 1] */, SC_COUNT = 40 };
 
 /* 4096 bytes per capture from src + row * sstride + soff to dst + row * dstride (256 threads x 16 bytes).  The input
  * history: the last 4096 staged bytes of a push are put aside (d_hist) when the push is enqueued and placed in front of
@@ -373,7 +376,7 @@ void wmbus_close(wmbus_ctx *c)
     void *host[] = {c->h_scalars, c->h_hdr, c->h_words, c->h_pending, c->h_pkts, c->h_bytes};
     for (void *p : host) if (p) hipHostFree(p);
     for (auto &e : c->ev) if (e) hipEventDestroy(e);
-    for (hipEvent_t e : {c->ev_staged, c->ev_ready, c->ev_fork, c->ev_join}) if (e) hipEventDestroy(e);
+    for (hipEvent_t e : {c->ev_staged, c->ev_ready, c->ev_fork, c->ev_join, c->ev_turn}) if (e) hipEventDestroy(e);
     if (c->side_stream) { hipStreamSynchronize(c->side_stream); hipStreamDestroy(c->side_stream); }
     if (c->copy_stream && c->copy_stream != c->stream) { hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); }
     if (c->stream) hipStreamDestroy(c->stream);
@@ -426,6 +429,10 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
                (cfg->time2_enabled ? WM_F_T2A : 0);
     if (c->S < 64u) { c->ema_rounds = 2; c->fr_rounds = 5; }
     if (const char *r_ = getenv("WMBUS_FR_ROUNDS")) c->fr_rounds = std::min<unsigned>(std::max(1, atoi(r_)), WM_MAX_ROUNDS);      /* tuning aid */
+    /* the run-length framer gets as many list rounds as the clock kernel (round 3: one fewer -- enough for 1.6 MS/s captures,
+     * "2300 re-runs, then 0", but configs[2] (-d 5 -s) leaves 750 lanes after the first round and fell to the host-driven
+     * path on EVERY push: 64 ms per step instead of 25) */
+    c->rla_rounds = std::min<unsigned>(c->fr_rounds + 1u, WM_MAX_ROUNDS + 1u);
     c->T = (uint32_t)WM_K1_TILE2;
     const uint32_t T = c->T;
     const uint64_t max_samples = cfg->max_push_bytes / 2;
@@ -455,6 +462,7 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
     for (auto &ev : c->ev) A(hipEventCreate(&ev));
     A(hipEventCreateWithFlags(&c->ev_staged, hipEventDisableTiming));
     A(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
+    A(hipEventCreateWithFlags(&c->ev_turn, hipEventDisableTiming));
     A(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     A(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     {
@@ -778,7 +786,7 @@ static int enqueue_front_impl(wmbus_ctx *c, size_t nbytes)
         const uint32_t T = c->T, ntiles = (g.M + T - 1) / T;
         c->ntiles = ntiles;
         c->k1a = K1Args{g, c->d_dphi, c->d_rssi, c->d_lut, c->d_lut + 32 * WM_MAX_DECIM, c->d_ema_head, c->d_ema_tail, ntiles, c->d_scalars + SC_ERR,
-                        nullptr, ema_carry(c, false), nullptr};
+                        nullptr, ema_carry(c, false), nullptr, 0u};
         static const int turns = getenv("WMBUS_K1_TURNS") ? atoi(getenv("WMBUS_K1_TURNS")) : 1;      /* 0: no order (A/B) */
         static const int k1_shared = getenv("WMBUS_K1_STREAM") ? atoi(getenv("WMBUS_K1_STREAM")) : 0;   /* 1: one shared stream carries every context's K1 (r04 A/B: -13 %) */
         int rc;
@@ -799,10 +807,27 @@ static int enqueue_front_impl(wmbus_ctx *c, size_t nbytes)
             } else {
                 if (turns && kc.last && kc.owner != c) HIPCHK(c, hipStreamWaitEvent(c->stream, kc.last, 0));
                 HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-                rc = launch_k1_any(c, c->k1a, dim3(ntiles, c->S));
+                /* The hand-over of the turn costs 0.15-0.2 ms (the next context's stream sits in an event wait on another
+                 * hardware queue; r03 trace: median 128 us between one K1 and the next, eight times per step = 5 % of it).
+                 * So the turn is handed over EARLY: a push's tiles leave in two launches, the event the next context waits for
+                 * lies behind the first, and the last WMBUS_K1_TAIL per mille of the tiles run while the hand-over is under
+                 * way -- beside the head of the next context's K1 at most. */
+                static const int tail_env = getenv("WMBUS_K1_TAIL") ? atoi(getenv("WMBUS_K1_TAIL")) : -1;
+                /* r04 A/B: exact 152.5 / 153.2 against 149.1 / 150.1 Gsamples/s with 60 per mille (30: 151.6 / 152.0, 120: 151.0 / 152.3, 250:
+                 * 148.9 / 147.4); tolerance mode, whose K1 is a third of the length, 170.1 / 171.9 against 171.0 / 173.0: off there */
+                const uint32_t tail_pm = tail_env >= 0 ? (uint32_t)tail_env : c->cfg.tolerance_mode ? 0u : 60u;
+                const uint32_t n_tail = turns ? std::min(ntiles - 1u, (uint32_t)((uint64_t)ntiles * tail_pm / 1000u)) : 0u;
+                K1Args k1 = c->k1a;
+                rc = launch_k1_any(c, k1, dim3(ntiles - n_tail, c->S));
                 if (rc) return rc;
+                if (n_tail) {
+                    HIPCHK(c, hipEventRecord(c->ev_turn, c->stream));
+                    k1.tile0 = ntiles - n_tail;
+                    rc = launch_k1_any(c, k1, dim3(n_tail, c->S));
+                    if (rc) return rc;
+                }
                 HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
-                if (turns) { kc.last = c->ev[4]; kc.owner = c; }
+                if (turns) { kc.last = n_tail ? c->ev_turn : c->ev[4]; kc.owner = c; }
             }
         }
         /* Everything behind K1 is enqueued while it runs -- no step of a push waits for the host any more:
@@ -856,7 +881,7 @@ static int enqueue_front_impl(wmbus_ctx *c, size_t nbytes)
             HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
             HIPCHK(c, hipEventRecord(c->ev[9], c->side_stream));
             fr_launch(c, WMBUS_ALGO_RLA, 0xFFFFFFFFu, c->side_stream);
-            for (unsigned r = 1; r < c->fr_rounds && opt_rounds; r++) { fr_verify(c, WMBUS_ALGO_RLA, SC_RLA + r, c->side_stream); fr_launch(c, WMBUS_ALGO_RLA, SC_RLA + r, c->side_stream); }
+            for (unsigned r = 1; r < c->rla_rounds && opt_rounds; r++) { fr_verify(c, WMBUS_ALGO_RLA, SC_RLA + r, c->side_stream); fr_launch(c, WMBUS_ALGO_RLA, SC_RLA + r, c->side_stream); }
             HIPCHK(c, hipEventRecord(c->ev[10], c->side_stream));
             HIPCHK(c, hipEventRecord(c->ev_join, c->side_stream));
             for (unsigned r = 0; r < c->fr_rounds && opt_rounds; r++) { fr_verify(c, WMBUS_ALGO_T2A, SC_CLK + r); fr_launch(c, WMBUS_ALGO_T2A, SC_CLK + r); }
@@ -868,11 +893,12 @@ static int enqueue_front_impl(wmbus_ctx *c, size_t nbytes)
             HIPCHK(c, hipEventRecord(c->ev[8], c->stream));
             if (rla) {
                 fr_launch(c, WMBUS_ALGO_RLA, 0xFFFFFFFFu);
-                for (unsigned r = 1; r < c->fr_rounds && opt_rounds; r++) { fr_verify(c, WMBUS_ALGO_RLA, SC_RLA + r); fr_launch(c, WMBUS_ALGO_RLA, SC_RLA + r); }
+                for (unsigned r = 1; r < c->rla_rounds && opt_rounds; r++) { fr_verify(c, WMBUS_ALGO_RLA, SC_RLA + r); fr_launch(c, WMBUS_ALGO_RLA, SC_RLA + r); }
             } else HIPCHK(c, hipMemsetAsync(c->d_counts[0], 0, (size_t)2 * c->S * c->nseg_cap[0] * sizeof(uint32_t), c->stream));
         }
+        c->rla_fin = c->fused ? c->fr_rounds : c->rla_rounds;
         fr_verify(c, WMBUS_ALGO_T2A, SC_CLK + c->fr_rounds);
-        if (rla) fr_verify(c, WMBUS_ALGO_RLA, SC_RLA + c->fr_rounds);
+        if (rla) fr_verify(c, WMBUS_ALGO_RLA, SC_RLA + c->rla_fin);
         HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
         fr_carry(c);
         c->committed = true;
@@ -960,7 +986,7 @@ static int finish_slowly(wmbus_ctx *c, bool ema_left, bool clk_left, bool rla_le
     }
     for (int algo = 1; algo >= 0; algo--) {                    /* clock first: with -o the slicer words depend on it */
         if (!(algo ? clk_left : rla_left)) continue;
-        uint32_t cnt = (algo ? SC_CLK : SC_RLA) + c->fr_rounds, n = 0;
+        uint32_t cnt = algo ? SC_CLK + c->fr_rounds : SC_RLA + c->rla_fin, n = 0;
         for (uint32_t round = 0;; round++) {
             (algo ? c->tim.clock_reruns : c->tim.rla_reruns) += c->h_scalars[cnt];
             fr_launch(c, algo, cnt);
@@ -975,11 +1001,11 @@ static int finish_slowly(wmbus_ctx *c, bool ema_left, bool clk_left, bool rla_le
         if (algo == 1 && (c->flags & WM_F_DC) && (c->flags & WM_F_RLA)) {
             /* the run-length framer ran on slicer words that the clock re-runs have just replaced: all of it again */
             fr_launch(c, WMBUS_ALGO_RLA, 0xFFFFFFFFu);
-            hipLaunchKernelGGL(k_copy_word, dim3(1), dim3(1), 0, c->stream, c->d_scalars + SC_RLA + c->fr_rounds, 0u);
-            fr_verify(c, WMBUS_ALGO_RLA, SC_RLA + c->fr_rounds);
+            hipLaunchKernelGGL(k_copy_word, dim3(1), dim3(1), 0, c->stream, c->d_scalars + SC_RLA + c->rla_fin, 0u);
+            fr_verify(c, WMBUS_ALGO_RLA, SC_RLA + c->rla_fin);
             HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, SC_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
-            rla_left = c->h_scalars[SC_RLA + c->fr_rounds] != 0;
+            rla_left = c->h_scalars[SC_RLA + c->rla_fin] != 0;
         }
     }
     fr_carry(c);
@@ -1116,8 +1142,9 @@ static int wait_gpu(wmbus_ctx *c)
         hipEventElapsedTime(&ms, c->ev[2], c->ev[7]); c->tim.gpu_total_ms = ms;
         const uint32_t *hs = c->h_scalars;
         for (unsigned r = 0; r < c->ema_rounds; r++) c->tim.ema_retries += hs[SC_EMA + r];
-        for (unsigned r = 0; r < c->fr_rounds; r++) { c->tim.clock_reruns += hs[SC_CLK + r]; c->tim.rla_reruns += hs[SC_RLA + r]; }
-        const bool ema_left = hs[SC_EMA + c->ema_rounds], clk_left = hs[SC_CLK + c->fr_rounds], rla_left = hs[SC_RLA + c->fr_rounds];
+        for (unsigned r = 0; r < c->fr_rounds; r++) c->tim.clock_reruns += hs[SC_CLK + r];
+        for (unsigned r = 0; r < c->rla_fin; r++) c->tim.rla_reruns += hs[SC_RLA + r];
+        const bool ema_left = hs[SC_EMA + c->ema_rounds], clk_left = hs[SC_CLK + c->fr_rounds], rla_left = hs[SC_RLA + c->rla_fin];
         static const bool dbg_rounds = getenv("WMBUS_DEBUG_ROUNDS") != nullptr;
         if (dbg_rounds)
             fprintf(stderr, "rounds: ema %u %u | clock %u %u %u %u | rla %u %u %u %u\n", hs[SC_EMA], hs[SC_EMA + 1], hs[SC_CLK], hs[SC_CLK + 1], hs[SC_CLK + 2],

@@ -41,6 +41,7 @@ struct K1Args {
     const uint32_t *relist;
     const float *ema_carry;  /* [2][S] exact EMA carried in from the previous push */
     const uint32_t *n_relist;/* repair launches: entries in `relist` (on the device: k1_collect has just written it) */
+    uint32_t tile0;          /* first pass: the launch's first tile (a push's tiles may leave in two launches, see enqueue_front_impl) */
 };
 
 /* =============================================================================================
@@ -413,7 +414,7 @@ __global__ __launch_bounds__(256, GEN ? 1 : 8) void k1_demod2(K1Args a)         
      * launches, per-thread addresses kept across tiles -- and the whole job 10 % slower: the framer kernels of the other
      * contexts get onto a CU when demodulation blocks retire, and blocks that live twice as long halve their chances; r03
      * A/B in DESIGN.md section 10.) */
-    if (!GEN || a.relist == nullptr) { k1_tile<D, SHIFT, GEN, FAST>(a, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x); return; }
+    if (!GEN || a.relist == nullptr) { k1_tile<D, SHIFT, GEN, FAST>(a, (int)(blockIdx.x + a.tile0), (int)blockIdx.y, (int)threadIdx.x); return; }
     /* repair launch: a fixed grid walks the list k1_collect has just written (no host round trip in between) */
     const uint32_t n = *a.n_relist;
     for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
@@ -531,7 +532,7 @@ __device__ __forceinline__ void k1_tile_ppf(const K1Args &a, const int tile, con
 
 __global__ __launch_bounds__(256) void k1_demod_ppf(K1Args a)
 {
-    if (a.relist == nullptr) { k1_tile_ppf(a, (int)blockIdx.x, (int)blockIdx.y); return; }
+    if (a.relist == nullptr) { k1_tile_ppf(a, (int)(blockIdx.x + a.tile0), (int)blockIdx.y); return; }
     const uint32_t n = *a.n_relist;
     for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
         k1_tile_ppf(a, (int)(a.relist[e] % a.ntiles), (int)(a.relist[e] / a.ntiles));

@@ -89,7 +89,7 @@ long wm_emu_k1(const uint8_t *in, uint64_t in_stride, uint32_t S, uint32_t d, ui
     }
     std::vector<uint32_t> first_bad(rows, 0xFFFFFFFFu), relist((size_t)rows * ntiles + 1);
     uint32_t err = 0, n_relist = 0;
-    K1Args a{g, dphi, rssi, lut.data(), lut.data() + 32 * WM_MAX_DECIM, head.data(), tail.data(), ntiles, &err, nullptr, ema_carry};
+    K1Args a{g, dphi, rssi, lut.data(), lut.data() + 32 * WM_MAX_DECIM, head.data(), tail.data(), ntiles, &err, nullptr, ema_carry, nullptr, 0u};
     const bool sh = flags & WM_F_SHIFT;
     auto launch = [&](uint32_t n_list) {
         a.relist = n_list ? relist.data() : nullptr;
