@@ -150,6 +150,7 @@ struct wmbus_ctx {
     bool poisoned = false, gpu_decode = true;                              /* an internal error left the carried state undefined */
     uint32_t *d_first_bad = nullptr;                    /* [2][S] first uncertified EMA tile of a row, or ~0 */
     uint32_t *d_ckpt = nullptr; uint32_t nck = 0;       /* clock kernel checkpoints [2][S][nseg_cap][nck][16] */
+    uint32_t *d_bad = nullptr;                          /* [2][S][nseg_cap[0]] the run-length verifier's verdict per segment (K2Args.bad) */
     uint2 *d_hits = nullptr; uint32_t hits_cap = 0;
     uint32_t *d_pending = nullptr;
     uint32_t hdr_cap = 0, words_cap = 0, pkts_cap = 0, bytes_cap = 0;
@@ -368,7 +369,7 @@ void wmbus_close(wmbus_ctx *c)
         std::lock_guard<std::mutex> lk(kc.m);
         if (kc.owner == c) { kc.last = nullptr; kc.owner = nullptr; }      /* nobody may wait on an event that is about to go */
     }
-    void *dev[] = {c->d_hist, c->d_list_ema, c->d_spill, c->d_chain, c->d_list2, c->d_first_bad, c->d_ckpt, c->d_in, c->d_dphi, c->d_rssi, c->d_bits, c->d_lut, c->d_ema_head, c->d_ema_tail, c->d_ema_carry,
+    void *dev[] = {c->d_bad, c->d_hist, c->d_list_ema, c->d_spill, c->d_chain, c->d_list2, c->d_first_bad, c->d_ckpt, c->d_in, c->d_dphi, c->d_rssi, c->d_bits, c->d_lut, c->d_ema_head, c->d_ema_tail, c->d_ema_carry,
                    c->d_chips[0], c->d_chips[1], c->d_counts[0], c->d_counts[1], c->d_st_start[0], c->d_st_start[1],
                    c->d_st_final[0], c->d_st_final[1], c->d_st_carry[0], c->d_st_carry[1], c->d_list, c->d_scalars,
                    c->d_hits, c->d_pending};
@@ -504,6 +505,10 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
     A(dalloc(&c->d_list_ema, (size_t)rows));
     c->nck = c->C[1] / WM_CK_SAMPLES ? c->C[1] / WM_CK_SAMPLES - 1 : 0;
     A(dalloc(&c->d_ckpt, std::max<size_t>(16, (size_t)rows * c->nseg_cap[1] * c->nck * 16)));
+    {
+        static const bool chains = !(getenv("WMBUS_RLA_CHAINS") && atoi(getenv("WMBUS_RLA_CHAINS")) == 0);      /* 0: every listed segment on its own (r03; A/B) */
+        if (chains) { A(dalloc(&c->d_bad, (size_t)rows * c->nseg_cap[0])); if (e == hipSuccess) A(hipMemset(c->d_bad, 0, (size_t)rows * c->nseg_cap[0] * sizeof(uint32_t))); }
+    }
     {
         const size_t n_seen0 = (size_t)rows * c->nseg_cap[0], n_seen1 = (size_t)rows * c->nseg_cap[1], n_chain = (size_t)rows * c->nseg_cap[0] + 1;
         c->zero_words = SC_COUNT + n_seen0 + n_seen1 + n_chain;
@@ -657,7 +662,8 @@ static void fr_verify(wmbus_ctx *c, int algo, uint32_t cnt, hipStream_t st = nul
     const K2Args &a = algo == WMBUS_ALGO_RLA ? c->k2rla : c->k2clk;
     const uint32_t lanes = 2u * a.g.nseg[algo] * a.g.S, words = (algo == WMBUS_ALGO_RLA ? sizeof(WmRlaState) : sizeof(WmClkState)) / 4;
     hipLaunchKernelGGL(k2_verify, dim3((lanes + 255) / 256), dim3(256), 0, st, a.g, (uint32_t)algo, (const uint32_t *)a.st_start,
-                       (const uint32_t *)a.st_final, words, algo == WMBUS_ALGO_RLA ? c->d_list2 : c->d_list, c->d_scalars + cnt);
+                       (const uint32_t *)a.st_final, words, algo == WMBUS_ALGO_RLA ? c->d_list2 : c->d_list, c->d_scalars + cnt,
+                       algo == WMBUS_ALGO_RLA ? c->d_bad : (uint32_t *)nullptr);
 }
 
 /* one framer's kernel alone: every lane (cnt == ~0) or the re-run list whose length is scalar `cnt` */
@@ -851,7 +857,7 @@ static int enqueue_front_impl(wmbus_ctx *c, size_t nbytes)
         ka.algo = WMBUS_ALGO_T2A;
         ka.chips = c->d_chips[1]; ka.counts = c->d_counts[1]; ka.sync_seen = c->d_sync_seen[1];
         ka.st_start = c->d_st_start[1]; ka.st_final = c->d_st_final[1]; ka.st_carry = st_carry(c, 1, false);
-        kr.algo = WMBUS_ALGO_RLA;
+        kr.algo = WMBUS_ALGO_RLA; kr.bad = c->d_bad;
         kr.chips = c->d_chips[0]; kr.counts = c->d_counts[0]; kr.sync_seen = c->d_sync_seen[0];
         kr.st_start = c->d_st_start[0]; kr.st_final = c->d_st_final[0]; kr.st_carry = st_carry(c, 0, false);
         /* fused framer launches (clock re-run lanes + run-length framer in one launch) were worth 4 ms of a context's

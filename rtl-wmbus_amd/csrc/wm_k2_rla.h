@@ -60,19 +60,14 @@ struct RlaLds { uint32_t chip[64 * WM_RLA_WPB * WM_RLA_CROW]; };     /* lane-pri
 
 /* PASS: 0 = first pass only (a.list == nullptr), 1 = re-run list only, 2 = either (the fused launch): like the clock kernel,
  * each kind of launch has its own kernel (the main pass then carries no list walk: 78 instead of 97 VGPRs). */
-template <int PASS = 2>
-__device__ __forceinline__ void rla_lanes(const K2Args &a, const uint32_t block_id, RlaLds &lds)
+/* One segment of one (chain, capture); `from`: the exact state a re-run starts from when the caller has it at hand (nullptr: the
+ * predecessor's record / the carried state).  Leaves the segment's end state in `fin` (and in st_final). */
+template <int PASS>
+__device__ __forceinline__ void rla_segment(const K2Args &a, RlaLds &lds, const bool rerun, const uint32_t ch, const uint32_t stream, const uint32_t seg,
+                                            const WmRlaState *from, WmRlaState &fin)
 {
     uint32_t *s_chip = lds.chip;
-    uint32_t lane = block_id * (64 * WM_RLA_WPB) + threadIdx.x;
-    if (lane >= k2_lane_count(a)) return;
-    const bool rerun = PASS == 2 ? a.list != nullptr : PASS == 1;
-    if (rerun) lane = a.list[lane];
     const WmPush &g = a.g;
-    uint32_t ch, stream, seg;
-    lane_decode(g, 0, lane, ch, stream, seg);
-    if (!(g.flags & (ch ? WM_F_S1 : WM_F_T1C1))) return;
-
     const uint64_t row = (uint64_t)ch * g.S + stream;
     const uint64_t sidx = row * g.nseg_cap[0] + seg;
     const uint32_t mb = seg * g.seg_len[0], me = min(g.M, mb + g.seg_len[0]);
@@ -82,7 +77,7 @@ __device__ __forceinline__ void rla_lanes(const K2Args &a, const uint32_t block_
 
     WmRlaState s;
     uint32_t m;
-    if (rerun) { s = seg ? stF[sidx - 1] : stC[row]; m = mb; }
+    if (rerun) { s = from ? *from : seg ? stF[sidx - 1] : stC[row]; m = mb; }
     else if (mb <= g.lookback) { s = stC[row]; m = 0; }
     else { s = reset; m = (mb - g.lookback) & ~63u; }     /* whole 64-sample steps (segments are multiples of 1024) */
 
@@ -232,6 +227,49 @@ __device__ __forceinline__ void rla_lanes(const K2Args &a, const uint32_t block_
     a.counts[sidx] = n_stored < n_out ? n_stored : n_out;        /* chips that can be read back */
     if (saw_sync) a.sync_seen[sidx] = 1u;
     if (n_stored < n_out) atomicOr(a.err, WM_ERR_CHIP_TRUNC);     /* a warning: the framer state is exact, some chips of this segment are lost */
+    fin = s;
+}
+
+/* The lanes of one launch.  First pass: lane = (chain, segment, capture), every lane one segment.
+ * Re-run list (round 4): a listed lane walks its CHAIN.  A segment is listed because its start did not match its predecessor's
+ * end (k2_verify also leaves that verdict per segment in `a.bad`); a re-run starts from the predecessor's end state -- which is
+ * stale when the predecessor is re-run in the same launch.  A burst longer than a segment (an S1 telegram is 30-100 ms, a
+ * segment 10 ms; configs[2] puts those into the T1/C1 chain's band as well) makes a run of consecutive listed segments, and
+ * round 3 needed one round per segment of the run: verify, list, launch each time, and beyond the rounds enqueued the
+ * host-driven path -- on EVERY push of configs[2] (64 ms per step).  Now the FIRST listed segment of a run does them all, one
+ * after the other, each from the exact end state of the one before (the others return at once), and goes on into the segment
+ * behind the run as long as the end state it arrives with differs from that segment's recorded start -- unless that segment
+ * has a lane of its own in this launch (listed behind an unlisted one), which the next round sorts out. */
+template <int PASS = 2>
+__device__ __forceinline__ void rla_lanes(const K2Args &a, const uint32_t block_id, RlaLds &lds)
+{
+    uint32_t lane = block_id * (64 * WM_RLA_WPB) + threadIdx.x;
+    if (lane >= k2_lane_count(a)) return;
+    const bool rerun = PASS == 2 ? a.list != nullptr : PASS == 1;
+    if (rerun) lane = a.list[lane];
+    const WmPush &g = a.g;
+    uint32_t ch, stream, seg;
+    lane_decode(g, 0, lane, ch, stream, seg);
+    if (!(g.flags & (ch ? WM_F_S1 : WM_F_T1C1))) return;
+    WmRlaState fin;
+    if (!rerun || a.bad == nullptr) { rla_segment<PASS>(a, lds, rerun, ch, stream, seg, nullptr, fin); return; }
+    const uint64_t row = (uint64_t)ch * g.S + stream;
+    const uint32_t *bad = a.bad + row * g.nseg_cap[0];
+    const WmRlaState *stS = (const WmRlaState *)a.st_start;
+    if (seg > 0u && bad[seg - 1u]) return;                 /* the head of my run covers me */
+    const WmRlaState *from = nullptr;
+    for (;;) {
+        rla_segment<PASS>(a, lds, true, ch, stream, seg, from, fin);
+        if (seg + 1u >= g.nseg[0]) return;
+        const uint32_t *x = (const uint32_t *)&fin, *y = (const uint32_t *)&stS[row * g.nseg_cap[0] + seg + 1u];
+        bool same = true;
+#pragma unroll
+        for (int k = 0; k < (int)(sizeof(WmRlaState) / 4); k++) same &= x[k] == y[k];
+        if (same) return;                                  /* the next segment started from exactly this state */
+        if (bad[seg + 1u] && !bad[seg]) return;            /* it is listed and has a lane of its own in this launch: next round */
+        seg++;
+        from = &fin;
+    }
 }
 
 #ifndef WM_RLA_WAVES_PER_SIMD

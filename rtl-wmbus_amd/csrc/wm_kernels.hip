@@ -68,7 +68,7 @@ __global__ __launch_bounds__(64 * WM_RLA_WPB, WM_FUSED_WAVES_PER_SIMD) void k2_c
 
 /* start[seg] must equal final[seg-1]; mismatching lanes are appended to `list`. */
 __global__ void k2_verify(WmPush g, uint32_t algo, const uint32_t *st_start, const uint32_t *st_final, uint32_t words,
-                          uint32_t *list, uint32_t *n_list)
+                          uint32_t *list, uint32_t *n_list, uint32_t *bad)
 {
     wm_framer_prio();
     const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
@@ -80,6 +80,7 @@ __global__ void k2_verify(WmPush g, uint32_t algo, const uint32_t *st_start, con
     const uint32_t *p = st_start + sidx * words, *q = st_final + (sidx - 1) * words;
     bool same = true;
     for (uint32_t k = 0; k < words; k++) same &= p[k] == q[k];
+    if (bad) bad[sidx] = same ? 0u : 1u;                  /* the verdict per segment (segments 0 and disabled chains stay 0) */
     if (!same) list[atomicAdd(n_list, 1u)] = lane;
 }
 

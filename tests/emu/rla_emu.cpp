@@ -34,6 +34,8 @@ using std::min;
 extern "C" {
 
 int wm_emu_descending = 1;
+int wm_emu_last_rounds = 0;               /* list rounds the last call needed */
+int wm_emu_chains = 1;                    /* K2Args.bad: a listed lane walks its chain of listed segments (round 4); 0: every listed segment on its own */
 /* optional spill storage (WmSpill, wm_dev.h) for the next wm_emu_rla call: arena, chain [2][S][nseg][WM_SPILL_LEVELS],
  * nchain [2][S][nseg] followed by the bump counter; all zero = none */
 static WmSpill emu_spill = {};
@@ -59,12 +61,13 @@ long wm_emu_rla(const uint32_t *bits, uint32_t S, uint32_t M, uint32_t Mcap, uin
     g.sp = emu_spill;
     const uint32_t rows = 2 * S, nseg = g.nseg[0], lanes = rows * nseg;
     std::vector<WmRlaState> st_start((size_t)rows * nseg), st_final((size_t)rows * nseg);
-    std::vector<uint32_t> seen((size_t)rows * nseg, 0), list;
+    std::vector<uint32_t> seen((size_t)rows * nseg, 0), bad((size_t)rows * nseg, 0), list;
     uint32_t err = 0;
     K2Args a{};
     a.g = g; a.bits = const_cast<uint32_t *>(bits); a.chips = chips; a.counts = counts;
     a.st_start = st_start.data(); a.st_final = st_final.data(); a.st_carry = carry;
     a.algo = 0; a.err = &err; a.sync_seen = seen.data();
+    a.bad = wm_emu_chains ? bad.data() : nullptr;
     static RlaLds lds;
     const uint32_t B = 64 * WM_RLA_WPB;
     auto launch = [&](const uint32_t *lst, uint32_t n) {
@@ -86,8 +89,11 @@ long wm_emu_rla(const uint32_t *bits, uint32_t S, uint32_t M, uint32_t Mcap, uin
             lane_decode(g, 0, lane, ch, stream, seg);
             if (!(g.flags & (ch ? WM_F_S1 : WM_F_T1C1)) || seg == 0) continue;
             const size_t sidx = ((size_t)ch * S + stream) * nseg + seg;
-            if (std::memcmp(&st_start[sidx], &st_final[sidx - 1], sizeof(WmRlaState))) list.push_back(lane);
+            const bool differs = std::memcmp(&st_start[sidx], &st_final[sidx - 1], sizeof(WmRlaState)) != 0;
+            bad[sidx] = differs;                                         /* the verdict per segment, stable during the launch that follows */
+            if (differs) list.push_back(lane);
         }
+        wm_emu_last_rounds = (int)round;
         if (list.empty()) break;
         if (round > nseg + 1) return -1;
         reruns += (long)list.size();

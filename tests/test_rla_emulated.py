@@ -33,9 +33,10 @@ def emu():
     return L
 
 
-def run_emulated(emu, bit_rows, pushes, seg_len, lookback, flags=F_T1C1 | F_S1, descending=True, cap=None, spill_words=None):
+def run_emulated(emu, bit_rows, pushes, seg_len, lookback, flags=F_T1C1 | F_S1, descending=True, cap=None, spill_words=None, chains=True):
     """bit_rows: [2][M] uint8 slicer bits of one capture; pushes: decimated samples per push."""
     ctypes.c_int.in_dll(emu, "wm_emu_descending").value = int(descending)   # see rla_emu.cpp: launch semantics
+    ctypes.c_int.in_dll(emu, "wm_emu_chains").value = int(chains)           # a listed lane walks its chain of listed segments (K2Args.bad)
     sb = emu.wm_emu_rla_state_bytes()
     carry = np.zeros(2 * sb, np.uint8)
     for r in range(2):
@@ -149,6 +150,22 @@ def interferer_capture(wm):
     cu8[a:a + 2 * n_sq:2] = 128 + 60 * np.cos(2 * np.pi * 0.03 * t * (2 * ph - 1))
     cu8[a + 1:a + 2 * n_sq:2] = 128 + 60 * np.sin(2 * np.pi * 0.03 * t * (2 * ph - 1))
     return cu8
+
+
+def test_a_burst_longer_than_a_segment_is_settled_by_one_chain_walk(emu, oracle, wm):
+    """S1 telegrams are 30-100 ms long, a run-length segment 10 ms (and the tests' short segments 1.3 ms): every segment inside
+    a burst starts wrongly from the reset state.  Lone re-runs (round 3) need one round per segment of the burst; the chain
+    walk (round 4: the first listed segment of a run does them all, from exact state to exact state) one.  Both are exact."""
+    cu8 = wm.synth_capture(seed=4242, n_samples=1 << 18, kinds=8, frames_per_s=40.0, amplitude=60.0, l_min=60, l_max=120)[0]
+    ref = oracle.run(cu8, flags_to_oracle_opts(oracle, ["-v"]), taps=True, chips=True)
+    rounds = {}
+    for chains in (False, True):
+        got, reruns = run_emulated(emu, ref["bit"], [ref["m"]], 1024, 64, chains=chains)
+        rounds[chains] = ctypes.c_int.in_dll(emu, "wm_emu_last_rounds").value
+        assert reruns > 0
+        for ch in (0, 1):
+            assert np.array_equal(got[ch], truncate_runs(oracle_rla_chips(ref, ch))), (chains, ch)
+    assert rounds[False] >= 4 and rounds[True] <= 2, rounds
 
 
 def test_chip_flood_continues_in_the_spill_arena(emu, oracle, wm):
