@@ -150,7 +150,8 @@ struct wmbus_ctx {
     bool poisoned = false, gpu_decode = true;                              /* an internal error left the carried state undefined */
     uint32_t *d_first_bad = nullptr;                    /* [2][S] first uncertified EMA tile of a row, or ~0 */
     uint32_t *d_ckpt = nullptr; uint32_t nck = 0;       /* clock kernel checkpoints [2][S][nseg_cap][nck][16] */
-    uint32_t *d_bad = nullptr;                          /* [2][S][nseg_cap[0]] the run-length verifier's verdict per segment (K2Args.bad) */
+    uint32_t *d_bad = nullptr;                          /* [2][nseg_cap[0]][S] the run-length verifier's verdict per segment (K2Args.bad) */
+    bool rla_chains = false;                            /* the chain walk is in use (switched on by the first push whose unattended rounds did not suffice) */
     uint2 *d_hits = nullptr; uint32_t hits_cap = 0;
     uint32_t *d_pending = nullptr;
     uint32_t hdr_cap = 0, words_cap = 0, pkts_cap = 0, bytes_cap = 0;
@@ -506,10 +507,6 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
     c->nck = c->C[1] / WM_CK_SAMPLES ? c->C[1] / WM_CK_SAMPLES - 1 : 0;
     A(dalloc(&c->d_ckpt, std::max<size_t>(16, (size_t)rows * c->nseg_cap[1] * c->nck * 16)));
     {
-        static const bool chains = !(getenv("WMBUS_RLA_CHAINS") && atoi(getenv("WMBUS_RLA_CHAINS")) == 0);      /* 0: every listed segment on its own (r03; A/B) */
-        if (chains) { A(dalloc(&c->d_bad, (size_t)rows * c->nseg_cap[0])); if (e == hipSuccess) A(hipMemset(c->d_bad, 0, (size_t)rows * c->nseg_cap[0] * sizeof(uint32_t))); }
-    }
-    {
         const size_t n_seen0 = (size_t)rows * c->nseg_cap[0], n_seen1 = (size_t)rows * c->nseg_cap[1], n_chain = (size_t)rows * c->nseg_cap[0] + 1;
         c->zero_words = SC_COUNT + n_seen0 + n_seen1 + n_chain;
         A(dalloc(&c->d_scalars, c->zero_words));
@@ -532,6 +529,17 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
     }
     A(dalloc(&c->d_hits, (size_t)c->hits_cap));
     A(dalloc(&c->d_pending, (size_t)4 * c->S));
+    {
+        /* WMBUS_RLA_CHAINS: 0 = every listed segment on its own (r03), 1 = the chain walk switched on by need, 2 (default) = from
+         * the first push (r04 A/B, bench workload: 148.3 / 150.2 | 149.3 / 149.5 | 147.3 / 149.7 Gsamples/s for 1 | 0 | 2: no difference).  (Zeroed on the context's own stream: a synchronous hipMemset runs on the NULL stream, whose hardware
+         * queue then takes part in the round-robin of streams onto queues -- eight contexts lost 5 % to that in this round's A/Bs.) */
+        static const int chains = getenv("WMBUS_RLA_CHAINS") ? atoi(getenv("WMBUS_RLA_CHAINS")) : 2;
+        if (chains) {
+            A(dalloc(&c->d_bad, (size_t)rows * c->nseg_cap[0]));
+            if (e == hipSuccess) A(hipMemsetAsync(c->d_bad, 0, (size_t)rows * c->nseg_cap[0] * sizeof(uint32_t), c->stream));
+            c->rla_chains = chains == 2;
+        }
+    }
     A(hipHostMalloc((void **)&c->h_scalars, SC_COUNT * sizeof(uint32_t)));
     A(hipHostMalloc((void **)&c->h_hdr, (size_t)c->hdr_cap * sizeof(WmBurstHdr)));
     A(hipHostMalloc((void **)&c->h_words, (size_t)c->words_cap * sizeof(uint32_t)));
@@ -663,7 +671,7 @@ static void fr_verify(wmbus_ctx *c, int algo, uint32_t cnt, hipStream_t st = nul
     const uint32_t lanes = 2u * a.g.nseg[algo] * a.g.S, words = (algo == WMBUS_ALGO_RLA ? sizeof(WmRlaState) : sizeof(WmClkState)) / 4;
     hipLaunchKernelGGL(k2_verify, dim3((lanes + 255) / 256), dim3(256), 0, st, a.g, (uint32_t)algo, (const uint32_t *)a.st_start,
                        (const uint32_t *)a.st_final, words, algo == WMBUS_ALGO_RLA ? c->d_list2 : c->d_list, c->d_scalars + cnt,
-                       algo == WMBUS_ALGO_RLA ? c->d_bad : (uint32_t *)nullptr);
+                       algo == WMBUS_ALGO_RLA && c->rla_chains ? c->d_bad : (uint32_t *)nullptr);
 }
 
 /* one framer's kernel alone: every lane (cnt == ~0) or the re-run list whose length is scalar `cnt` */
@@ -675,6 +683,12 @@ static void fr_launch(wmbus_ctx *c, int algo, uint32_t cnt, hipStream_t st = nul
     const bool all = cnt == 0xFFFFFFFFu;
     a.list = all ? nullptr : (algo == WMBUS_ALGO_RLA ? c->d_list2 : c->d_list);
     a.n_lanes = lanes; a.n_ptr = all ? nullptr : c->d_scalars + cnt;
+    /* The run-length framer's FIRST list round re-runs every listed segment on its own, in parallel, from its predecessor's
+     * end state as recorded: a neighbour that is listed too usually comes out of its re-run with the end state it had (the
+     * framer resets inside the segment), so that state was right all along -- walking such runs serially made the round twice
+     * as long on the bench workload (r04 A/B: 133 against 147 Gsamples/s).  What is STILL listed after that round is a true
+     * cascade (a burst longer than a segment): from the second list round on a listed lane walks its chain (rla_lanes). */
+    if (algo == WMBUS_ALGO_RLA && !all && cnt == SC_RLA + 1u) a.bad = nullptr;
     /* list launches: blocks for 3/16 of the lanes (a re-run list is a few percent of them; the blocks walk whatever is more) */
     const uint32_t B = 64 * (algo == WMBUS_ALGO_RLA ? WM_RLA_WPB : WM_CLK_WPB), grid = all ? (lanes + B - 1) / B : std::max(16u, (lanes / B) * 3u / 16u);
     if (algo == WMBUS_ALGO_RLA) {
@@ -857,7 +871,7 @@ static int enqueue_front_impl(wmbus_ctx *c, size_t nbytes)
         ka.algo = WMBUS_ALGO_T2A;
         ka.chips = c->d_chips[1]; ka.counts = c->d_counts[1]; ka.sync_seen = c->d_sync_seen[1];
         ka.st_start = c->d_st_start[1]; ka.st_final = c->d_st_final[1]; ka.st_carry = st_carry(c, 1, false);
-        kr.algo = WMBUS_ALGO_RLA; kr.bad = c->d_bad;
+        kr.algo = WMBUS_ALGO_RLA; kr.bad = c->rla_chains ? c->d_bad : nullptr;
         kr.chips = c->d_chips[0]; kr.counts = c->d_counts[0]; kr.sync_seen = c->d_sync_seen[0];
         kr.st_start = c->d_st_start[0]; kr.st_final = c->d_st_final[0]; kr.st_carry = st_carry(c, 0, false);
         /* fused framer launches (clock re-run lanes + run-length framer in one launch) were worth 4 ms of a context's
@@ -1155,6 +1169,12 @@ static int wait_gpu(wmbus_ctx *c)
         if (dbg_rounds)
             fprintf(stderr, "rounds: ema %u %u | clock %u %u %u %u | rla %u %u %u %u\n", hs[SC_EMA], hs[SC_EMA + 1], hs[SC_CLK], hs[SC_CLK + 1], hs[SC_CLK + 2],
                     hs[SC_CLK + 3], hs[SC_RLA], hs[SC_RLA + 1], hs[SC_RLA + 2], hs[SC_RLA + 3]);   /* entries beyond the rounds compiled in stay 0 */
+        /* The chain walk of the run-length re-run lanes (rla_lanes) is switched on by need: a stream whose bursts outlast a
+         * segment (configs[2]: every push) leaves lanes listed behind the unattended rounds ONCE, and from its next push on the
+         * second list round walks chains and settles them on the device.  A stream that never does (the bench workload) never
+         * pays for the verdict flags -- measured with them always on: 142 against 150 Gsamples/s, although the kernels' own
+         * durations did not move (r04, visits q / p). */
+        if (rla_left && c->d_bad) c->rla_chains = true;
         if (ema_left || clk_left || rla_left) {
             const int rc = finish_slowly(c, ema_left, clk_left, rla_left);
             if (rc) { c->poisoned = true; return rc; }

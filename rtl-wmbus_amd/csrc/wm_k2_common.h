@@ -27,7 +27,7 @@ struct K2Args {
      * far (16 words each).  A re-run stops at the first checkpoint it reproduces: from there on the
      * speculative pass had already been on the exact trajectory. */
     uint32_t *ckpt; uint32_t nck;
-    /* [2][S][nseg_cap]: k2_verify's verdict per segment (1: its start did not match its predecessor's end), for the chain
+    /* [2][nseg_cap][S]: k2_verify's verdict per segment (1: its start did not match its predecessor's end), for the chain
      * walk of the run-length kernel's re-run lanes (rla_lanes); nullptr: every listed segment on its own, as in round 3 */
     const uint32_t *bad;
 };

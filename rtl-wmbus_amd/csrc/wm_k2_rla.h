@@ -60,11 +60,10 @@ struct RlaLds { uint32_t chip[64 * WM_RLA_WPB * WM_RLA_CROW]; };     /* lane-pri
 
 /* PASS: 0 = first pass only (a.list == nullptr), 1 = re-run list only, 2 = either (the fused launch): like the clock kernel,
  * each kind of launch has its own kernel (the main pass then carries no list walk: 78 instead of 97 VGPRs). */
-/* One segment of one (chain, capture); `from`: the exact state a re-run starts from when the caller has it at hand (nullptr: the
- * predecessor's record / the carried state).  Leaves the segment's end state in `fin` (and in st_final). */
+/* One segment of one (chain, capture).  A re-run starts from the predecessor's recorded end state (the carried state for
+ * segment 0) and leaves its own in st_final. */
 template <int PASS>
-__device__ __forceinline__ void rla_segment(const K2Args &a, RlaLds &lds, const bool rerun, const uint32_t ch, const uint32_t stream, const uint32_t seg,
-                                            const WmRlaState *from, WmRlaState &fin)
+__device__ __forceinline__ void rla_segment(const K2Args &a, RlaLds &lds, const bool rerun, const uint32_t ch, const uint32_t stream, const uint32_t seg)
 {
     uint32_t *s_chip = lds.chip;
     const WmPush &g = a.g;
@@ -77,7 +76,7 @@ __device__ __forceinline__ void rla_segment(const K2Args &a, RlaLds &lds, const 
 
     WmRlaState s;
     uint32_t m;
-    if (rerun) { s = from ? *from : seg ? stF[sidx - 1] : stC[row]; m = mb; }
+    if (rerun) { s = seg ? stF[sidx - 1] : stC[row]; m = mb; }
     else if (mb <= g.lookback) { s = stC[row]; m = 0; }
     else { s = reset; m = (mb - g.lookback) & ~63u; }     /* whole 64-sample steps (segments are multiples of 1024) */
 
@@ -227,7 +226,6 @@ __device__ __forceinline__ void rla_segment(const K2Args &a, RlaLds &lds, const 
     a.counts[sidx] = n_stored < n_out ? n_stored : n_out;        /* chips that can be read back */
     if (saw_sync) a.sync_seen[sidx] = 1u;
     if (n_stored < n_out) atomicOr(a.err, WM_ERR_CHIP_TRUNC);     /* a warning: the framer state is exact, some chips of this segment are lost */
-    fin = s;
 }
 
 /* The lanes of one launch.  First pass: lane = (chain, segment, capture), every lane one segment.
@@ -251,24 +249,23 @@ __device__ __forceinline__ void rla_lanes(const K2Args &a, const uint32_t block_
     uint32_t ch, stream, seg;
     lane_decode(g, 0, lane, ch, stream, seg);
     if (!(g.flags & (ch ? WM_F_S1 : WM_F_T1C1))) return;
-    WmRlaState fin;
-    if (!rerun || a.bad == nullptr) { rla_segment<PASS>(a, lds, rerun, ch, stream, seg, nullptr, fin); return; }
+    if (!rerun || a.bad == nullptr) { rla_segment<PASS>(a, lds, rerun, ch, stream, seg); return; }
+    /* nothing but (chain, capture, segment) lives across a segment: the end state a walk goes on from is the record the
+     * segment has just written (kept in registers across the segment's loops it cost 13 VGPRs and spills: 2 ms per stage) */
     const uint64_t row = (uint64_t)ch * g.S + stream;
-    const uint32_t *bad = a.bad + row * g.nseg_cap[0];
-    const WmRlaState *stS = (const WmRlaState *)a.st_start;
-    if (seg > 0u && bad[seg - 1u]) return;                 /* the head of my run covers me */
-    const WmRlaState *from = nullptr;
+    const uint32_t *bad = a.bad + (uint64_t)ch * g.nseg_cap[0] * g.S + stream;       /* verdict of segment j at bad[j * S] */
+    if (seg > 0u && bad[(uint64_t)(seg - 1u) * g.S]) return;            /* the head of my run covers me */
     for (;;) {
-        rla_segment<PASS>(a, lds, true, ch, stream, seg, from, fin);
+        rla_segment<PASS>(a, lds, true, ch, stream, seg);
         if (seg + 1u >= g.nseg[0]) return;
-        const uint32_t *x = (const uint32_t *)&fin, *y = (const uint32_t *)&stS[row * g.nseg_cap[0] + seg + 1u];
+        const uint64_t sidx = row * g.nseg_cap[0] + seg;
+        const uint32_t *x = (const uint32_t *)((const WmRlaState *)a.st_final + sidx), *y = (const uint32_t *)((const WmRlaState *)a.st_start + sidx + 1u);
         bool same = true;
 #pragma unroll
         for (int k = 0; k < (int)(sizeof(WmRlaState) / 4); k++) same &= x[k] == y[k];
         if (same) return;                                  /* the next segment started from exactly this state */
-        if (bad[seg + 1u] && !bad[seg]) return;            /* it is listed and has a lane of its own in this launch: next round */
+        if (bad[(uint64_t)(seg + 1u) * g.S] && !bad[(uint64_t)seg * g.S]) return;      /* it is listed and has a lane of its own in this launch: next round */
         seg++;
-        from = &fin;
     }
 }
 

@@ -80,7 +80,9 @@ __global__ void k2_verify(WmPush g, uint32_t algo, const uint32_t *st_start, con
     const uint32_t *p = st_start + sidx * words, *q = st_final + (sidx - 1) * words;
     bool same = true;
     for (uint32_t k = 0; k < words; k++) same &= p[k] == q[k];
-    if (bad) bad[sidx] = same ? 0u : 1u;                  /* the verdict per segment (segments 0 and disabled chains stay 0) */
+    /* the verdict per segment, laid out [chain][segment][capture] so that a wave's 64 captures store one line (capture-major it
+     * was 200 000 scattered 4-byte stores per verification: read-modify-write traffic worth 2 ms of every step) */
+    if (bad) bad[((uint64_t)ch * g.nseg_cap[algo] + seg) * g.S + stream] = same ? 0u : 1u;
     if (!same) list[atomicAdd(n_list, 1u)] = lane;
 }
 

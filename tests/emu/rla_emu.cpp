@@ -90,7 +90,7 @@ long wm_emu_rla(const uint32_t *bits, uint32_t S, uint32_t M, uint32_t Mcap, uin
             if (!(g.flags & (ch ? WM_F_S1 : WM_F_T1C1)) || seg == 0) continue;
             const size_t sidx = ((size_t)ch * S + stream) * nseg + seg;
             const bool differs = std::memcmp(&st_start[sidx], &st_final[sidx - 1], sizeof(WmRlaState)) != 0;
-            bad[sidx] = differs;                                         /* the verdict per segment, stable during the launch that follows */
+            bad[((size_t)ch * nseg + seg) * S + stream] = differs;          /* the verdict per segment ([chain][segment][capture]), stable during the launch that follows */
             if (differs) list.push_back(lane);
         }
         wm_emu_last_rounds = (int)round;
