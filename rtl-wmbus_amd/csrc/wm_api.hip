@@ -151,6 +151,7 @@ struct wmbus_ctx {
     uint32_t *d_first_bad = nullptr;                    /* [2][S] first uncertified EMA tile of a row, or ~0 */
     uint32_t *d_ckpt = nullptr; uint32_t nck = 0;       /* clock kernel checkpoints [2][S][nseg_cap][nck][16] */
     uint32_t *d_bad = nullptr;                          /* [2][nseg_cap[0]][S] the run-length verifier's verdict per segment (K2Args.bad) */
+    uint32_t *d_bad_clk = nullptr;                      /* [2][nseg_cap[1]][S] the clock verifier's */
     bool rla_chains = false;                            /* the chain walk is in use (switched on by the first push whose unattended rounds did not suffice) */
     uint2 *d_hits = nullptr; uint32_t hits_cap = 0;
     uint32_t *d_pending = nullptr;
@@ -370,7 +371,7 @@ void wmbus_close(wmbus_ctx *c)
         std::lock_guard<std::mutex> lk(kc.m);
         if (kc.owner == c) { kc.last = nullptr; kc.owner = nullptr; }      /* nobody may wait on an event that is about to go */
     }
-    void *dev[] = {c->d_bad, c->d_hist, c->d_list_ema, c->d_spill, c->d_chain, c->d_list2, c->d_first_bad, c->d_ckpt, c->d_in, c->d_dphi, c->d_rssi, c->d_bits, c->d_lut, c->d_ema_head, c->d_ema_tail, c->d_ema_carry,
+    void *dev[] = {c->d_bad, c->d_bad_clk, c->d_hist, c->d_list_ema, c->d_spill, c->d_chain, c->d_list2, c->d_first_bad, c->d_ckpt, c->d_in, c->d_dphi, c->d_rssi, c->d_bits, c->d_lut, c->d_ema_head, c->d_ema_tail, c->d_ema_carry,
                    c->d_chips[0], c->d_chips[1], c->d_counts[0], c->d_counts[1], c->d_st_start[0], c->d_st_start[1],
                    c->d_st_final[0], c->d_st_final[1], c->d_st_carry[0], c->d_st_carry[1], c->d_list, c->d_scalars,
                    c->d_hits, c->d_pending};
@@ -539,6 +540,11 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
             if (e == hipSuccess) A(hipMemsetAsync(c->d_bad, 0, (size_t)rows * c->nseg_cap[0] * sizeof(uint32_t), c->stream));
             c->rla_chains = chains == 2;
         }
+        static const bool clk_chains = !(getenv("WMBUS_CLK_CHAINS") && atoi(getenv("WMBUS_CLK_CHAINS")) == 0);
+        if (clk_chains) {
+            A(dalloc(&c->d_bad_clk, (size_t)rows * c->nseg_cap[1]));
+            if (e == hipSuccess) A(hipMemsetAsync(c->d_bad_clk, 0, (size_t)rows * c->nseg_cap[1] * sizeof(uint32_t), c->stream));
+        }
     }
     A(hipHostMalloc((void **)&c->h_scalars, SC_COUNT * sizeof(uint32_t)));
     A(hipHostMalloc((void **)&c->h_hdr, (size_t)c->hdr_cap * sizeof(WmBurstHdr)));
@@ -671,7 +677,7 @@ static void fr_verify(wmbus_ctx *c, int algo, uint32_t cnt, hipStream_t st = nul
     const uint32_t lanes = 2u * a.g.nseg[algo] * a.g.S, words = (algo == WMBUS_ALGO_RLA ? sizeof(WmRlaState) : sizeof(WmClkState)) / 4;
     hipLaunchKernelGGL(k2_verify, dim3((lanes + 255) / 256), dim3(256), 0, st, a.g, (uint32_t)algo, (const uint32_t *)a.st_start,
                        (const uint32_t *)a.st_final, words, algo == WMBUS_ALGO_RLA ? c->d_list2 : c->d_list, c->d_scalars + cnt,
-                       algo == WMBUS_ALGO_RLA && c->rla_chains ? c->d_bad : (uint32_t *)nullptr);
+                       algo == WMBUS_ALGO_RLA ? (c->rla_chains ? c->d_bad : (uint32_t *)nullptr) : c->d_bad_clk);
 }
 
 /* one framer's kernel alone: every lane (cnt == ~0) or the re-run list whose length is scalar `cnt` */
@@ -688,7 +694,7 @@ static void fr_launch(wmbus_ctx *c, int algo, uint32_t cnt, hipStream_t st = nul
      * framer resets inside the segment), so that state was right all along -- walking such runs serially made the round twice
      * as long on the bench workload (r04 A/B: 133 against 147 Gsamples/s).  What is STILL listed after that round is a true
      * cascade (a burst longer than a segment): from the second list round on a listed lane walks its chain (rla_lanes). */
-    if (algo == WMBUS_ALGO_RLA && !all && cnt == SC_RLA + 1u) a.bad = nullptr;
+    if (!all && cnt == (algo == WMBUS_ALGO_RLA ? SC_RLA + 1u : (uint32_t)SC_CLK)) a.bad = nullptr;      /* the same for the clock kernel (clock_lanes) */
     /* list launches: blocks for 3/16 of the lanes (a re-run list is a few percent of them; the blocks walk whatever is more) */
     const uint32_t B = 64 * (algo == WMBUS_ALGO_RLA ? WM_RLA_WPB : WM_CLK_WPB), grid = all ? (lanes + B - 1) / B : std::max(16u, (lanes / B) * 3u / 16u);
     if (algo == WMBUS_ALGO_RLA) {
@@ -868,7 +874,7 @@ static int enqueue_front_impl(wmbus_ctx *c, size_t nbytes)
         k2.ckpt = c->d_ckpt; k2.nck = c->nck;
         c->k2clk = k2; c->k2rla = k2;
         K2Args &ka = c->k2clk, &kr = c->k2rla;
-        ka.algo = WMBUS_ALGO_T2A;
+        ka.algo = WMBUS_ALGO_T2A; ka.bad = c->d_bad_clk;
         ka.chips = c->d_chips[1]; ka.counts = c->d_counts[1]; ka.sync_seen = c->d_sync_seen[1];
         ka.st_start = c->d_st_start[1]; ka.st_final = c->d_st_final[1]; ka.st_carry = st_carry(c, 1, false);
         kr.algo = WMBUS_ALGO_RLA; kr.bad = c->rla_chains ? c->d_bad : nullptr;

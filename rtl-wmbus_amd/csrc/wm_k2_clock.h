@@ -183,29 +183,25 @@ template <int W> struct ClkLds {         /* per block: W independent waves */
 /* PASS: 0 = the speculative first pass only (a.list == nullptr), 1 = a re-run list only, 2 = either (host emulation): each kind of launch has its own
  * kernel, so the first pass carries neither the list walk nor the checkpoint comparison (with both in one kernel behind
  * a grid-stride loop the first pass needed 254 VGPRs + 16 AGPRs and ran at one wave per SIMD, round 2). */
-template <bool DC, int W, bool LEAN = false, int PASS = 2>
-__device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t block, ClkLds<W> &lds)
+/* One segment of one (chain, capture): returns 0 when the lane ran to the segment's end (`fin` = its end state, also written to
+ * st_final), 1 when a re-run left early at a checkpoint it reproduced (the end state in st_final was exact already), 2 when
+ * there was nothing to do.  `from`: the exact state a re-run starts from when the caller has it at hand (nullptr: the
+ * predecessor's record / the carried state). */
+template <bool DC, int W, bool LEAN, int PASS>
+__device__ __forceinline__ int clock_segment(const K2Args &a, ClkLds<W> &lds, const uint32_t wv, const uint32_t ln, const bool rerun,
+                                             const uint32_t ch, const uint32_t stream, const uint32_t seg, const WmClkState *from, WmClkState &fin)
 {
-    const uint32_t ln = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    if (wv >= (uint32_t)W) return;           /* W < waves of the block: the fused launch (see k2_clock_rla) */
     float *s_x = lds.x[wv];
     uint32_t *s_chip = lds.chip[wv], *s_bits = lds.bits[wv];
-    uint32_t lane = (block * W + wv) * 64 + ln;
-    const bool rerun = PASS == 2 ? a.list != nullptr : PASS == 1;
     const WmPush &g = a.g;
     const bool coop = !rerun && (g.S % 64u) == 0u;         /* wave = 64 consecutive streams, lock step */
-    if (lane >= k2_lane_count(a)) return;
-    if (rerun) lane = a.list[lane];
-    uint32_t ch, stream, seg;
-    lane_decode(g, 1, lane, ch, stream, seg);
-    if (!(g.flags & (ch ? WM_F_S1 : WM_F_T1C1))) return;
 
     /* S1 lanes may span two segments (WmPush.s1_span): the odd segment rides with its even predecessor.  The lane then
      * owns both segments' chip regions, checkpoint slots and hand-off records (they are adjacent): chips and count go to
      * the even one (the odd one's count is 0), the end state to the odd one's record, and the pair (final[even],
      * start[odd]) is set to one constant so that the verifier, which knows nothing of this, sees a certified hand-off. */
     const uint32_t span = (ch == 1u && g.s1_span == 2u) ? 2u : 1u;
-    if (seg % span) return;
+    if (seg % span) return 2;
     const uint64_t row = (uint64_t)ch * g.S + stream;
     const uint64_t sidx = row * g.nseg_cap[1] + seg;
     const uint32_t mb = seg * g.seg_len[1], me = min(g.M, mb + span * g.seg_len[1]);
@@ -217,7 +213,7 @@ __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t bloc
 
     WmClkState s;
     uint32_t m;
-    if (rerun) { s = seg ? stF[sidx - 1] : stC[row]; m = mb; }
+    if (rerun) { s = from ? *from : seg ? stF[sidx - 1] : stC[row]; m = mb; }
     else {
         const uint32_t w = g.warm[ch];
         if (mb <= w) { s = stC[row]; m = 0; }            /* exact: run from the push start  */
@@ -415,7 +411,7 @@ __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t bloc
                         for (uint32_t jj = j; jj < nck; jj++) ck[16u * jj + 12u] -= n0 - n1;
                     }
                     if (saw_sync) a.sync_seen[sidx] = 1u;       /* the tail's flag, if any, is already set */
-                    return;
+                    return 1;
                 }
                 /* Not on the recorded trajectory: from here on the region holds MY chips (and all of it
                  * if I run to the end), so the checkpoint must describe me -- a later round that re-runs
@@ -450,6 +446,58 @@ __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t bloc
     a.counts[sidx] = min(n_out, cap_t2);
     if (saw_sync) a.sync_seen[sidx] = 1u;
     if (n_out > cap_t2) atomicOr(a.err, WM_ERR_CHIP_OVERFLOW);       /* cannot happen: the lock pattern takes >= 4 samples per chip */
+    fin = s;
+    return 0;
+}
+
+/* The lanes of one launch.  First pass: lane = (chain, segment, capture), every lane one segment.
+ * Re-run list, from the SECOND list round on (round 4; K2Args.bad set): a listed lane walks its CHAIN.  A segment is listed
+ * because its start did not match its predecessor's end; k2_verify also leaves that verdict per segment in `a.bad`.  The first
+ * list round re-runs every listed segment on its own, in parallel, from the predecessor's end state as recorded -- right
+ * unless that predecessor is itself re-run and comes out different, which is rare with whole-wave batches (fewer than ten
+ * lanes of 16 384) and the rule with the short segments of a small batch, where a slowly converging stretch covers several
+ * segments and every round settled one more of them (a single capture of configs[1] fell to the host-driven path on every
+ * push).  In a chain walk the FIRST listed segment of a run of consecutive listed ones does them all, one after the other,
+ * each from the exact end state of the one before (the others return at once), and goes on into the segment behind the run
+ * as long as the end state it arrives with differs from that segment's recorded start -- unless that segment has a lane of
+ * its own in this launch (listed behind an unlisted one), which the next round sorts out.  (Walking chains already in the
+ * first list round made it 2.8 ms longer on the bench workload: neighbours that are both listed usually both leave at an
+ * early checkpoint, and serialising them doubles the longest lane.) */
+template <bool DC, int W, bool LEAN = false, int PASS = 2>
+__device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t block, ClkLds<W> &lds)
+{
+    const uint32_t ln = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    if (wv >= (uint32_t)W) return;           /* W < waves of the block: the fused launch (see k2_clock_rla) */
+    uint32_t lane = (block * W + wv) * 64 + ln;
+    const bool rerun = PASS == 2 ? a.list != nullptr : PASS == 1;
+    const WmPush &g = a.g;
+    if (lane >= k2_lane_count(a)) return;
+    if (rerun) lane = a.list[lane];
+    uint32_t ch, stream, seg;
+    lane_decode(g, 1, lane, ch, stream, seg);
+    if (!(g.flags & (ch ? WM_F_S1 : WM_F_T1C1))) return;
+    WmClkState fin;
+    const bool chains = rerun && a.bad != nullptr && !(ch == 1u && g.s1_span == 2u);
+    if (!chains) { clock_segment<DC, W, LEAN, PASS>(a, lds, wv, ln, rerun, ch, stream, seg, nullptr, fin); return; }
+    const uint64_t row = (uint64_t)ch * g.S + stream;
+    const uint32_t *bad = a.bad + (uint64_t)ch * g.nseg_cap[1] * g.S + stream;       /* verdict of segment j at bad[j * S] */
+    const WmClkState *stS = (const WmClkState *)a.st_start, *stF = (const WmClkState *)a.st_final;
+    if (seg > 0u && bad[(uint64_t)(seg - 1u) * g.S]) return;            /* the head of my run covers me */
+    const WmClkState *from = nullptr;
+    for (;;) {
+        const int how = clock_segment<DC, W, LEAN, PASS>(a, lds, wv, ln, true, ch, stream, seg, from, fin);
+        const uint64_t sidx = row * g.nseg_cap[1] + seg;
+        if (how == 1) fin = stF[sidx];                     /* left at a checkpoint: the recorded end state was exact */
+        if (how == 2 || seg + 1u >= g.nseg[1]) return;
+        const uint32_t *x = (const uint32_t *)&fin, *y = (const uint32_t *)&stS[sidx + 1u];
+        bool same = true;
+#pragma unroll
+        for (int k = 0; k < (int)(sizeof(WmClkState) / 4); k++) same &= x[k] == y[k];
+        if (same) return;                                  /* the next segment started from exactly this state */
+        if (bad[(uint64_t)(seg + 1u) * g.S] && !bad[(uint64_t)seg * g.S]) return;      /* it is listed and has a lane of its own in this launch: next round */
+        seg++;
+        from = &fin;
+    }
 }
 
 template <bool DC>

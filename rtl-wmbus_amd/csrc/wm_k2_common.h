@@ -28,7 +28,7 @@ struct K2Args {
      * speculative pass had already been on the exact trajectory. */
     uint32_t *ckpt; uint32_t nck;
     /* [2][nseg_cap][S]: k2_verify's verdict per segment (1: its start did not match its predecessor's end), for the chain
-     * walk of the run-length kernel's re-run lanes (rla_lanes); nullptr: every listed segment on its own, as in round 3 */
+     * walk of the framer kernels' re-run lanes (clock_lanes, rla_lanes); nullptr: every listed segment on its own, as in round 3 */
     const uint32_t *bad;
 };
 

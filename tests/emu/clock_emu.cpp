@@ -46,6 +46,7 @@ int wm_emu_descending = 1;
 int wm_emu_s1_span = 0;                   /* WmPush.s1_span of the next calls */
 uint32_t *wm_emu_seen_out = nullptr;      /* optional: receives the per-region "access-code chip seen" flags */
 int wm_emu_lean_reruns = 0;
+int wm_emu_chains = 1;                    /* K2Args.bad: a listed lane walks its chain (round 4); 0: every listed segment on its own */
 
 /* One push of M decimated samples for S captures.  dphi: [2][S][Mcap] soft symbols; carry: [2][S]
  * WmClkState in/out; bits: [2][S][Mcap/32] out; chips: [2][S][nseg][cap]; counts: [2][S][nseg].
@@ -61,12 +62,14 @@ long wm_emu_clock(const float *dphi, uint32_t S, uint32_t M, uint32_t Mcap, uint
     const uint32_t rows = 2 * S, nseg = g.nseg[1], lanes = rows * nseg;
     const uint32_t nck = seg_len / WM_CK_SAMPLES ? seg_len / WM_CK_SAMPLES - 1 : 0;
     std::vector<WmClkState> st_start((size_t)rows * nseg), st_final((size_t)rows * nseg);
+    std::vector<uint32_t> bad((size_t)rows * nseg, 0);
     std::vector<uint32_t> seen((size_t)rows * nseg, 0), ckpt(std::max<size_t>(16, (size_t)rows * nseg * nck * 16), 0xDEADBEEFu), list;
     uint32_t err = 0;
     K2Args a{};
     a.g = g; a.dphi = dphi; a.bits = bits; a.chips = chips; a.counts = counts;
     a.st_start = st_start.data(); a.st_final = st_final.data(); a.st_carry = carry;
     a.algo = 1; a.err = &err; a.sync_seen = seen.data(); a.ckpt = ckpt.data(); a.nck = nck;
+    a.bad = wm_emu_chains ? bad.data() : nullptr;
     static ClkLds<1> lds;
     const bool dc = flags & WM_F_DC;
     auto launch = [&](const uint32_t *lst, uint32_t n) {
@@ -102,11 +105,14 @@ long wm_emu_clock(const float *dphi, uint32_t S, uint32_t M, uint32_t Mcap, uint
             lane_decode(g, 1, lane, ch, stream, seg);
             if (!(g.flags & (ch ? WM_F_S1 : WM_F_T1C1)) || seg == 0) continue;
             const size_t sidx = ((size_t)ch * S + stream) * nseg + seg;
-            if (std::memcmp(&st_start[sidx], &st_final[sidx - 1], sizeof(WmClkState))) list.push_back(lane);
+            const bool differs = std::memcmp(&st_start[sidx], &st_final[sidx - 1], sizeof(WmClkState)) != 0;
+            bad[((size_t)ch * nseg + seg) * S + stream] = differs;          /* the verdict per segment ([chain][segment][capture]), stable during the launch that follows */
+            if (differs) list.push_back(lane);
         }
         if (list.empty()) break;
         if (round > nseg + 1) return -1;
         reruns += (long)list.size();
+        a.bad = (wm_emu_chains && round >= 1) ? bad.data() : nullptr;   /* the first list round re-runs lone segments (wm_api.hip fr_launch) */
         launch(list.data(), (uint32_t)list.size());
     }
     WmClkState *c = (WmClkState *)carry;                                 /* k_carry */

@@ -97,6 +97,7 @@ long wm_emu_rla(const uint32_t *bits, uint32_t S, uint32_t M, uint32_t Mcap, uin
         if (list.empty()) break;
         if (round > nseg + 1) return -1;
         reruns += (long)list.size();
+        a.bad = (wm_emu_chains && round >= 1) ? bad.data() : nullptr;   /* the first list round re-runs lone segments (wm_api.hip fr_launch) */
         launch(list.data(), (uint32_t)list.size());
     }
     WmRlaState *c = (WmRlaState *)carry;                                 /* k_carry */
