@@ -13,7 +13,7 @@
  * rtl_wmbus.c:1281), -S statistics, and
  *   rtl_wmbus_hip [switches] a.cu8 b.cu8 ...      batch mode: one capture per file, lines prefixed "a.cu8: ".
  * A batch is a wmbus_batch of the library per device: the files are split over several receiver contexts (whole groups
- * of 64, eight contexts at most) that run on their own threads and overlap each other, 8 MiB per file and push, the next
+ * of 64, eight contexts at most) that run on their own threads and overlap each other, 2 MiB per file and push, the next
  * push read into page-locked memory and staged into a context's second input window while the previous one is in
  * flight.  With -G all (or -G 0,2,5) the files are sharded over the GPUs of the node, file i on device list[i mod n]
  * (file-per-GPU, no collective), each file's lines in its own order.  -M prints that map and exits.
@@ -51,7 +51,7 @@ static void print_usage(const char *prog)
     fprintf(stdout, "\t-s receive S1 and T1/C1 datagrams simultaneously. rtl_sdr _MUST_ be set to 868.625MHz (-f 868.625M)\n");
     fprintf(stdout, "\t-p [T,S] to disable processing T1/C1 or S1 mode\n");
     fprintf(stdout, "\t-f exit if flow of incoming data stops\n");
-    fprintf(stdout, "\t-B bytes per GPU push (multiple of 4096; default 1048576 for a live stream, 8388608 per file in batch mode)\n");
+    fprintf(stdout, "\t-B bytes per GPU push (multiple of 4096; default 1048576 for a live stream, 2097152 per file in batch mode)\n");
     fprintf(stdout, "\t-L ms a live stream's bytes wait at most this long for their push to fill (default 50; 0: only full pushes)\n");
     fprintf(stdout, "\t-S batch mode: print samples, seconds and Msamples/s to stderr\n");
     fprintf(stdout, "\t-G HIP device ordinal (default 0); batch mode: 'all' or a list '0,2,5' shards the files, file i on device list[i mod n]\n");
@@ -338,8 +338,11 @@ int main(int argc, char **argv)
     }
 
     if (optind < argc) {
-        /* batch mode: 8 MiB per file and push (the headline configuration's push; -B overrides) */
-        if (cfg.max_push_bytes == 0) cfg.max_push_bytes = 8u << 20;
+        /* batch mode: 2 MiB per file and push (-B overrides).  The staging is page-locked -- 2 x files x push bytes, pinned by
+         * the driver one allocation at a time at about 6 GB/s -- and a job whose files are a few pushes long spends longer
+         * pinning than decoding: 1024 files of 64 MiB took 3.9-4.3 s end to end with 8 MiB pushes (16 GB of staging),
+         * 2.5-2.7 s with 2 MiB (4 GB), 2.9-3.1 s with 4 MiB; r03, which pinned everything before its first push: 6.6-7.4 s */
+        if (cfg.max_push_bytes == 0) cfg.max_push_bytes = 2u << 20;
         if (n_devs == 0) { devs[0] = cfg.device; n_devs = 1; }
         finish(run_sharded(cfg, argc - optind, argv + optind, devs, n_devs, map_only, stats));
     }

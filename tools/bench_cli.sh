@@ -26,9 +26,9 @@ run() {  # $1 = tag, rest = CLI arguments
   e=$(date +%s.%N)
   echo "$tag wall $(python3 -c "print(round($e - $s, 3))") s, lines $(wc -l < $D/out_$tag.txt)"; grep "total:" $D/err_$tag.txt
 }
-run warm -v          # first touch of the page cache, HIP start-up
-run a -v
-run b -v
+run warm -v $CLI_ARGS         # first touch of the page cache, HIP start-up
+run a -v $CLI_ARGS
+run b -v $CLI_ARGS
 python3 - <<PY
 import json, re, subprocess, os
 def parse(tag):
@@ -38,11 +38,11 @@ def parse(tag):
                 with_setup_s=float(m.group(6)), with_setup_msamples_s=float(m.group(7)), lines=sum(1 for _ in open("$D/out_%s.txt" % tag)))
 runs = [parse("a"), parse("b")]
 best = max(runs, key=lambda r: r["decode_msamples_s"])
-out = {"command": "rtl_wmbus_hip -v -S f0000.cu8 ... f%04d.cu8 (batch mode, default 8 MiB pushes, $NFILES files of $PASSES x 8 MiB in /dev/shm)" % ($NFILES - 1),
+out = {"collected_at": os.environ.get("WMBUS_COMMIT", "unknown"), "command": "rtl_wmbus_hip -v -S f0000.cu8 ... f%04d.cu8 (batch mode, default 8 MiB pushes, $NFILES files of $PASSES x 8 MiB in /dev/shm)" % ($NFILES - 1),
        "value": best["decode_msamples_s"], "unit": "Msamples/s", "runs": runs,
        "pcie_bound_msamples_s": 24800.0, "note": "decode = wmbus_batch_run wall clock (file reads into page-locked slabs, H2D, kernels, host decode, printing); "
        "with_setup adds opening the contexts and allocating the page-locked staging"}
-fh = subprocess.run("timeout 600 python bench.py --from-host --steps 8 --warmup 1 --no-cpu-baseline --no-check", shell=True, capture_output=True, text=True)
+fh = subprocess.run("true" if os.environ.get("CLI_SKIP_FROM_HOST") else "timeout 600 python bench.py --from-host --steps 8 --warmup 1 --no-cpu-baseline --no-check", shell=True, capture_output=True, text=True)
 try:
     out["bench_from_host_msamples_s"] = json.loads(fh.stdout.strip().splitlines()[-1])["value"]
     out["cli_over_bench_from_host"] = round(out["value"] / out["bench_from_host_msamples_s"], 3)
