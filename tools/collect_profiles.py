@@ -23,6 +23,8 @@ COPIES = [("trace/bench_kernel_stats.csv", "bench_kernel_stats.csv"),
           ("bench_under_rocprof.json", "bench_under_rocprof.json"),
           ("trace1/single_kernel_stats.csv", "single_context_kernel_stats.csv"),
           ("single_context_under_rocprof.json", "single_context_under_rocprof.json"),
+          ("trace_c3/c3_kernel_stats.csv", "c3_kernel_stats.csv"),
+          ("c3_under_rocprof.json", "c3_under_rocprof.json"),
           ("pmc_fetch_size.csv", "pmc_fetch_size.csv"),
           ("pmc_write_size.csv", "pmc_write_size.csv"),
           ("pmc_sq.csv", "pmc_sq_counters.csv")]

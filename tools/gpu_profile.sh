@@ -3,11 +3,14 @@
 # WRITE_SIZE PMC passes (separate runs, single context so that one k1 launch covers all captures)
 mkdir -p gpurun_out/prof; export TMPDIR=/tmp; cd /tmp
 R=$GRAFT_REPO_ROOT
-timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof/trace -o bench --output-format csv -- python $R/bench.py --steps 5 --warmup 1 --no-tolerance-leg > $R/gpurun_out/prof/bench_under_rocprof.json 2> $R/gpurun_out/prof/trace.log
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof/trace -o bench --output-format csv -- python $R/bench.py --steps 5 --warmup 1 --no-tolerance-leg --no-legs > $R/gpurun_out/prof/bench_under_rocprof.json 2> $R/gpurun_out/prof/trace.log
 tail -1 $R/gpurun_out/prof/bench_under_rocprof.json | cut -c1-400
 # (1b) the same kernels un-overlapped: one context of 1024 captures, nothing runs beside anything
 timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof/trace1 -o single --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --contexts 1 --no-cpu-baseline --no-check > $R/gpurun_out/prof/single_context_under_rocprof.json 2> $R/gpurun_out/prof/trace1.log
 tail -1 $R/gpurun_out/prof/single_context_under_rocprof.json | cut -c1-300
+# (1c) configs[2] at batch size: the -d 5 -s instantiation of the demodulation kernel and the framers behind it
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof/trace_c3 -o c3 --output-format csv -- python $R/tools/gpu_c3.py > $R/gpurun_out/prof/c3_under_rocprof.json 2> $R/gpurun_out/prof/trace_c3.log
+tail -1 $R/gpurun_out/prof/c3_under_rocprof.json | cut -c1-300
 for ctr in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $ctr --kernel-trace --stats -d $R/gpurun_out/prof/pmc_$ctr -o pmc --output-format csv -- python $R/bench.py --steps 1 --warmup 0 --contexts 1 --no-cpu-baseline --no-check > $R/gpurun_out/prof/pmc_$ctr.log 2>&1
   echo "$ctr rc=$?"
