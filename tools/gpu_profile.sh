@@ -3,16 +3,16 @@
 # WRITE_SIZE PMC passes (separate runs, single context so that one k1 launch covers all captures)
 mkdir -p gpurun_out/prof; export TMPDIR=/tmp; cd /tmp
 R=$GRAFT_REPO_ROOT
-timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof/trace -o bench --output-format csv -- python $R/bench.py --steps 5 --warmup 1 --no-tolerance-leg --no-legs > $R/gpurun_out/prof/bench_under_rocprof.json 2> $R/gpurun_out/prof/trace.log
+[ -n "$PMC_ONLY" ] || timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof/trace -o bench --output-format csv -- python $R/bench.py --steps 5 --warmup 1 --no-tolerance-leg --no-legs > $R/gpurun_out/prof/bench_under_rocprof.json 2> $R/gpurun_out/prof/trace.log
 tail -1 $R/gpurun_out/prof/bench_under_rocprof.json | cut -c1-400
 # (1b) the same kernels un-overlapped: one context of 1024 captures, nothing runs beside anything
-timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof/trace1 -o single --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --contexts 1 --no-cpu-baseline --no-check > $R/gpurun_out/prof/single_context_under_rocprof.json 2> $R/gpurun_out/prof/trace1.log
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof/trace1 -o single --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --contexts 1 --quick > $R/gpurun_out/prof/single_context_under_rocprof.json 2> $R/gpurun_out/prof/trace1.log
 tail -1 $R/gpurun_out/prof/single_context_under_rocprof.json | cut -c1-300
 # (1c) configs[2] at batch size: the -d 5 -s instantiation of the demodulation kernel and the framers behind it
-timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof/trace_c3 -o c3 --output-format csv -- python $R/tools/gpu_c3.py > $R/gpurun_out/prof/c3_under_rocprof.json 2> $R/gpurun_out/prof/trace_c3.log
+[ -n "$PMC_ONLY" ] || timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof/trace_c3 -o c3 --output-format csv -- python $R/tools/gpu_c3.py > $R/gpurun_out/prof/c3_under_rocprof.json 2> $R/gpurun_out/prof/trace_c3.log
 tail -1 $R/gpurun_out/prof/c3_under_rocprof.json | cut -c1-300
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $ctr --kernel-trace --stats -d $R/gpurun_out/prof/pmc_$ctr -o pmc --output-format csv -- python $R/bench.py --steps 1 --warmup 0 --contexts 1 --no-cpu-baseline --no-check > $R/gpurun_out/prof/pmc_$ctr.log 2>&1
+  timeout 600 rocprofv3 --pmc $ctr --kernel-trace --stats -d $R/gpurun_out/prof/pmc_$ctr -o pmc --output-format csv -- python $R/bench.py --steps 1 --warmup 0 --contexts 1 --quick > $R/gpurun_out/prof/pmc_$ctr.log 2>&1
   echo "$ctr rc=$?"
 done
 # (3) SQ counters of the same single-context run (1024 captures per launch), each group in its own pass: what the VALU
@@ -21,7 +21,7 @@ i=0
 for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC" ; do
   i=$((i+1))
-  timeout 600 rocprofv3 --pmc $grp --kernel-trace --stats -d $R/gpurun_out/prof/pmc_sq$i -o pmc --output-format csv -- python $R/bench.py --steps 1 --warmup 0 --contexts 1 --no-cpu-baseline --no-check > $R/gpurun_out/prof/pmc_sq$i.log 2>&1
+  timeout 600 rocprofv3 --pmc $grp --kernel-trace --stats -d $R/gpurun_out/prof/pmc_sq$i -o pmc --output-format csv -- python $R/bench.py --steps 1 --warmup 0 --contexts 1 --quick > $R/gpurun_out/prof/pmc_sq$i.log 2>&1
   echo "SQ group $i rc=$?"
 done
 python3 - <<'PY'
