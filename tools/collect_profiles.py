@@ -124,15 +124,16 @@ n_k1, f_k1 = pick(fetch, "k1_demod2")
 _, w_k1 = pick(write, "k1_demod2")
 if n_k1:
     S, N = 1024, 1 << 22
-    fetch_b = 2.0 * f_k1 * 1024 / n_k1          # FETCH_SIZE reports half of wide coalesced reads on gfx950
-    write_b = w_k1 * 1024 / n_k1
+    PASSES = 2                                  # bench.py --steps 1 --warmup 0: the timed step + the un-overlapped calibration pass
+    fetch_b = 2.0 * f_k1 * 1024 / PASSES        # FETCH_SIZE reports half of wide coalesced reads on gfx950; per PASS over the
+    write_b = w_k1 * 1024 / PASSES              # 1024 captures (since round 4 a pass is two launches: the main part and the tail)
     traffic = {
         "collected_at": COLLECTED_AT, "profiles_tag": tag,
         "kernel": "k1_demod2<2,false>",
-        "launch": f"{S} captures x 2^22 IQ samples in one launch (bench.py --contexts 1 --steps 1 --warmup 0: the timed step "
-                  f"plus the un-overlapped calibration pass = {n_k1} launches)",
-        "FETCH_SIZE_KB_per_launch": round(f_k1 / n_k1, 2),
-        "WRITE_SIZE_KB_per_launch": round(w_k1 / n_k1, 2),
+        "launch": f"{S} captures x 2^22 IQ samples per pass (bench.py --contexts 1 --steps 1 --warmup 0: the timed step "
+                  f"plus the un-overlapped calibration pass = {PASSES} passes, {n_k1} launches: main part + tail each)",
+        "FETCH_SIZE_KB_per_launch": round(f_k1 / PASSES, 2),
+        "WRITE_SIZE_KB_per_launch": round(w_k1 / PASSES, 2),
         "correction": "FETCH_SIZE doubled (gfx950 reports 1/2 of wide coalesced reads, MI355X_MICROARCH.md section HBM); "
                       "WRITE_SIZE taken as reported (k_fill calibration in the first session: 1.10x of the bytes written)",
         "k1_demod_hbm_bytes_per_launch": fetch_b + write_b,
