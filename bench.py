@@ -164,7 +164,7 @@ def leg_single_stream(wm, O, name, n, kw, okw, synth_kw, reps=7):
             "reruns": {k: tim[k] for k in ("clock_reruns", "rla_reruns", "ema_retries", "slow_path")}}
 
 
-def leg_c3_batch(wm, O, shard, S, n, device, steps):
+def leg_c3_batch(wm, O, shard, S, n, device, steps, **tune):
     """configs[2] at batch size (informational): S captures at 4.0 MS/s through `-d 5 -s` (both chains fed from the +-325 kHz
     translation), resident in HBM.  Rate, the demodulation kernel alone, 16 captures' first pass against the oracle."""
     caps = [None] * S
@@ -175,7 +175,7 @@ def leg_c3_batch(wm, O, shard, S, n, device, steps):
     with cf.ThreadPoolExecutor(min(os.cpu_count() or 1, 64)) as ex:
         list(ex.map(gen, range(S)))
     b = wm.Batch(n_streams=S, contexts=0, max_push_bytes=2 * n, device=device, decimation=5, simultaneous=True, show_algorithm=True, fixed_timestamp=True,
-                 host_threads=shard.host_threads_per_context(1, 8), keep_taps=False)
+                 host_threads=shard.host_threads_per_context(1, 8), keep_taps=False, **tune)
     try:
         for s_ in range(S):
             b.stage(s_, caps[s_])

@@ -418,7 +418,12 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
         uint32_t k = 1;
         while (k < 8u && c->S * k < 64u) k *= 2u;          /* 1 for >= 64 captures ... 8 for fewer than 16 */
         c->C[1] = cfg->seg_len ? cfg->seg_len : 32768u / k;
-        c->C[0] = cfg->rla_seg_len ? cfg->rla_seg_len : std::max(2048u, 8192u / k);
+        /* run-length segments: 4096 (r04 A/B on the bench workload: 151.0 / 151.1 against 148.9 / 150.6 with round 3's 8192 and
+         * 136.3 / 134.1 with 2048); 2048 with -s, where S1 telegrams -- 30-100 ms, several segments long -- are expected in both
+         * chains and every segment inside one is re-run in a chain walk whose length is the telegram's whatever the segment
+         * length, while first pass and first list round scale with it (configs[2] batch: 92.8 / 110.3 / 133.3 Gsamples/s with
+         * 8192 / 4096 / 2048, 124.9 with 1024) */
+        c->C[0] = cfg->rla_seg_len ? cfg->rla_seg_len : std::max(2048u, (cfg->simultaneous ? 2048u : 4096u) / k);
     }
     for (int a = 0; a < 2; a++)
         if (c->C[a] < 1024u || c->C[a] > (1u << 20) || (c->C[a] & (c->C[a] - 1)))
