@@ -47,10 +47,29 @@ def test_cli_batch_of_320_files_runs_on_several_contexts_and_matches_the_oracle(
     m = re.search(rb"320 files, (\d+) contexts, (\d+) samples", p.stderr)
     assert m and int(m.group(1)) == 5                          # the library split the batch, not the caller
     assert int(m.group(2)) == 320 * lens[0] // 2                 # every group advanced by its longest file
-    # the product starts decoding at its first read (rtl_wmbus.c:1298-1308) -- setting up (HIP runtime, contexts;
-    # the page-locked staging is pinned by the workers while the first contexts already decode) takes less than the decode
-    t = re.search(rb"decode ([\d.]+) s = .*?with set-up .*? ([\d.]+) s =", p.stderr)
-    assert t and float(t.group(2)) - float(t.group(1)) <= float(t.group(1)), p.stderr[-400:]
+
+
+def test_cli_batch_sets_up_faster_than_it_decodes(wm, tmp_path):
+    """the reference starts decoding at its first read (rtl_wmbus.c:1298-1308).  320 files of 16 MiB (names linked
+    onto eight captures): starting the HIP runtime and opening five contexts takes less than the decode, because the page-locked
+    staging is pinned by the contexts' own threads while the first of them already decode (round 3 pinned everything first: 5-6 s
+    of set-up before 1.6 s of decode for 1024 files)."""
+    caps = [wm.synth_capture(seed=9500 + i, n_samples=1 << 23, kinds=7, frames_per_s=20.0)[0] for i in range(8)]
+    for i, c in enumerate(caps):
+        c.tofile(tmp_path / f"src{i}.cu8")
+    names = []
+    for i in range(320):
+        os.symlink(tmp_path / f"src{i % 8}.cu8", tmp_path / f"f{i:03d}.cu8")
+        names.append(f"f{i:03d}.cu8")
+    best = None
+    for _ in range(2):                                         # the first run also loads the code objects and fills the page cache
+        p = subprocess.run([wm.CLI_PATH, "-v", "-S"] + names, cwd=tmp_path, capture_output=True, env=dict(os.environ, WMBUS_FIXED_TS="1"), timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        t = re.search(rb"decode ([\d.]+) s = .*?with set-up .*? ([\d.]+) s =", p.stderr)
+        assert t, p.stderr[-400:]
+        best = (float(t.group(1)), float(t.group(2)))
+    assert p.stdout.count(b"\n") > 10000
+    assert best[1] - best[0] <= best[0], best                   # set-up <= decode
 
 
 def test_cli_batch_closes_its_batches_when_asked_to_exit_slowly(wm, oracle, tmp_path):
