@@ -1,18 +1,33 @@
-/* wm_k2_rla.h -- K2 run-length framer lanes.  Uses no wave-level or float intrinsics beyond __ffs and __frcp_rn, so
+/* wm_k2_rla.h -- K2 run-length framer lanes.  Uses no wave-level or float intrinsics beyond __ffs and one reciprocal, so
  * tests/emu compiles this file for the host and runs it lane by lane against the oracle.
  * Device code, included by wm_kernels.hip (one translation unit, see the overview there). */
 #ifndef WM_K2_RLA_H
 #define WM_K2_RLA_H
 
-/* Exact truncating signed division for |a| < 2^24, 0 < b < 2^12 via one float reciprocal and a
- * +-1 fix-up (the hardware integer divide is ~40 instructions and sits on the serial path). */
-__device__ __forceinline__ int wm_sdiv(int a, int b)
+/* Exact truncating division for |a| < 2^24, 4 <= b < 2^12 via the hardware's APPROXIMATE reciprocal and a +-1 fix-up (the
+ * integer divide is ~40 instructions and sits on the serial path of every edge; round 3 used the correctly rounded reciprocal,
+ * itself a ten-instruction sequence -- three divisions were 130 of the ~310 instructions of an edge trip).
+ * Why +-1 suffices: v_rcp_f32 is within 1 ulp, so rcp = (1 / b)(1 + e1), |e1| <= 2^-23; the product rounds once more,
+ * |e2| <= 2^-24; ua converts exactly.  |estimate - ua / b| <= (ua / b) * 1.5 * 2^-23 < (2^24 / b) * 1.5 * 2^-23 = 3 / b <= 0.75
+ * for b >= 4: the truncated estimate is q - 1, q or q + 1, and the remainder test repairs it.  Divisors below 4 (a bit-length
+ * tracker dragged to nothing by an interferer) and operands beyond the bounds take the integer divide.  The result is an exact
+ * integer either way, so the host emulation (1.0f / x) and the device agree whatever the reciprocals' last bits. */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define WM_RCP_APPROX(x) __builtin_amdgcn_rcpf(x)
+#else
+#define WM_RCP_APPROX(x) (1.0f / (x))
+#endif
+__device__ __forceinline__ unsigned wm_udiv(unsigned ua, unsigned b)          /* ua / b for non-negative operands */
 {
-    const unsigned ua = (unsigned)(a < 0 ? -a : a);
-    if (ua >= (1u << 24) || (unsigned)b >= (1u << 12)) return a / b;
-    unsigned q = (unsigned)((float)ua * __frcp_rn((float)b));
-    const int r = (int)ua - (int)(q * (unsigned)b);
-    if (r < 0) q--; else if (r >= b) q++;
+    if (ua >= (1u << 24) || b - 4u >= (1u << 12) - 4u) return ua / b;
+    unsigned q = (unsigned)((float)ua * WM_RCP_APPROX((float)b));
+    const int r = (int)ua - (int)(q * b);
+    q = r < 0 ? q - 1u : r >= (int)b ? q + 1u : q;
+    return q;
+}
+__device__ __forceinline__ int wm_sdiv(int a, int b)                          /* C's truncating a / b, b > 0 */
+{
+    const unsigned q = wm_udiv((unsigned)(a < 0 ? -a : a), (unsigned)b);
     return a < 0 ? -(int)q : (int)q;
 }
 
@@ -203,7 +218,7 @@ __device__ __forceinline__ void rla_segment(const K2Args &a, RlaLds &lds, const 
                     s.cum += rest;
                     s.bitlen += wm_sdiv(rest + s.cum / 16, 32 * n);                          /* :792-796 */
                 } else {
-                    const int v = wm_sdiv(run0, n);                                          /* :698 */
+                    const int v = (int)wm_udiv((unsigned)run0, (unsigned)n);                  /* :698; run0 > half >= 0, n >= 1 */
                     if (level) s.spb1 = v; else s.spb0 = v;
                 }
             }

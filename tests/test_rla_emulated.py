@@ -168,6 +168,16 @@ def test_a_burst_longer_than_a_segment_is_settled_by_one_chain_walk(emu, oracle,
     assert rounds[False] >= 4 and rounds[True] <= 2, rounds
 
 
+def test_division_through_an_approximate_reciprocal_is_exact(tmp_path):
+    """The run-length kernel's divisions (chips per run, bit-length update, samples per bit) go through v_rcp_f32 -- within 1 ulp,
+    not correctly rounded -- and one +-1 repair (wm_udiv): tests/sdiv_check.cpp runs the formula with the reciprocal pushed 1 ulp
+    either way over the whole divisor domain (10^9 cases)."""
+    exe = str(tmp_path / "sdiv_check")
+    subprocess.run(["g++", "-O2", "-o", exe, os.path.join(HERE, "sdiv_check.cpp")], check=True)
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and p.stdout.strip().endswith(" 0 wrong"), p.stdout
+
+
 def test_chip_flood_continues_in_the_spill_arena(emu, oracle, wm):
     """The reference's chip loop never gives up (rtl_wmbus.c:765-779); a segment that outgrows its primary region (the
     product's half a chip per sample) continues in chunks of the spill arena, re-runs reuse the segment's chain, and the
