@@ -412,12 +412,13 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
     /* Time segments: 32768 / 8192 decimated samples for batches of whole waves (r02 / r03 A/Bs: clock 65536 -8 %, 16384 -25 %;
      * run-length 16384 -9 %, 4096 -20 %).  A batch with fewer captures than a wave has lanes is bound by how long ONE lane
      * walks (5 us per 32 samples whatever runs beside it), not by the work: its segments shrink with the capture count, down
-     * to 4096 / 2048 for a single capture (one 2^22-sample push of one capture: 19 -> 9 ms; the result does not depend on the
+     * to 8192 / 2048 for a single capture (one 2^22-sample push of one capture: 29 -> 9 ms; the result does not depend on the
      * segmentation, test_result_independent_of_segmentation). */
     {
         uint32_t k = 1;
         while (k < 8u && c->S * k < 64u) k *= 2u;          /* 1 for >= 64 captures ... 8 for fewer than 16 */
-        c->C[1] = cfg->seg_len ? cfg->seg_len : 32768u / k;
+        c->C[1] = cfg->seg_len ? cfg->seg_len : 32768u / std::min(k, 4u);      /* one capture, r04: 9.3 / 8.8 / 7.7 ms per configs[1] push with 4096 / 8192 / 16384,
+                                                                                  9.5 / 9.0 / 10.5 for configs[2]: 8192 */
         /* run-length segments: 4096 (r04 A/B on the bench workload: 151.0 / 151.1 against 148.9 / 150.6 with round 3's 8192 and
          * 136.3 / 134.1 with 2048); 2048 with -s, where S1 telegrams -- 30-100 ms, several segments long -- are expected in both
          * chains and every segment inside one is re-run in a chain walk whose length is the telegram's whatever the segment
