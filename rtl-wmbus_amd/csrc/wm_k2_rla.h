@@ -197,21 +197,23 @@ __device__ __forceinline__ void rla_segment(const K2Args &a, RlaLds &lds, const 
                  * decoder consumes at most 16*290 chips after an access code, and identical chips
                  * cannot complete one, so the rest of the run is not materialised -- only counted, as
                  * the reference's loop would. */
+                /* Only the FIRST chip of a run can complete an access code (both end in two different chips, :97-103; the
+                 * chips of a run are equal), and only it carries the reset marker: the others are one constant word, and
+                 * the shift register takes them in one shift (what the wave pays per edge is the LONGEST run among its lanes). */
+                s.sr = ((s.sr << 1) | level) & syncm;
                 if (emit) {
-                    uint32_t mark = (s.state & 2u) ? 4u : 0u;                            /* reset marker travels with the first chip */
-                    for (uint32_t i = 0; i < n_emit; i++) {
-                        s.sr = ((s.sr << 1) | level) & syncm;
-                        const uint32_t val = level | (s.sr == syncw ? 2u : 0u) | mark;
-                        mark = 0u;
-                        saw_sync |= val & 2u;
-                        my_chip[pend] = WM_CHIP_WORD(m + k - mb, val);
-                        if (++pend == 16u) flush8();         /* a long run can emit many chips at one edge */
+                    const uint32_t word = WM_CHIP_WORD(m + k - mb, level);
+                    const uint32_t hit = s.sr == syncw ? 2u : 0u;
+                    saw_sync |= hit;
+                    my_chip[pend] = word | hit | ((s.state & 2u) << 1);                      /* reset marker travels with the first chip */
+                    if (++pend == 16u) flush8();             /* a long run can emit many chips at one edge */
+                    for (uint32_t i = 1; i < n_emit; i++) {
+                        my_chip[pend] = word;
+                        if (++pend == 16u) flush8();
                     }
-                    if ((uint32_t)n > n_emit) s.sr = level ? syncm : 0u;
-                } else {                                     /* look-back: only the shift register matters */
-                    const uint32_t sh = n_emit < 24u ? n_emit : 24u;
-                    s.sr = ((s.sr << sh) | (level ? (1u << sh) - 1u : 0u)) & syncm;
                 }
+                const uint32_t sh = n_emit - 1u < 24u ? n_emit - 1u : 24u;                   /* n >= 1 */
+                s.sr = ((s.sr << sh) | (level ? (1u << sh) - 1u : 0u)) & syncm;
                 s.state &= ~2u;
                 const int rest = runq - n * unit;            /* what the count-down leaves: (half - unit, half] */
                 if (!s1) {
