@@ -77,8 +77,8 @@ struct RlaLds { uint32_t chip[64 * WM_RLA_WPB * WM_RLA_CROW]; };     /* lane-pri
  * each kind of launch has its own kernel (the main pass then carries no list walk: 78 instead of 97 VGPRs). */
 /* One segment of one (chain, capture).  A re-run starts from the predecessor's recorded end state (the carried state for
  * segment 0) and leaves its own in st_final. */
-template <int PASS>
-__device__ __forceinline__ void rla_segment(const K2Args &a, RlaLds &lds, const bool rerun, const uint32_t ch, const uint32_t stream, const uint32_t seg)
+template <int PASS, bool s1>
+__device__ __forceinline__ void rla_segment_of(const K2Args &a, RlaLds &lds, const bool rerun, const uint32_t ch, const uint32_t stream, const uint32_t seg)
 {
     uint32_t *s_chip = lds.chip;
     const WmPush &g = a.g;
@@ -97,7 +97,6 @@ __device__ __forceinline__ void rla_segment(const K2Args &a, RlaLds &lds, const 
 
     const uint32_t *bw = a.bits + row * (g.Mcap / 32);
     uint32_t *out = a.chips + sidx * cap_rl;
-    const bool s1 = ch != 0;
     const uint32_t syncw = s1 ? WM_SYNC_S1 : WM_SYNC_T1C1, syncm = s1 ? WM_SYNC_S1_MASK : WM_SYNC_T1C1_MASK;
     const uint32_t hist_mask = s1 ? 0x1Cu : 0x1Fu;       /* S1 looks back 3 samples, T1/C1 5      */
 
@@ -243,6 +242,16 @@ __device__ __forceinline__ void rla_segment(const K2Args &a, RlaLds &lds, const 
     a.counts[sidx] = n_stored < n_out ? n_stored : n_out;        /* chips that can be read back */
     if (saw_sync) a.sync_seen[sidx] = 1u;
     if (n_stored < n_out) atomicOr(a.err, WM_ERR_CHIP_TRUNC);     /* a warning: the framer state is exact, some chips of this segment are lost */
+}
+
+/* The chain is a compile-time constant inside the segment (a wave of the first pass holds one chain; as a per-lane value every
+ * `if (s1)` of the edge loop was a masked if/else -- seven scalar instructions each, three per edge -- and the access code, its
+ * mask and the history mask were registers). */
+template <int PASS>
+__device__ __forceinline__ void rla_segment(const K2Args &a, RlaLds &lds, const bool rerun, const uint32_t ch, const uint32_t stream, const uint32_t seg)
+{
+    if (ch) rla_segment_of<PASS, true>(a, lds, rerun, ch, stream, seg);
+    else rla_segment_of<PASS, false>(a, lds, rerun, ch, stream, seg);
 }
 
 /* The lanes of one launch.  First pass: lane = (chain, segment, capture), every lane one segment.
