@@ -31,6 +31,14 @@ __device__ __forceinline__ int wm_sdiv(int a, int b)                          /*
     return a < 0 ? -(int)q : (int)q;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define WM_WAVE_ANY(c) (__builtin_amdgcn_ballot_w64(c) != 0ull)    /* over the lanes active here */
+#else
+#define WM_WAVE_ANY(c) (c)                                         /* host emulation: lane by lane; only the moment of a flush depends on it */
+#endif
+#ifndef WM_RLA_TRIP_HOOK
+#define WM_RLA_TRIP_HOOK(stream, sample)                           /* host measurements (tests/emu) count a lane's edge trips per step */
+#endif
 #define WM_RLA_CROW 17           /* words per lane in the run-length kernel's chip staging (16 + 1: conflict-free) */
 /* Deglitch filter for a whole 32-sample block, bit-parallel.  W holds raw slicer bits in time
  * order: bit 5+k = sample k of the block, bits 0..4 = the five samples before it.
@@ -71,7 +79,10 @@ __device__ __forceinline__ uint32_t deglitch_word(uint32_t W, bool s1)
  * the lane only iterates over the EDGES of the deglitched signal.  A framer reset clears the raw
  * history (rtl_wmbus.c:632,723), so after one the remaining levels of the block are recomputed
  * from the masked history.  WmRlaState.raw keeps the last five raw bits in time order. */
-struct RlaLds { uint32_t chip[64 * WM_RLA_WPB * WM_RLA_CROW]; };     /* lane-private staging; the block's waves are independent */
+struct RlaLds {                  /* lane-private; the block's waves are independent */
+    uint64_t dw[3 * 64 * WM_RLA_WPB];                /* deglitched words 1-3 of the 256-sample step, [word][lane] */
+    uint32_t chip[64 * WM_RLA_WPB * WM_RLA_CROW];    /* chip staging */
+};
 
 /* PASS: 0 = first pass only (a.list == nullptr), 1 = re-run list only, 2 = either (the fused launch): like the clock kernel,
  * each kind of launch has its own kernel (the main pass then carries no list walk: 78 instead of 97 VGPRs). */
@@ -93,7 +104,7 @@ __device__ __forceinline__ void rla_segment_of(const K2Args &a, RlaLds &lds, con
     uint32_t m;
     if (rerun) { s = seg ? stF[sidx - 1] : stC[row]; m = mb; }
     else if (mb <= g.lookback) { s = stC[row]; m = 0; }
-    else { s = reset; m = (mb - g.lookback) & ~63u; }     /* whole 64-sample steps (segments are multiples of 1024) */
+    else { s = reset; m = (mb - g.lookback) & ~255u; }    /* whole 256-sample steps (segments are multiples of 1024) */
 
     const uint32_t *bw = a.bits + row * (g.Mcap / 32);
     uint32_t *out = a.chips + sidx * cap_rl;
@@ -148,29 +159,54 @@ __device__ __forceinline__ void rla_segment_of(const K2Args &a, RlaLds &lds, con
         if (gq * 256u < g.Mcap) { nq0 = *(const uint4 *)(bw + 8u * gq); nq1 = *(const uint4 *)(bw + 8u * gq + 4); }
     };
     fetch_group(grp + 1u);
-    /* One step = 64 samples (two slicer words).  The wave walks its 64 lanes' edges in lock step, so a
-     * step costs the wave the LARGEST edge count among its lanes; over 64 samples that maximum is
-     * relatively smaller than over 32 (T1/C1 on the bench workload, measured on the host emulation with 64
-     * captures as the lanes: 8.4 edges per 64 samples on average, 18.9 for the unluckiest of 64 lanes). */
+    /* One step = 256 samples = one group of slicer words.  The wave walks its 64 lanes' edges in lock step, so a step costs
+     * the wave the LARGEST edge count among its lanes, and that maximum is relatively smaller the longer the step: on the
+     * bench workload (tools/rla_trips.py: the device source on the host, 64 captures as the 64 lanes) a T1/C1 lane has 7.5
+     * edges per 64 samples on average, and the unluckiest of 64 lanes 18.1 per 64-sample step (round 3), 14.8 per 64 samples
+     * of a 128-sample step, 12.6 of a 256-sample step (S1 chain: 2.8 on average; 6.0, 5.4, 5.0).  The step's four 64-bit words are deglitched in lock step up
+     * front (words 1-3 wait in LDS); a lane that runs out of edges in its word takes the next one inside the same trip.  The
+     * first five levels of a word look at raw history of the word before, which a framer reset in that word has cleared
+     * (rtl_wmbus.c:632,723): they are redone at the hand-over from the history as it then is. */
+    uint64_t *my_dw = lds.dw + threadIdx.x;                  /* word i of the step at my_dw[(i - 1) * lanes per block] */
     auto block = [&](const bool emit) {
-        const uint32_t sub = (m >> 6) & 3u;                  /* word pair within the group of 8 */
+        const uint32_t kstep = min(256u, me - m);            /* ragged only at the end of the push */
         const uint32_t lo4[4] = {wq0.x, wq0.z, wq1.x, wq1.z}, hi4[4] = {wq0.y, wq0.w, wq1.y, wq1.w};
-        uint32_t w_lo = lo4[0], w_hi = hi4[0];
+        uint64_t Rw[4];
 #pragma unroll
-        for (int i = 1; i < 4; i++) { w_lo = sub == (uint32_t)i ? lo4[i] : w_lo; w_hi = sub == (uint32_t)i ? hi4[i] : w_hi; }
-        const uint32_t kend = min(64u, me - m);
-        const uint64_t valid = kend == 64u ? ~0ull : ((1ull << kend) - 1ull);
-        uint64_t R = (((uint64_t)w_hi << 32) | w_lo) & valid;    /* raw slicer bits, bit j = sample j of the step */
-        uint32_t hist = s.raw & hist_mask;                   /* the five samples before it, bit 4 = newest */
-        uint64_t D = (uint64_t)deglitch_block(((uint64_t)(uint32_t)R << 5) | hist, s1) |
-                     ((uint64_t)deglitch_block(((R >> 32) << 5) | ((uint32_t)R >> 27), s1) << 32);
-        uint32_t k0 = 0;
-        while (k0 < kend) {
+        for (int i = 0; i < 4; i++) {
+            const uint32_t n = kstep > 64u * i ? min(64u, kstep - 64u * i) : 0u;
+            Rw[i] = (((uint64_t)hi4[i] << 32) | lo4[i]) & (n == 64u ? ~0ull : ((1ull << n) - 1ull));   /* raw slicer bits, bit j = sample j of the word */
+        }
+        auto deglitch64 = [&](const uint64_t r, const uint32_t h) {
+            return (uint64_t)deglitch_block(((uint64_t)(uint32_t)r << 5) | h, s1) | ((uint64_t)deglitch_block(((r >> 32) << 5) | ((uint32_t)r >> 27), s1) << 32);
+        };
+        uint32_t hist = s.raw & hist_mask;                   /* the five samples before the word, bit 4 = newest */
+        uint64_t R = Rw[0], D = deglitch64(R, hist);
+#pragma unroll
+        for (int i = 1; i < 4; i++) my_dw[(i - 1) * (64 * WM_RLA_WPB)] = deglitch64(Rw[i], 0u);
+        uint32_t w = 0, k0 = 0, kend = min(64u, kstep);
+        uint32_t pos = m - mb;                               /* sample 0 of the word, relative to the segment (look-back: unused) */
+        for (;;) {
             const uint32_t level = s.state & 1u;
-            const uint64_t x = (level ? ~D : D) & valid & (~0ull << k0);
-            if (!x) { s.run += (int)(kend - k0); break; }
+            uint64_t valid = kend == 64u ? ~0ull : ((1ull << kend) - 1ull);
+            uint64_t x = k0 < kend ? (level ? ~D : D) & valid & (~0ull << k0) : 0ull;
+            bool more = true;
+            while (!x) {                                     /* no edge left in this word: on into the next one */
+                s.run += (int)(kend - k0);
+                if (64u * (w + 1u) >= kstep) { more = false; break; }
+                hist = (uint32_t)(R >> 59) & hist_mask;      /* a whole word lies behind (only the last one can be ragged) */
+                w++;
+                R = w == 1u ? Rw[1] : w == 2u ? Rw[2] : Rw[3];
+                D = my_dw[(w - 1u) * (64 * WM_RLA_WPB)];
+                D = (D & ~0x1Full) | (deglitch_word((((uint32_t)R & 0x1Fu) << 5) | hist, s1) & 0x1Fu);
+                kend = min(64u, kstep - 64u * w); k0 = 0; pos += 64u;
+                valid = kend == 64u ? ~0ull : ((1ull << kend) - 1ull);
+                x = (level ? ~D : D) & valid;
+            }
+            if (!more) break;
             const uint32_t k = (uint32_t)__ffsll((long long)x) - 1u;  /* first sample whose level differs */
             s.run += (int)(k - k0);
+            WM_RLA_TRIP_HOOK(stream, m + 64u * w);
             /* Everything below is written for a wave whose 64 lanes take DIFFERENT paths at almost every
              * edge (a path one lane in fifty takes is taken by the wave nearly every time): no
              * data-dependent loop for the common cases, and the rare ones kept short. */
@@ -201,7 +237,7 @@ __device__ __forceinline__ void rla_segment_of(const K2Args &a, RlaLds &lds, con
                  * the shift register takes them in one shift (what the wave pays per edge is the LONGEST run among its lanes). */
                 s.sr = ((s.sr << 1) | level) & syncm;
                 if (emit) {
-                    const uint32_t word = WM_CHIP_WORD(m + k - mb, level);
+                    const uint32_t word = WM_CHIP_WORD(pos + k, level);
                     const uint32_t hit = s.sr == syncw ? 2u : 0u;
                     saw_sync |= hit;
                     my_chip[pend] = word | hit | ((s.state & 2u) << 1);                      /* reset marker travels with the first chip */
@@ -210,6 +246,10 @@ __device__ __forceinline__ void rla_segment_of(const K2Args &a, RlaLds &lds, con
                         my_chip[pend] = word;
                         if (++pend == 16u) flush8();
                     }
+                    /* chips leave at the end of a step, all lanes together; a 256-sample step fills the 16 staged words several
+                     * times over, and lanes flushing one by one would put the flush into nearly every trip of the wave:
+                     * when one lane is about to run full, every lane that has a whole group sends it */
+                    if (WM_WAVE_ANY(pend >= 12u) && pend >= 8u) flush8();
                 }
                 const uint32_t sh = n_emit - 1u < 24u ? n_emit - 1u : 24u;                   /* n >= 1 */
                 s.sr = ((s.sr << sh) | (level ? (1u << sh) - 1u : 0u)) & syncm;
@@ -227,11 +267,11 @@ __device__ __forceinline__ void rla_segment_of(const K2Args &a, RlaLds &lds, con
             s.run = 1;
             k0 = k + 1u;
         }
-        /* the five newest raw bits, time order (a ragged last step may be shorter than five samples) */
+        /* the five newest raw bits, time order (a ragged last word may be shorter than five samples) */
         s.raw = (kend >= 5u ? (uint32_t)(R >> (kend - 5u)) : (((uint32_t)R << (5u - kend)) | (hist >> kend))) & 0x1Fu & hist_mask;
-        if (sub == 3u) { wq0 = nq0; wq1 = nq1; grp++; fetch_group(grp + 1u); }
+        wq0 = nq0; wq1 = nq1; grp++; fetch_group(grp + 1u);
         if (emit && pend >= 8u) flush8();
-        m += 64;
+        m += 256;
     };
     while (m < mb) block(false);                         /* speculative look-back: no stores at all */
     stS[sidx] = s;

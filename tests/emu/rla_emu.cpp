@@ -27,6 +27,10 @@ static inline uint32_t atomicOr(uint32_t *p, uint32_t v) { const uint32_t o = *p
 static inline uint32_t atomicAdd(uint32_t *p, uint32_t v) { const uint32_t o = *p; *p += v; return o; }
 using std::min;
 
+/* measurements (tools/rla_trips.py): edge trips of the first pass per (row, 64 samples) */
+extern "C" { uint32_t *wm_emu_trip_tab = nullptr; uint32_t wm_emu_trip_words = 0; }
+#define WM_RLA_TRIP_HOOK(stream, sample) do { if (wm_emu_trip_tab && !rerun && (sample) >= mb) wm_emu_trip_tab[(size_t)row * wm_emu_trip_words + ((sample) >> 6)]++; } while (0)
+
 #include "wm_dev.h"
 #include "wm_k2_common.h"
 #include "wm_k2_rla.h"
