@@ -82,7 +82,13 @@ __device__ __forceinline__ uint32_t deglitch_word(uint32_t W, bool s1)
 struct RlaLds {                  /* lane-private; the block's waves are independent */
     uint64_t dw[3 * 64 * WM_RLA_WPB];                /* deglitched words 1-3 of the 256-sample step, [word][lane] */
     uint32_t chip[64 * WM_RLA_WPB * WM_RLA_CROW];    /* chip staging */
+    uint8_t lut[2][1024];                            /* [S1][new five raw bits << 5 | the five before] -> the five levels (deglitch_word) */
 };
+/* by all threads of the block before its first lane runs, a barrier behind it */
+__device__ __forceinline__ void rla_lds_init(RlaLds &lds, const uint32_t tid, const uint32_t nthreads)
+{
+    for (uint32_t i = tid; i < 2048u; i += nthreads) lds.lut[i >> 10][i & 1023u] = (uint8_t)(deglitch_word(i & 1023u, i >= 1024u) & 0x1Fu);
+}
 
 /* PASS: 0 = first pass only (a.list == nullptr), 1 = re-run list only, 2 = either (the fused launch): like the clock kernel,
  * each kind of launch has its own kernel (the main pass then carries no list walk: 78 instead of 97 VGPRs). */
@@ -167,6 +173,7 @@ __device__ __forceinline__ void rla_segment_of(const K2Args &a, RlaLds &lds, con
      * front (words 1-3 wait in LDS); a lane that runs out of edges in its word takes the next one inside the same trip.  The
      * first five levels of a word look at raw history of the word before, which a framer reset in that word has cleared
      * (rtl_wmbus.c:632,723): they are redone at the hand-over from the history as it then is. */
+    const uint8_t *lut = lds.lut[s1 ? 1 : 0];               /* levels of five samples from those and the five before (rla_lds_init) */
     uint64_t *my_dw = lds.dw + threadIdx.x;                  /* word i of the step at my_dw[(i - 1) * lanes per block] */
     auto block = [&](const bool emit) {
         const uint32_t kstep = min(256u, me - m);            /* ragged only at the end of the push */
@@ -186,11 +193,14 @@ __device__ __forceinline__ void rla_segment_of(const K2Args &a, RlaLds &lds, con
         for (int i = 1; i < 4; i++) my_dw[(i - 1) * (64 * WM_RLA_WPB)] = deglitch64(Rw[i], 0u);
         uint32_t w = 0, k0 = 0, kend = min(64u, kstep);
         uint32_t pos = m - mb;                               /* sample 0 of the word, relative to the segment (look-back: unused) */
+        uint64_t rem = kend == 64u ? ~0ull : ((1ull << kend) - 1ull);     /* samples of the word still to look at */
         for (;;) {
             const uint32_t level = s.state & 1u;
-            uint64_t valid = kend == 64u ? ~0ull : ((1ull << kend) - 1ull);
-            uint64_t x = k0 < kend ? (level ? ~D : D) & valid & (~0ull << k0) : 0ull;
+            uint64_t x = (level ? ~D : D) & rem;
             bool more = true;
+            /* The hand-over is in nearly every trip of the wave (64 lanes, three each per step, spread over fifty trips), so
+             * it is kept to a few instructions: the deglitched word from LDS, the raw one picked from registers, the first
+             * five levels from the table. */
             while (!x) {                                     /* no edge left in this word: on into the next one */
                 s.run += (int)(kend - k0);
                 if (64u * (w + 1u) >= kstep) { more = false; break; }
@@ -198,10 +208,10 @@ __device__ __forceinline__ void rla_segment_of(const K2Args &a, RlaLds &lds, con
                 w++;
                 R = w == 1u ? Rw[1] : w == 2u ? Rw[2] : Rw[3];
                 D = my_dw[(w - 1u) * (64 * WM_RLA_WPB)];
-                D = (D & ~0x1Full) | (deglitch_word((((uint32_t)R & 0x1Fu) << 5) | hist, s1) & 0x1Fu);
+                D = (D & ~0x1Full) | lut[(((uint32_t)R & 0x1Fu) << 5) | hist];
                 kend = min(64u, kstep - 64u * w); k0 = 0; pos += 64u;
-                valid = kend == 64u ? ~0ull : ((1ull << kend) - 1ull);
-                x = (level ? ~D : D) & valid;
+                rem = kend == 64u ? ~0ull : ((1ull << kend) - 1ull);
+                x = (level ? ~D : D) & rem;
             }
             if (!more) break;
             const uint32_t k = (uint32_t)__ffsll((long long)x) - 1u;  /* first sample whose level differs */
@@ -222,7 +232,7 @@ __device__ __forceinline__ void rla_segment_of(const K2Args &a, RlaLds &lds, con
                  * deglitching the whole step again (shifts by k + 1 <= 64 in two parts) */
                 const uint32_t v5 = (uint32_t)((R >> k) >> 1) & 0x1Fu;                  /* raw samples k+1 .. k+5 */
                 const uint64_t pm = (0x1Full << k) << 1;
-                D = (D & ~pm) | (((uint64_t)(deglitch_word(v5 << 5, s1) & 0x1Fu) << k) << 1);
+                D = (D & ~pm) | (((uint64_t)lut[v5 << 5] << k) << 1);
             } else {
                 /* chips of this run: the reference counts the run down chip by chip (:765-779 / :680-694),
                  * i.e. n = ceil((run - half) / unit) >= 1 */
@@ -266,6 +276,7 @@ __device__ __forceinline__ void rla_segment_of(const K2Args &a, RlaLds &lds, con
             s.state = (s.state & 2u) | (level ^ 1u);
             s.run = 1;
             k0 = k + 1u;
+            rem &= ~1ull << k;                               /* k = 63: nothing left */
         }
         /* the five newest raw bits, time order (a ragged last word may be shorter than five samples) */
         s.raw = (kend >= 5u ? (uint32_t)(R >> (kend - 5u)) : (((uint32_t)R << (5u - kend)) | (hist >> kend))) & 0x1Fu & hist_mask;
@@ -342,6 +353,8 @@ __global__ __launch_bounds__(64 * WM_RLA_WPB, WM_RLA_WAVES_PER_SIMD) void k2_rla
 {
     wm_framer_prio();
     __shared__ RlaLds lds;
+    rla_lds_init(lds, threadIdx.x, 64 * WM_RLA_WPB);
+    __syncthreads();
     rla_lanes<0>(a, blockIdx.x, lds);
 }
 
@@ -349,6 +362,8 @@ __global__ __launch_bounds__(64 * WM_RLA_WPB, WM_RLA_WAVES_PER_SIMD) void k2_rla
 {
     wm_framer_prio();
     __shared__ RlaLds lds;
+    rla_lds_init(lds, threadIdx.x, 64 * WM_RLA_WPB);
+    __syncthreads();
     const uint32_t n = k2_lane_count(a);
     for (uint32_t b = blockIdx.x; (uint64_t)b * (64u * WM_RLA_WPB) < n; b += gridDim.x) rla_lanes<1>(a, b, lds);
 }

@@ -61,6 +61,8 @@ __global__ __launch_bounds__(64 * WM_RLA_WPB, WM_FUSED_WAVES_PER_SIMD) void k2_c
         const uint32_t n = k2_lane_count(clk);
         for (uint32_t b = blockIdx.x; (uint64_t)b * 64u < n; b += clk_blocks) clock_lanes<false, 1, WM_FUSED_LEAN_CLOCK != 0, 1>(clk, b, lds.c);
     } else {
+        rla_lds_init(lds.r, threadIdx.x, 64 * WM_RLA_WPB);     /* the whole block is on this side */
+        __syncthreads();
         const uint32_t n = k2_lane_count(rla), nb = gridDim.x - clk_blocks;
         for (uint32_t b = blockIdx.x - clk_blocks; (uint64_t)b * (64u * WM_RLA_WPB) < n; b += nb) rla_lanes(rla, b, lds.r);
     }

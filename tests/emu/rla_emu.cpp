@@ -20,6 +20,7 @@ struct uint4 { uint32_t x, y, z, w; };
 static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
 struct Idx3 { uint32_t x, y, z; };
 static Idx3 threadIdx, blockIdx, gridDim;
+static inline void __syncthreads(void) {}                           /* the kernels themselves are not run here (lanes one by one) */
 static inline int __ffs(int v) { return __builtin_ffs(v); }
 static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 static inline float __frcp_rn(float x) { return 1.0f / x; }          /* correctly rounded on both sides */
@@ -73,6 +74,7 @@ long wm_emu_rla(const uint32_t *bits, uint32_t S, uint32_t M, uint32_t Mcap, uin
     a.algo = 0; a.err = &err; a.sync_seen = seen.data();
     a.bad = wm_emu_chains ? bad.data() : nullptr;
     static RlaLds lds;
+    rla_lds_init(lds, 0, 1);
     const uint32_t B = 64 * WM_RLA_WPB;
     auto launch = [&](const uint32_t *lst, uint32_t n) {
         a.list = lst; a.n_lanes = n;
