@@ -188,6 +188,7 @@ class Batch:
 
     def __init__(self, n_streams, contexts=0, **kw):
         L = lib()
+        kw.setdefault("keep_taps", False)                   # the product's configuration (the CLI's): no debug views, RSSI on demand
         self.cfg = _make_cfg(n_streams=n_streams, **kw)
         self.n_streams = n_streams
         self._h = ctypes.c_void_p()

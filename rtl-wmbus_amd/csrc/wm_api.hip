@@ -149,6 +149,13 @@ struct wmbus_ctx {
     unsigned rla_fin = 3;                               /* this push: index of the run-length framer's last (unattended) verification */
     bool poisoned = false, gpu_decode = true;                              /* an internal error left the carried state undefined */
     uint32_t *d_first_bad = nullptr;                    /* [2][S] first uncertified EMA tile of a row, or ~0 */
+    /* RSSI on demand (wm_k1_demod.h): the first pass leaves the RSSI out, k3_spans lists the tiles whose RSSI is read, an
+     * RS = 2 launch computes those.  Off for contexts with debug taps (they show every sample's RSSI) and for the option
+     * kernels; WMBUS_RSSI_FULL=1 turns it off for A/Bs. */
+    bool rs_od = false, rs_full_now = false;            /* rs_full_now: this push has fallen back to the full pass */
+    bool rs_this = false;                               /* this push runs on demand (a context whose bursts cover most of its tiles takes the full pass for a while) */
+    unsigned rs_pause = 0;                              /* pushes left before on demand is tried again */
+    uint32_t *d_rs_flags = nullptr, *d_rs_list = nullptr;   /* [ntiles_cap][S] chains read per (tile, capture); the tiles listed */
     uint32_t *d_ckpt = nullptr; uint32_t nck = 0;       /* clock kernel checkpoints [2][S][nseg_cap][nck][16] */
     uint32_t *d_bad = nullptr;                          /* [2][nseg_cap[0]][S] the run-length verifier's verdict per segment (K2Args.bad) */
     uint32_t *d_bad_clk = nullptr;                      /* [2][nseg_cap[1]][S] the clock verifier's */
@@ -210,6 +217,7 @@ enum { WM_MAX_ROUNDS = 6 };                     /* counters per kind: rounds + 1
  * that every hand-off failure is finished by the host-driven path */
 static const bool opt_rounds = !(getenv("WMBUS_OPT_ROUNDS") && atoi(getenv("WMBUS_OPT_ROUNDS")) == 0);
 enum { SC_ERR = 0, SC_NHITS = 1, SC_NHDR = 2, SC_NWORDS = 3, SC_NPKTS = 4, SC_NBYTES = 5, SC_SLOW = 6, SC_CHIPS = 8 /* [algo][chain] */,
+       SC_RS_N = 12 /* tiles listed for the RSSI-on-demand launch */, SC_RS_FAIL = 13 /* a lane that is read could not prove its value */,
        SC_EMA = 16 /* [ema_rounds + 1] */, SC_CLK = 24 /* [fr_rounds + 1] */, SC_RLA = 32 /* [rla_rounds + 1] */, SC_COUNT = 40 };
 
 /* 4096 bytes per capture from src + row * sstride + soff to dst + row * dstride (256 threads x 16 bytes).  The input
@@ -258,23 +266,26 @@ __global__ __launch_bounds__(256) void k_sum_counts(WmPush g, const uint32_t *co
     }
 }
 
-template <int D, bool SHIFT, bool GEN, bool FAST = false> int launch_k1v3(wmbus_ctx *c, const K1Args &a, dim3 grid, hipStream_t st)
+template <int D, bool SHIFT, bool GEN, bool FAST = false, int RS = 0> int launch_k1v3(wmbus_ctx *c, const K1Args &a, dim3 grid, hipStream_t st)
 {
     const size_t sm = K1Geo::smem(D ? D : (int)c->d, SHIFT);
     static std::atomic<size_t> set_for[WM_MAX_DEVICES];     /* per device: the attribute call is not free, a push makes several launches */
     if (set_for[c->cfg.device] < sm) {
-        HIPCHK(c, hipFuncSetAttribute((const void *)k1_demod2<D, SHIFT, GEN, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+        HIPCHK(c, hipFuncSetAttribute((const void *)k1_demod2<D, SHIFT, GEN, FAST, RS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
         set_for[c->cfg.device] = sm;
     }
-    hipLaunchKernelGGL((k1_demod2<D, SHIFT, GEN, FAST>), grid, dim3(256), sm, st, a);
+    hipLaunchKernelGGL((k1_demod2<D, SHIFT, GEN, FAST, RS>), grid, dim3(256), sm, st, a);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
 
 /* the default switches' first pass runs the kernel without the option paths (k1_demod2<.., GEN = false>) */
-template <int D, bool SHIFT> int launch_k1v2(wmbus_ctx *c, const K1Args &a, dim3 grid, hipStream_t st)
+template <int D, bool SHIFT> int launch_k1v2(wmbus_ctx *c, const K1Args &a, dim3 grid, hipStream_t st, int rs)
 {
     const uint32_t need = WM_F_ACCURATE | WM_F_T1C1 | WM_F_S1, never = WM_F_APPROX1 | WM_F_APPROX2;
+    if (D != 0 && rs == 1)                       /* RSSI on demand (wmbus_open has checked the switches): the first pass without it */
+        return c->cfg.tolerance_mode ? launch_k1v3<D, SHIFT, false, true, 1>(c, a, grid, st) : launch_k1v3<D, SHIFT, false, false, 1>(c, a, grid, st);
+    if (D != 0 && rs == 2) return launch_k1v3<D, SHIFT, false, false, 2>(c, a, grid, st);     /* ... and the listed tiles' RSSI (the same in tolerance mode) */
     if (D != 0 && a.relist == nullptr && (c->flags & need) == need && !(c->flags & never))
         /* tolerance mode (an option of the default switches' kernel only; everything else stays exact) */
         return c->cfg.tolerance_mode ? launch_k1v3<D, SHIFT, false, true>(c, a, grid, st) : launch_k1v3<D, SHIFT, false>(c, a, grid, st);
@@ -371,7 +382,7 @@ void wmbus_close(wmbus_ctx *c)
         std::lock_guard<std::mutex> lk(kc.m);
         if (kc.owner == c) { kc.last = nullptr; kc.owner = nullptr; }      /* nobody may wait on an event that is about to go */
     }
-    void *dev[] = {c->d_bad, c->d_bad_clk, c->d_hist, c->d_list_ema, c->d_spill, c->d_chain, c->d_list2, c->d_first_bad, c->d_ckpt, c->d_in, c->d_dphi, c->d_rssi, c->d_bits, c->d_lut, c->d_ema_head, c->d_ema_tail, c->d_ema_carry,
+    void *dev[] = {c->d_rs_flags, c->d_rs_list, c->d_bad, c->d_bad_clk, c->d_hist, c->d_list_ema, c->d_spill, c->d_chain, c->d_list2, c->d_first_bad, c->d_ckpt, c->d_in, c->d_dphi, c->d_rssi, c->d_bits, c->d_lut, c->d_ema_head, c->d_ema_tail, c->d_ema_carry,
                    c->d_chips[0], c->d_chips[1], c->d_counts[0], c->d_counts[1], c->d_st_start[0], c->d_st_start[1],
                    c->d_st_final[0], c->d_st_final[1], c->d_st_carry[0], c->d_st_carry[1], c->d_list, c->d_scalars,
                    c->d_hits, c->d_pending};
@@ -493,6 +504,13 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
     A(dalloc(&c->d_ema_tail, (size_t)rows * c->ntiles_cap));
     A(dalloc(&c->d_ema_carry, (size_t)2 * rows));
     A(dalloc(&c->d_first_bad, (size_t)rows));
+    {
+        const uint32_t need = WM_F_ACCURATE | WM_F_T1C1 | WM_F_S1, never = WM_F_APPROX1 | WM_F_APPROX2;
+        static const bool rs_full = getenv("WMBUS_RSSI_FULL") && atoi(getenv("WMBUS_RSSI_FULL")) != 0;
+        c->rs_od = !rs_full && !cfg->keep_taps && cfg->prefilter != WMBUS_PREFILTER_POLYPHASE && c->d >= 2 && c->d <= 5 &&
+                   (c->flags & need) == need && !(c->flags & never);
+        if (c->rs_od) { A(dalloc(&c->d_rs_flags, (size_t)c->ntiles_cap * c->S)); A(dalloc(&c->d_rs_list, (size_t)c->ntiles_cap * c->S)); }
+    }
     const size_t stw[2] = {sizeof(WmRlaState), sizeof(WmClkState)};
     for (int a = 0; a < 2; a++) {
         A(dalloc(&c->d_chips[a], (size_t)rows * c->nseg_cap[a] * c->cap[a]));
@@ -642,16 +660,16 @@ static void *st_carry(wmbus_ctx *c, int algo, bool out)
     return (char *)c->d_st_carry[algo] + (size_t)(c->carry_in ^ (out ? 1u : 0u)) * 2 * c->S * w;
 }
 
-static int launch_k1_any(wmbus_ctx *c, const K1Args &k1, dim3 grid, hipStream_t st = nullptr)
+static int launch_k1_any(wmbus_ctx *c, const K1Args &k1, dim3 grid, hipStream_t st = nullptr, int rs = 0)    /* rs: 0 everything, 1 no RSSI, 2 RSSI of the listed tiles */
 {
     const bool sh = c->flags & WM_F_SHIFT;
     if (!st) st = c->stream;
     if (c->cfg.prefilter == WMBUS_PREFILTER_POLYPHASE) return launch_k1_ppf(c, k1, grid, st);
-    if (c->d == 2) return sh ? launch_k1v2<2, true>(c, k1, grid, st) : launch_k1v2<2, false>(c, k1, grid, st);
-    if (c->d == 3) return sh ? launch_k1v2<3, true>(c, k1, grid, st) : launch_k1v2<3, false>(c, k1, grid, st);
-    if (c->d == 4) return sh ? launch_k1v2<4, true>(c, k1, grid, st) : launch_k1v2<4, false>(c, k1, grid, st);
-    if (c->d == 5) return sh ? launch_k1v2<5, true>(c, k1, grid, st) : launch_k1v2<5, false>(c, k1, grid, st);
-    return sh ? launch_k1v2<0, true>(c, k1, grid, st) : launch_k1v2<0, false>(c, k1, grid, st);      /* any other rate */
+    if (c->d == 2) return sh ? launch_k1v2<2, true>(c, k1, grid, st, rs) : launch_k1v2<2, false>(c, k1, grid, st, rs);
+    if (c->d == 3) return sh ? launch_k1v2<3, true>(c, k1, grid, st, rs) : launch_k1v2<3, false>(c, k1, grid, st, rs);
+    if (c->d == 4) return sh ? launch_k1v2<4, true>(c, k1, grid, st, rs) : launch_k1v2<4, false>(c, k1, grid, st, rs);
+    if (c->d == 5) return sh ? launch_k1v2<5, true>(c, k1, grid, st, rs) : launch_k1v2<5, false>(c, k1, grid, st, rs);
+    return sh ? launch_k1v2<0, true>(c, k1, grid, st, rs) : launch_k1v2<0, false>(c, k1, grid, st, rs);      /* any other rate */
 }
 
 /* EMA hand-offs between tiles (k1_verify), the first uncertified tile of every row into the repair list (k1_collect),
@@ -748,7 +766,7 @@ static int launch_k3(wmbus_ctx *c, bool again)
     const WmPush &g = c->last;
     if (again) {                                             /* collect's slow path: the counters of the first attempt go */
         HIPCHK(c, hipMemsetAsync(c->d_scalars + SC_NHITS, 0, 5 * sizeof(uint32_t), c->stream));          /* NHITS .. NBYTES */
-        HIPCHK(c, hipMemsetAsync(c->d_scalars + SC_CHIPS, 0, 4 * sizeof(uint32_t), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_scalars + SC_CHIPS, 0, 6 * sizeof(uint32_t), c->stream));          /* CHIPS, RS_N, RS_FAIL */
         /* ... and so does its burst-storage warning (chips dropped by the framers stay dropped: that bit is kept) */
         hipLaunchKernelGGL(k_and_word, dim3(1), dim3(1), 0, c->stream, c->d_scalars + SC_ERR, ~(uint32_t)WM_ERR_BURST_OVERFLOW);
     }
@@ -766,6 +784,19 @@ static int launch_k3(wmbus_ctx *c, bool again)
     if (c->gpu_decode) {
         k3.pkts = (WmPkt *)c->dv_pkts; k3.pkts_cap = c->pkts_cap; k3.bytes = (uint8_t *)c->dv_bytes; k3.bytes_cap = c->bytes_cap;
         k3.n_pkts = c->d_scalars + SC_NPKTS; k3.n_bytes = c->d_scalars + SC_NBYTES;
+    }
+    if (c->rs_this && !c->rs_full_now) {
+        /* RSSI on demand: which tiles do the bursts touch (k3_spans), then their RSSI (an RS = 2 launch of the demodulation
+         * kernel over the list, a fixed grid), then the bursts */
+        HIPCHK(c, hipMemsetAsync(c->d_rs_flags, 0, (size_t)c->ntiles * c->S * sizeof(uint32_t), c->stream));
+        static const uint32_t span_blocks = getenv("WMBUS_K3_BLOCKS") ? (uint32_t)atoi(getenv("WMBUS_K3_BLOCKS")) : 64u;
+        hipLaunchKernelGGL(k3_spans, dim3(std::max(1u, std::min((4 * c->S + c->hits_cap + 3u) / 4u, span_blocks))), dim3(256), 0, c->stream, k3, c->T, c->ntiles,
+                           c->d_rs_flags, c->d_rs_list, c->d_scalars + SC_RS_N);
+        K1Args k1 = c->k1a;
+        k1.relist = c->d_rs_list; k1.n_relist = c->d_scalars + SC_RS_N;
+        static const uint32_t rs_blocks = getenv("WMBUS_RS_BLOCKS") ? (uint32_t)atoi(getenv("WMBUS_RS_BLOCKS")) : 2048u;
+        const int rc = launch_k1_any(c, k1, dim3(std::max(1u, std::min(rs_blocks, c->ntiles * c->S)), 1), nullptr, 2);
+        if (rc) return rc;
     }
     /* Few blocks: a latency-bound wave parked on a SIMD costs the demodulation kernel one of its eight wave slots there
      * for as long as it lives; 256 blocks put one on every SIMD of the chip (r02 sweep: 256 -> 64 blocks + 6 %, 16 blocks - 9 %: then the kernel itself becomes the longest link of the chain) */
@@ -817,8 +848,15 @@ static int enqueue_front_impl(wmbus_ctx *c, size_t nbytes)
         /* K1 */
         const uint32_t T = c->T, ntiles = (g.M + T - 1) / T;
         c->ntiles = ntiles;
+        /* on demand pays while the bursts touch a minority of the tiles (an RS = 2 tile costs a third of a full one, and the
+         * first pass saves a seventh): a context that has just listed more than WMBUS_RS_MAX per mille of them (configs[2]: S1
+         * telegrams of 30-100 ms in both chains) takes the full pass for the next sixteen pushes, then looks again
+         * (r04 visit: configs[2] lists 31 % of its tiles and loses 7 % on demand -- its front end, five input samples per decimated one
+         * through the -s rotation, is most of the kernel; the bench workload lists 11 % and gains 5-7 %) */
+        c->rs_this = c->rs_od && c->rs_pause == 0;
+        if (c->rs_pause) c->rs_pause--;
         c->k1a = K1Args{g, c->d_dphi, c->d_rssi, c->d_lut, c->d_lut + 32 * WM_MAX_DECIM, c->d_ema_head, c->d_ema_tail, ntiles, c->d_scalars + SC_ERR,
-                        nullptr, ema_carry(c, false), nullptr, 0u};
+                        nullptr, ema_carry(c, false), nullptr, 0u, c->d_rs_flags, ema_carry(c, true), c->d_scalars + SC_RS_FAIL};
         static const int turns = getenv("WMBUS_K1_TURNS") ? atoi(getenv("WMBUS_K1_TURNS")) : 1;      /* 0: no order (A/B) */
         static const int k1_shared = getenv("WMBUS_K1_STREAM") ? atoi(getenv("WMBUS_K1_STREAM")) : 0;   /* 1: one shared stream carries every context's K1 (r04 A/B: -13 %) */
         int rc;
@@ -831,7 +869,7 @@ static int enqueue_front_impl(wmbus_ctx *c, size_t nbytes)
                 HIPCHK(c, hipEventRecord(c->ev_ready, c->stream));
                 HIPCHK(c, hipStreamWaitEvent(kc.stream, c->ev_ready, 0));
                 HIPCHK(c, hipEventRecord(c->ev[3], kc.stream));
-                rc = launch_k1_any(c, c->k1a, dim3(ntiles, c->S), kc.stream);
+                rc = launch_k1_any(c, c->k1a, dim3(ntiles, c->S), kc.stream, c->rs_this ? 1 : 0);
                 if (rc) return rc;
                 HIPCHK(c, hipEventRecord(c->ev[4], kc.stream));
                 HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev[4], 0));
@@ -850,12 +888,13 @@ static int enqueue_front_impl(wmbus_ctx *c, size_t nbytes)
                 const uint32_t tail_pm = tail_env >= 0 ? (uint32_t)tail_env : c->cfg.tolerance_mode ? 0u : 60u;
                 const uint32_t n_tail = turns ? std::min(ntiles - 1u, (uint32_t)((uint64_t)ntiles * tail_pm / 1000u)) : 0u;
                 K1Args k1 = c->k1a;
-                rc = launch_k1_any(c, k1, dim3(ntiles - n_tail, c->S));
+                const int rs = c->rs_this ? 1 : 0;
+                rc = launch_k1_any(c, k1, dim3(ntiles - n_tail, c->S), nullptr, rs);
                 if (rc) return rc;
                 if (n_tail) {
                     HIPCHK(c, hipEventRecord(c->ev_turn, c->stream));
                     k1.tile0 = ntiles - n_tail;
-                    rc = launch_k1_any(c, k1, dim3(n_tail, c->S));
+                    rc = launch_k1_any(c, k1, dim3(n_tail, c->S), nullptr, rs);
                     if (rc) return rc;
                 }
                 HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
@@ -865,13 +904,16 @@ static int enqueue_front_impl(wmbus_ctx *c, size_t nbytes)
         /* Everything behind K1 is enqueued while it runs -- no step of a push waits for the host any more:
          * hand-off verification makes its first rounds on the device (counters per round), K3 reads its item
          * count there, the results land in pinned host memory.  wmbus_collect looks at the last counters. */
-        for (unsigned r = 0; r < c->ema_rounds && opt_rounds; r++) {
-            ema_verify(c, SC_EMA + r);
-            rc = ema_repair(c, SC_EMA + r);
-            if (rc) return rc;
+        c->rs_full_now = false;
+        if (!c->rs_this) {                                      /* (on demand: the RSSI comes behind the framers, launch_k3) */
+            for (unsigned r = 0; r < c->ema_rounds && opt_rounds; r++) {
+                ema_verify(c, SC_EMA + r);
+                rc = ema_repair(c, SC_EMA + r);
+                if (rc) return rc;
+            }
+            ema_verify(c, SC_EMA + c->ema_rounds);
+            ema_commit(c);
         }
-        ema_verify(c, SC_EMA + c->ema_rounds);
-        ema_commit(c);
 
         /* K2: clock recovery + time2 framer (also produces the slicer bits the RLA needs) */
         K2Args k2{};
@@ -992,7 +1034,7 @@ int wmbus_process(wmbus_ctx *c, size_t nbytes)
 
 /* The optimistic rounds of wmbus_process left work: finish it round by round with the host in the loop (rare: a
  * cascade of hand-off failures longer than the rounds enqueued), then redo what depended on it. */
-static int finish_slowly(wmbus_ctx *c, bool ema_left, bool clk_left, bool rla_left)
+static int finish_slowly(wmbus_ctx *c, bool ema_left, bool clk_left, bool rla_left, bool rs_left = false)
 {
     auto leftovers = [&](uint32_t *n) -> int {
         HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, SC_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
@@ -1001,8 +1043,22 @@ static int finish_slowly(wmbus_ctx *c, bool ema_left, bool clk_left, bool rla_le
         return 0;
     };
     const uint32_t max_rounds = std::max({c->ntiles, c->last.nseg[0], c->last.nseg[1]}) + 4;
+    if (rs_left) {
+        /* RSSI on demand, and a lane whose value is read could not prove it (wm_k1_demod.h: constant input can keep the bracket
+         * open): this push's RSSI the long way -- the full kernel over every tile, its hand-offs verified against the carried
+         * state and repaired like any other context's */
+        uint32_t n = 0;
+        int rc = launch_k1_any(c, c->k1a, dim3(c->ntiles, c->S));
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_copy_word, dim3(1), dim3(1), 0, c->stream, c->d_scalars + SC_SLOW, 0u);
+        ema_verify(c, SC_SLOW);
+        if ((rc = leftovers(&n))) return rc;
+        ema_left = n != 0;
+        if (!ema_left) ema_commit(c);
+        c->rs_full_now = true;
+    }
     if (ema_left) {
-        uint32_t cnt = SC_EMA + c->ema_rounds, n = 0;          /* the list of the last verify is still in d_list_ema */
+        uint32_t cnt = rs_left ? (uint32_t)SC_SLOW : SC_EMA + c->ema_rounds, n = 0;          /* the list of the last verify is still in d_list_ema */
         for (uint32_t round = 0;; round++) {
             c->tim.ema_retries += c->h_scalars[cnt];
             int rc = ema_repair(c, cnt);
@@ -1045,6 +1101,8 @@ static int finish_slowly(wmbus_ctx *c, bool ema_left, bool clk_left, bool rla_le
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, SC_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    /* the chips have changed, so have the bursts and the tiles they touch: one of those may be unprovable in turn */
+    if (c->rs_this && !c->rs_full_now && c->h_scalars[SC_RS_FAIL]) return finish_slowly(c, false, false, false, true);
     return 0;
 }
 
@@ -1177,6 +1235,7 @@ static int wait_gpu(wmbus_ctx *c)
         for (unsigned r = 0; r < c->fr_rounds; r++) c->tim.clock_reruns += hs[SC_CLK + r];
         for (unsigned r = 0; r < c->rla_fin; r++) c->tim.rla_reruns += hs[SC_RLA + r];
         const bool ema_left = hs[SC_EMA + c->ema_rounds], clk_left = hs[SC_CLK + c->fr_rounds], rla_left = hs[SC_RLA + c->rla_fin];
+        const bool rs_left = c->rs_this && hs[SC_RS_FAIL] != 0;
         static const bool dbg_rounds = getenv("WMBUS_DEBUG_ROUNDS") != nullptr;
         if (dbg_rounds)
             fprintf(stderr, "rounds: ema %u %u | clock %u %u %u %u | rla %u %u %u %u\n", hs[SC_EMA], hs[SC_EMA + 1], hs[SC_CLK], hs[SC_CLK + 1], hs[SC_CLK + 2],
@@ -1187,8 +1246,13 @@ static int wait_gpu(wmbus_ctx *c)
          * pays for the verdict flags -- measured with them always on: 142 against 150 Gsamples/s, although the kernels' own
          * durations did not move (r04, visits q / p). */
         if (rla_left && c->d_bad) c->rla_chains = true;
-        if (ema_left || clk_left || rla_left) {
-            const int rc = finish_slowly(c, ema_left, clk_left, rla_left);
+        if (c->rs_this) {
+            static const uint32_t rs_max = getenv("WMBUS_RS_MAX") ? (uint32_t)atoi(getenv("WMBUS_RS_MAX")) : 200u;
+            if ((uint64_t)hs[SC_RS_N] * 1000u > (uint64_t)rs_max * c->ntiles * c->S) c->rs_pause = 16;
+            if (dbg_rounds) fprintf(stderr, "rssi on demand: %u of %u tiles listed%s\n", hs[SC_RS_N], c->ntiles * c->S, hs[SC_RS_FAIL] ? ", unproven: full pass" : "");
+        }
+        if (ema_left || clk_left || rla_left || rs_left) {
+            const int rc = finish_slowly(c, ema_left, clk_left, rla_left, rs_left);
             if (rc) { c->poisoned = true; return rc; }
             c->tim.slow_path = 1;
         }

@@ -42,7 +42,26 @@ struct K1Args {
     const float *ema_carry;  /* [2][S] exact EMA carried in from the previous push */
     const uint32_t *n_relist;/* repair launches: entries in `relist` (on the device: k1_collect has just written it) */
     uint32_t tile0;          /* first pass: the launch's first tile (a push's tiles may leave in two launches, see enqueue_front_impl) */
+    /* RSSI on demand (RS = 2 launches; `relist` / `n_relist` then name the tiles k3_spans has listed) */
+    const uint32_t *rs_flags;/* [ntiles][S] bit 0: the T1/C1 chain's RSSI is read in this tile, bit 1: the S1 chain's */
+    float *ema_out;          /* [2][S] the EMA after the push's last sample (the last tile of every capture is always listed) */
+    uint32_t *rs_fail;       /* set when a lane that is read could not prove its value: the push falls back to the full pass */
 };
+
+/* RSSI on demand.  The RSSI of a sample (rtl_wmbus.c:475-495: EMA of the filtered magnitude) is READ only at the chips of
+ * bursts a packet decoder is looking at (t1_c1_packet_decoder.h:651,707; s1_packet_decoder.h:235,277) -- a sixth of the
+ * samples of the bench workload -- while computing it for every sample was 14 % of the demodulation kernel (eight exact
+ * square roots per thread, the EMA roles of stage B2).  With RS = 1 the first pass leaves it out; when the framers and
+ * k3_spans have found the bursts, an RS = 2 launch computes it for the 976-sample tiles they touch.
+ * The EMA is recursive, so a lane must PROVE the state it starts from without the chain of hand-offs the full pass
+ * certifies against (k1_verify): it runs its 32-sample warm-up twice, from 0 and from WM_EMA_UPPER.  The filter step
+ * y -> fl(fl(al x) + fl(be y)) is monotone in y and the true state lies in [0, WM_EMA_UPPER) (magnitudes are below 256:
+ * |i|, |q| <= 127.5 sqrt 2 after the -s rotation), so both trajectories bracket the true one at every sample, and where they
+ * meet bit for bit the true one is there too.  A lane whose bracket is still open takes its predecessor's end value if
+ * that one is proven and equals its own lower trajectory (the full pass's certificate).  If a lane that is read has neither
+ * (constant input can keep a bracket one ulp open for ever: the map has neighbouring fixed points), rs_fail is set and the
+ * host runs the full pass for this push -- slow, exact, rare. */
+#define WM_EMA_UPPER 256.0f
 
 /* =============================================================================================
  * K1, moving-average front end (second generation of this kernel; the first one -- 1024-sample
@@ -178,7 +197,7 @@ __device__ __forceinline__ void k1_fir_s(const K1Args &a, const float *yDrS, con
 #ifndef WM_K1_BALANCED
 #define WM_K1_BALANCED 1
 #endif
-template <bool GEN, bool FAST = false>
+template <bool GEN, bool FAST = false, int RS = 0>
 __device__ __forceinline__ void k1_stage_b(const K1Args &a, const int tid, const int tile, const int stream, const int ts, const int tn,
                                            const bool chT, const bool chS, const float *yDrT, const float *yDrS,
                                            const float *yMgT, const float *yMgS, float *sFin, float *sHead)
@@ -190,6 +209,11 @@ __device__ __forceinline__ void k1_stage_b(const K1Args &a, const int tid, const
      * ~870): the jobs rotate with the tile, so that no SIMD of a CU can end up with the heavy job block
      * after block whatever order the hardware places a workgroup's waves in (two instructions). */
     const int e = tid & 63, wv = ((tid >> 6) + tile) & 3, rt = 64 * wv + e;      /* rt: thread id within the rotated roles */
+    if (RS == 1) {                                            /* no RSSI here: every wave a quarter of each low-pass (4 x 92 + 2 x 44) */
+        if (chS) k1_fir_s<FAST>(a, yDrS, 64 * wv + e, stream, ts, tn);
+        if (chT) k1_fir_t<FAST>(a, yDrT, 64 * wv + e, stream, ts, tn);
+        return;
+    }
     const int ch = wv & 1;                                    /* EMA chain of waves 0, 1 */
     const bool on = wv < 2 && (ch ? chS : chT) && 16 * e < T;
     const float al = 0.6789f, be = wm_sub(1.0f, 0.6789f);
@@ -266,10 +290,62 @@ __device__ __forceinline__ void k1_stage_b(const K1Args &a, const int tid, const
     }
 }
 
+/* Stage B2 of an RS = 2 launch: the RSSI of one listed tile, every lane proving its own start (see WM_EMA_UPPER above).
+ * Waves 0 and 1 take one chain each, 16 samples per lane behind the 32-sample warm-up, as in the full pass. */
+__device__ __forceinline__ void k1_stage_rssi(const K1Args &a, const int tid, const int tile, const int stream, const int ts, const int tn,
+                                              const uint32_t mask, const float *yMgT, const float *yMgS, float *sFin)
+{
+    constexpr int T = WM_K1_TILE2;
+    const WmPush &g = a.g;
+    __syncthreads();                                          /* magnitude rows complete */
+    const int e = tid & 63, wv = tid >> 6, ch = wv & 1, rt = 64 * wv + e;
+    const bool on = wv < 2 && ((mask >> ch) & 1u) && 16 * e < T;
+    const float al = 0.6789f, be = wm_sub(1.0f, 0.6789f);
+    const int m0l = 16 * e;
+    const uint64_t row = (uint64_t)ch * g.S + stream;
+    float lo = 0.0f, hi = WM_EMA_UPPER, head = 0.0f, tail = 0.0f;
+    uint32_t pk[4] = {0u, 0u, 0u, 0u};
+    bool proven = false;
+    if (on) {
+        const float *mg = (ch ? yMgS : yMgT) + 17 * e;        /* element 16 e + kk at 17 e + kk + kk/16 */
+#pragma unroll
+        for (int k = WM_K1_HALO - WM_EMA_WARMUP; k < WM_K1_HALO; k++) {
+            const float x = wm_mul(al, mg[k + (k >> 4)]);
+            lo = wm_add(x, wm_mul(be, lo)); hi = wm_add(x, wm_mul(be, hi));
+        }
+        head = lo;
+        /* a warm-up that begins at or before the stream's first sample starts from the true state: zero, over zero input */
+        proven = wm_f2u(lo) == wm_f2u(hi) || (long)(g.m0 + (uint64_t)ts) + m0l - WM_EMA_WARMUP <= 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            lo = wm_add(wm_mul(al, mg[WM_K1_HALO + k + ((WM_K1_HALO + k) >> 4)]), wm_mul(be, lo));
+            pk[k >> 2] |= ((uint32_t)lo & 0xFFu) << (8 * (k & 3));
+            if (m0l + k == tn - 1) tail = lo;
+        }
+        sFin[rt] = lo;
+    }
+    __syncthreads();
+    if (wv >= 2) return;
+    const bool read = on && m0l < tn;                         /* lanes whose bytes exist */
+    const bool link = read && e > 0 && wm_f2u(head) == wm_f2u(sFin[rt - 1]);
+    unsigned long long ok = __ballot(on && proven);
+    const unsigned long long lk = __ballot(link), rd = __ballot(read);
+    for (;;) {                                                /* a proven predecessor whose end value I started from proves me */
+        const unsigned long long nx = ok | ((ok << 1) & lk);
+        if (nx == ok) break;
+        ok = nx;
+    }
+    if ((rd & ~ok) != 0ull && e == 0) atomicOr(a.rs_fail, 1u);
+    if (read) {
+        *(uint4 *)(a.rssi + row * g.Mcap + ts + m0l) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        if (tile == (int)a.ntiles - 1 && m0l <= tn - 1 && tn - 1 < m0l + 16) a.ema_out[row] = tail;
+    }
+}
+
 /* GEN = false: the kernel of the DEFAULT switches (both chains, cargf arctangent, first pass): the switch tests, the
  * -a / -A / -p paths and the RSSI repair walk are not compiled in, so the default path carries no cost for the options
  * (any other configuration, and every repair launch, runs the GEN = true kernel: same arithmetic, same results). */
-template <int D, bool SHIFT, bool GEN, bool FAST = false>
+template <int D, bool SHIFT, bool GEN, bool FAST = false, int RS = 0>
 __device__ __forceinline__ void k1_tile(const K1Args &a, const int tile, const int stream, const int tid)
 {
     using G = K1Geo;
@@ -290,7 +366,7 @@ __device__ __forceinline__ void k1_tile(const K1Args &a, const int tile, const i
     const bool accurate = !GEN || (g.flags & WM_F_ACCURATE);
     const int approx = !GEN ? 0 : (g.flags & WM_F_APPROX1) ? 1 : (g.flags & WM_F_APPROX2) ? 2 : 0;   /* option: atan2.h's approximations */
 
-    if (tid < WM_ATAN_TAB_WORDS) wm_atan_tab_word(tid, tab);   /* 5 range rows + range LUT */
+    if (RS != 2 && tid < WM_ATAN_TAB_WORDS) wm_atan_tab_word(tid, tab);   /* 5 range rows + range LUT */
 
     /* ---- stage 0: one dword (two IQ samples) per lane and pass: coalesced loads, LDS stores at a
      * two-word lane stride (the 16-byte-per-lane variant stored at an 8-word stride: 8-way bank
@@ -351,7 +427,7 @@ __device__ __forceinline__ void k1_tile(const K1Args &a, const int tile, const i
     __syncthreads();
 
     /* ---- stage A: thread = chunk ------------------------------------------------------------- */
-    float mgT[4], mgS[4];
+    float mgT[4] = {0.0f, 0.0f, 0.0f, 0.0f}, mgS[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     {
         const int c = tid;
         wm_s2 s8[5], s16[5], u8[5], u16[5];
@@ -366,14 +442,32 @@ __device__ __forceinline__ void k1_tile(const K1Args &a, const int tile, const i
             fT[j][0] = (float)s8[j].x; fT[j][1] = (float)s8[j].y;          /* 8 x the reference's i, q */
             fS[j][0] = (float)s16[j].x; fS[j][1] = (float)s16[j].y;       /* 16 x */
         }
-        if (accurate && chT && chS && !approx) {             /* default switches: no branch between the eight */
+        if (RS == 2) {                                       /* RSSI only: the magnitudes of the chunk's four samples, of the chains that are read */
+            const uint32_t mask = a.rs_flags[(uint64_t)tile * g.S + stream];
+#pragma unroll
+            for (int j = 0; j < 4; j++) { drT[j] = 0.0f; drS[j] = 0.0f; }
+            if (mask & 1u) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float iT = fT[j + 1][0], qT = fT[j + 1][1];
+                    mgT[j] = wm_mul(wm_sqrt_dom(wm_add(wm_mul(iT, iT), wm_mul(qT, qT))), 0.125f);
+                }
+            }
+            if (mask & 2u) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float iS = fS[j + 1][0], qS = fS[j + 1][1];
+                    mgS[j] = wm_mul(wm_sqrt_dom(wm_add(wm_mul(iS, iS), wm_mul(qS, qS))), 0.0625f);
+                }
+            }
+        } else if (accurate && chT && chS && !approx) {      /* default switches: no branch between the eight */
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 drT[j] = FAST ? wm_discriminator_tol(fT[j + 1][0], fT[j + 1][1], fT[j][0], fT[j][1]) : wm_discriminator_tab(fT[j + 1][0], fT[j + 1][1], fT[j][0], fT[j][1], tab);
                 drS[j] = FAST ? wm_discriminator_tol(fS[j + 1][0], fS[j + 1][1], fS[j][0], fS[j][1]) : wm_discriminator_tab(fS[j + 1][0], fS[j + 1][1], fS[j][0], fS[j][1], tab);
             }
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
+            for (int j = 0; j < 4 && RS == 0; j++) {
                 const float iT = fT[j + 1][0], qT = fT[j + 1][1], iS = fS[j + 1][0], qS = fS[j + 1][1];
                 mgT[j] = wm_mul(wm_sqrt_dom(wm_add(wm_mul(iT, iT), wm_mul(qT, qT))), 0.125f);
                 mgS[j] = wm_mul(wm_sqrt_dom(wm_add(wm_mul(iS, iS), wm_mul(qS, qS))), 0.0625f);
@@ -393,28 +487,38 @@ __device__ __forceinline__ void k1_tile(const K1Args &a, const int tile, const i
                 if (approx && (long)(g.m0 + (uint64_t)ts) + 4 * c + j < (long)WM_K1_HALO) { drT[j] = 0.0f; drS[j] = 0.0f; }
             }
         }
-        /* element a of a discriminator row lives at word a + 4 */
-        *(float4 *)(yDrT + 4 * c + 4) = make_float4(drT[0], drT[1], drT[2], drT[3]);
-        *(float4 *)(yDrS + 4 * c + 4) = make_float4(drS[0], drS[1], drS[2], drS[3]);
+        if (RS != 2) {                                       /* element a of a discriminator row lives at word a + 4 */
+            *(float4 *)(yDrT + 4 * c + 4) = make_float4(drT[0], drT[1], drT[2], drT[3]);
+            *(float4 *)(yDrS + 4 * c + 4) = make_float4(drS[0], drS[1], drS[2], drS[3]);
+        }
     }
     __syncthreads();                                          /* staging data retired */
-    {   /* element a of a magnitude row lives at word a + a/16 (conflict-free 17-word lane stride in B2) */
+    if (RS != 1) {   /* element a of a magnitude row lives at word a + a/16 (conflict-free 17-word lane stride in B2) */
         const int qb = 4 * tid + (tid >> 2);
 #pragma unroll
         for (int j = 0; j < 4; j++) { yMgT[qb + j] = mgT[j]; yMgS[qb + j] = mgS[j]; }
     }
 
-    k1_stage_b<GEN, FAST>(a, tid, tile, stream, ts, tn, chT, chS, yDrT, yDrS, yMgT, yMgS, sFin, sHead);
+    if (RS == 2) k1_stage_rssi(a, tid, tile, stream, ts, tn, a.rs_flags[(uint64_t)tile * g.S + stream], yMgT, yMgS, sFin);
+    else k1_stage_b<GEN, FAST, RS>(a, tid, tile, stream, ts, tn, chT, chS, yDrT, yDrS, yMgT, yMgS, sFin, sHead);
 }
 
-template <int D, bool SHIFT, bool GEN = true, bool FAST = false>
+template <int D, bool SHIFT, bool GEN = true, bool FAST = false, int RS = 0>
 __global__ __launch_bounds__(256, GEN ? 1 : 8) void k1_demod2(K1Args a)          /* first pass: at most 64 VGPRs -- eight waves fill a SIMD's register file exactly */
 {
     /* One tile per block.  (A bounded grid whose blocks walk several tiles made the kernel itself 6 % faster -- fewer block
      * launches, per-thread addresses kept across tiles -- and the whole job 10 % slower: the framer kernels of the other
      * contexts get onto a CU when demodulation blocks retire, and blocks that live twice as long halve their chances; r03
      * A/B in DESIGN.md section 10.) */
-    if (!GEN || a.relist == nullptr) { k1_tile<D, SHIFT, GEN, FAST>(a, (int)(blockIdx.x + a.tile0), (int)blockIdx.y, (int)threadIdx.x); return; }
+    if (RS == 2) {                                            /* the tiles k3_spans has listed, walked by a fixed grid */
+        const uint32_t n = *a.n_relist;
+        for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
+            k1_tile<D, SHIFT, GEN, FAST, RS>(a, (int)(a.relist[e] % a.ntiles), (int)(a.relist[e] / a.ntiles), (int)threadIdx.x);
+            __syncthreads();                                  /* the tile's LDS is reused by the next entry */
+        }
+        return;
+    }
+    if (!GEN || a.relist == nullptr) { k1_tile<D, SHIFT, GEN, FAST, RS>(a, (int)(blockIdx.x + a.tile0), (int)blockIdx.y, (int)threadIdx.x); return; }
     /* repair launch: a fixed grid walks the list k1_collect has just written (no host round trip in between) */
     const uint32_t n = *a.n_relist;
     for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {

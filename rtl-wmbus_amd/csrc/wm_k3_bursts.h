@@ -178,58 +178,81 @@ __device__ __forceinline__ uint32_t k3_crc16(const uint8_t *p, uint32_t n)
  * -- and if none precedes the last chip, lanes assemble the bytes (3-out-of-6 with the error flag, NRZ, Manchester)
  * and check the block CRCs.  The host gets {consumed, flags, RSSI pair, completing sample} and the bytes.  A burst
  * cut by the end of the push, and its continuation in the next one, still travel as chips to the host decoder. */
-__device__ void burst_item(const K3Args &a, const uint32_t item, const uint32_t ln, unsigned long long *s_bits, uint8_t *s_bytes)
+/* What k3_bursts and k3_spans both need to know about an item: where its chips are and how many of them a decoder takes. */
+struct K3Item {
+    uint32_t algo, ch, stream, seg, k, cont, nseg, seg_len, chip0, avail, n;
+    uint64_t row, sidx0;
+    const uint32_t *cnt;         /* chips per segment of the (framer, chain, capture) */
+    WmPlan plan;
+};
+__device__ __forceinline__ uint32_t k3_chip(const K3Args &a, const K3Item &it, uint32_t sg, uint32_t kk)
+{
+    return *wm_chip_ptr(a.g, a.chips[it.algo], it.algo, it.sidx0 + sg, kk);
+}
+__device__ __forceinline__ void k3_locate(const K3Item &it, uint32_t j, uint32_t &sg, uint32_t &kk)   /* chip0 + j -> (segment, index) */
+{
+    sg = it.seg; kk = it.k + j;
+    while (sg < it.nseg) { const uint32_t c = it.cnt[sg]; if (kk < c) break; kk -= c; sg++; }
+}
+/* false: nothing to do for this item (an empty continuation slot, a stale hit of a re-run segment).  By one wave. */
+__device__ __forceinline__ bool k3_item(const K3Args &a, const uint32_t item, const uint32_t ln, K3Item &it)
 {
     const WmPush &g = a.g;
     const uint32_t n_hits = min(*a.n_hits, a.hits_cap);
-    uint32_t algo, ch, stream, seg, k, cont = 0, want;
+    uint32_t want;
+    it.cont = 0;
     if (item < 4u * g.S) {                       /* continuation slots come first            */
-        algo = item / (2u * g.S); ch = (item / g.S) & 1u; stream = item % g.S;
+        it.algo = item / (2u * g.S); it.ch = (item / g.S) & 1u; it.stream = item % g.S;
         want = a.pending[item];
-        if (want == 0u) return;
-        seg = 0; k = 0; cont = 1;
+        if (want == 0u) return false;
+        it.seg = 0; it.k = 0; it.cont = 1;
     } else {
-        if (item - 4u * g.S >= n_hits) return;
+        if (item - 4u * g.S >= n_hits) return false;
         const uint2 h = a.hits[item - 4u * g.S];
-        algo = h.x >> 31;
-        lane_decode(g, algo, h.x & 0x7FFFFFFFu, ch, stream, seg);
-        k = h.y; want = 0;
+        it.algo = h.x >> 31;
+        lane_decode(g, it.algo, h.x & 0x7FFFFFFFu, it.ch, it.stream, it.seg);
+        it.k = h.y; want = 0;
     }
-    const uint32_t nseg = g.nseg[algo], seg_len = g.seg_len[algo];
-    const uint64_t row = (uint64_t)ch * g.S + stream;
-    const uint32_t *cnt = a.counts[algo] + row * g.nseg_cap[algo];
-    const uint64_t sidx0 = row * g.nseg_cap[algo];
-    auto chip = [&](uint32_t sg, uint32_t kk) { return *wm_chip_ptr(g, a.chips[algo], algo, sidx0 + sg, kk); };
-    if (!cont) {                                 /* stale record of a re-run segment?         */
-        if (k >= cnt[seg] || !(chip(seg, k) & 2u)) return;
+    it.nseg = g.nseg[it.algo]; it.seg_len = g.seg_len[it.algo];
+    it.row = (uint64_t)it.ch * g.S + it.stream;
+    it.cnt = a.counts[it.algo] + it.row * g.nseg_cap[it.algo];
+    it.sidx0 = it.row * g.nseg_cap[it.algo];
+    if (!it.cont) {                              /* stale record of a re-run segment?         */
+        if (it.k >= it.cnt[it.seg] || !(k3_chip(a, it, it.seg, it.k) & 2u)) return false;
     }
     /* chips before / from the hit in this push's chip stream: the wave sums the segment counts in
      * parallel (a serial scan of up to 256 dependent loads per wave was most of this kernel's time) */
     uint32_t before = 0, total = 0;
-    for (uint32_t s = ln; s < nseg; s += 64u) { const uint32_t c = cnt[s]; if (s < seg) before += c; total += c; }
+    for (uint32_t s = ln; s < it.nseg; s += 64u) { const uint32_t c = it.cnt[s]; if (s < it.seg) before += c; total += c; }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) { before += __shfl_xor(before, off); total += __shfl_xor(total, off); }
-    const uint32_t chip0 = before + k;
-    if (chip0 >= total) return;
-    const uint32_t avail = total - chip0;        /* chips from the hit to the end of the push */
-
-    auto locate = [&](uint32_t j, uint32_t &sg, uint32_t &kk) {   /* chip0 + j -> (segment, index) */
-        sg = seg; kk = k + j;
-        while (sg < nseg) { const uint32_t c = cnt[sg]; if (kk < c) break; kk -= c; sg++; }
-    };
-
-    uint32_t n;
-    WmPlan plan = {};
-    if (cont) n = min(want, avail);
+    it.chip0 = before + it.k;
+    if (it.chip0 >= total) return false;
+    it.avail = total - it.chip0;                 /* chips from the hit to the end of the push */
+    it.plan = WmPlan{};
+    if (it.cont) it.n = min(want, it.avail);
     else {
         uint32_t bit = 0;
-        if (ln < 24u && 1u + ln < avail) { uint32_t sg, kk; locate(1u + ln, sg, kk); bit = chip(sg, kk) & 1u; }
+        if (ln < 24u && 1u + ln < it.avail) { uint32_t sg, kk; k3_locate(it, 1u + ln, sg, kk); bit = k3_chip(a, it, sg, kk) & 1u; }
         const unsigned long long m = __ballot(bit);
         uint32_t hb = 0;
         for (int j = 0; j < 24; j++) hb |= (uint32_t)((m >> j) & 1ull) << (23 - j);
-        plan = burst_plan(ch, hb, min(24u, avail - 1u));
-        n = min(plan.need + 1u, avail);
+        it.plan = burst_plan(it.ch, hb, min(24u, it.avail - 1u));
+        it.n = min(it.plan.need + 1u, it.avail);
     }
+    return true;
+}
+
+__device__ void burst_item(const K3Args &a, const uint32_t item, const uint32_t ln, unsigned long long *s_bits, uint8_t *s_bytes)
+{
+    const WmPush &g = a.g;
+    K3Item it;
+    if (!k3_item(a, item, ln, it)) return;
+    const uint32_t algo = it.algo, ch = it.ch, stream = it.stream, cont = it.cont, seg_len = it.seg_len, chip0 = it.chip0, avail = it.avail, n = it.n;
+    const uint64_t row = it.row;
+    const WmPlan plan = it.plan;
+    auto chip = [&](uint32_t sg, uint32_t kk) { return k3_chip(a, it, sg, kk); };
+    auto locate = [&](uint32_t j, uint32_t &sg, uint32_t &kk) { k3_locate(it, j, sg, kk); };
 
     if (!cont && a.pkts != nullptr && plan.need + 1u <= avail) {
         /* ---- the whole burst is here: decode it -------------------------------------------------- */
@@ -368,6 +391,30 @@ __global__ __launch_bounds__(256) void k3_bursts(K3Args a, uint32_t n_items_host
     /* the host may not know the number of hits yet (no round trip between k3_scan and this kernel): ~0 = read it here */
     const uint32_t n_items = n_items_host != 0xFFFFFFFFu ? n_items_host : 4u * a.g.S + min(*a.n_hits, a.hits_cap);
     for (uint32_t item = blockIdx.x * 4u + wv; item < n_items; item += gridDim.x * 4u) burst_item(a, item, ln, lds.bits[wv], lds.bytes[wv]);
+}
+
+/* RSSI on demand (wm_k1_demod.h): the demodulation tiles whose RSSI bytes k3_bursts is going to read -- for every item
+ * the samples from its first chip to the last one a decoder takes -- are flagged per chain and listed once; the last tile
+ * of every capture is always listed (it carries the filter's state into the next push). */
+__device__ __forceinline__ void k3_mark(uint32_t *flags, uint32_t *list, uint32_t *n_list, uint32_t S, uint32_t ntiles, uint32_t tile, uint32_t stream, uint32_t bits)
+{
+    if (atomicOr(flags + (uint64_t)tile * S + stream, bits) == 0u) list[atomicAdd(n_list, 1u)] = stream * ntiles + tile;   /* at most one entry per (tile, capture) */
+}
+__global__ __launch_bounds__(256) void k3_spans(K3Args a, uint32_t tile_len, uint32_t ntiles, uint32_t *flags, uint32_t *list, uint32_t *n_list)
+{
+    wm_framer_prio();
+    const WmPush &g = a.g;
+    const uint32_t ln = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    for (uint32_t s = blockIdx.x * 256u + threadIdx.x; s < g.S; s += gridDim.x * 256u) k3_mark(flags, list, n_list, g.S, ntiles, ntiles - 1u, s, 3u);
+    const uint32_t n_items = 4u * g.S + min(*a.n_hits, a.hits_cap);
+    for (uint32_t item = blockIdx.x * 4u + wv; item < n_items; item += gridDim.x * 4u) {
+        K3Item it;
+        if (!k3_item(a, item, ln, it)) continue;
+        uint32_t pm = 0;
+        if (ln < 2u) { uint32_t sg, kk; k3_locate(it, ln ? it.n - 1u : 0u, sg, kk); pm = sg * it.seg_len + WM_CHIP_POS(k3_chip(a, it, sg, kk)); }
+        const uint32_t t0 = __shfl(pm, 0) / tile_len, t1 = min(__shfl(pm, 1) / tile_len, ntiles - 1u);
+        for (uint32_t tl = t0 + ln; tl <= t1; tl += 64u) k3_mark(flags, list, n_list, g.S, ntiles, tl, it.stream, 1u << it.ch);
+    }
 }
 
 /* Debug/parity helper: flatten one (chain, algo, stream) chip stream. */

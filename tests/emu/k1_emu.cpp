@@ -66,6 +66,16 @@ template <int D, bool SHIFT> static void run_k1(const K1Args &a, uint32_t gx, ui
         }
 }
 
+template <int D, bool SHIFT> static void run_k1_od(K1Args a, uint32_t ntiles, uint32_t S, const std::vector<uint32_t> &list, uint32_t *n_list)
+{
+    gridDim = {ntiles, S, 1};
+    for (uint32_t y = 0; y < S; y++)
+        for (uint32_t x = 0; x < ntiles; x++) { blockIdx = {x, y, 0}; block_emu::run_block(256, [&] { k1_demod2<D, SHIFT, false, false, 1>(a); }); }
+    a.relist = list.data(); a.n_relist = n_list;
+    gridDim = {5, 1, 1};                                                    /* a fixed grid walks the list */
+    for (uint32_t x = 0; x < 5; x++) { blockIdx = {x, 0, 0}; block_emu::run_block(256, [&] { k1_demod2<D, SHIFT, false, false, 2>(a); }); }
+}
+
 extern "C" {
 
 /* One push.  in: S rows of in_stride bytes (4096 history bytes first); dphi: [2][S][Mcap]; rssi:
@@ -125,6 +135,41 @@ long wm_emu_k1(const uint8_t *in, uint64_t in_stride, uint32_t S, uint32_t d, ui
     for (uint32_t r = 0; r < rows; r++) { blockIdx = {r / 64, 0, 0}; threadIdx = {r % 64, 0, 0}; k1_commit(tail.data(), ema_carry, ntiles, rows); }
     if (err_out) *err_out = err;
     return repaired;
+}
+
+/* RSSI on demand (wm_k1_demod.h): the first pass without the RSSI (RS = 1), then the RSSI of the tiles flagged in
+ * tile_flags [ntiles][S] (bit 0: T1/C1 chain, bit 1: S1; the last tile of every capture is added, as k3_spans does) by an
+ * RS = 2 launch over the list.  Default switches, d = 2..5 only.  ema_out: [2][S] the filter's state after the push.
+ * Returns 1 when a lane that is read could not prove its value (the product then runs the full pass), else 0. */
+long wm_emu_k1_od(const uint8_t *in, uint64_t in_stride, uint32_t S, uint32_t d, uint32_t flags, uint64_t n0, uint32_t n_new,
+                  uint32_t Mcap, float *dphi, uint8_t *rssi, float *ema_out, uint32_t *tile_flags)
+{
+    WmPush g{};
+    g.in = in; g.in_stride = in_stride; g.n0 = n0; g.m0 = n0 / d; g.n_new = n_new;
+    g.M = (uint32_t)((n0 + n_new) / d - g.m0); g.Mcap = Mcap; g.d = d; g.S = S; g.lut_n = 32 * d;
+    g.lut_phase0 = (uint32_t)((13ull * (n0 % g.lut_n)) % g.lut_n); g.flags = flags;
+    if (g.M == 0 || d < 2 || d > 5) return -1;
+    const uint32_t T = WM_K1_TILE2, ntiles = (g.M + T - 1) / T;
+    std::vector<float> lut(2 * 32 * WM_MAX_DECIM, 0.f);
+    const int fs_khz = (int)d * 800;
+    for (size_t n = 0; n < (size_t)(fs_khz / 25); n++) {
+        const double phi = (2. * M_PI * (25 * (double)n)) / fs_khz;
+        lut[n] = cosf(phi); lut[32 * WM_MAX_DECIM + n] = -sinf(phi);
+    }
+    std::vector<uint32_t> list;
+    for (uint32_t s = 0; s < S; s++) tile_flags[(size_t)(ntiles - 1) * S + s] |= 3u;
+    for (uint32_t tl = 0; tl < ntiles; tl++)
+        for (uint32_t s = 0; s < S; s++) if (tile_flags[(size_t)tl * S + s]) list.push_back(s * ntiles + tl);
+    uint32_t err = 0, fail = 0, n_list = (uint32_t)list.size();
+    K1Args a{g, dphi, rssi, lut.data(), lut.data() + 32 * WM_MAX_DECIM, nullptr, nullptr, ntiles, &err, nullptr, nullptr, nullptr, 0u, tile_flags, ema_out, &fail};
+    const bool sh = flags & WM_F_SHIFT;
+    switch (d) {
+    case 2: sh ? run_k1_od<2, true>(a, ntiles, S, list, &n_list) : run_k1_od<2, false>(a, ntiles, S, list, &n_list); break;
+    case 3: sh ? run_k1_od<3, true>(a, ntiles, S, list, &n_list) : run_k1_od<3, false>(a, ntiles, S, list, &n_list); break;
+    case 4: sh ? run_k1_od<4, true>(a, ntiles, S, list, &n_list) : run_k1_od<4, false>(a, ntiles, S, list, &n_list); break;
+    default: sh ? run_k1_od<5, true>(a, ntiles, S, list, &n_list) : run_k1_od<5, false>(a, ntiles, S, list, &n_list); break;
+    }
+    return err ? -2 : (long)fail;
 }
 
 }

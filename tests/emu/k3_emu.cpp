@@ -48,6 +48,13 @@ void wm_emu_k3_set_decode(void *pkts, uint32_t pkts_cap, uint32_t *n_pkts, uint8
 }
 unsigned wm_emu_pkt_bytes(void) { return sizeof(WmPkt); }
 
+/* optional: RSSI on demand.  k3_spans flags the demodulation tiles whose RSSI the bursts read (flags [ntiles], S = 1);
+ * k3_bursts then gets a copy of the RSSI rows in which every OTHER tile reads 0 -- below the decoders' capture threshold,
+ * so a read that k3_spans did not announce changes what comes out. */
+static uint32_t *emu_span_flags = nullptr; static uint32_t emu_span_tiles = 0, emu_span_listed = 0;
+void wm_emu_k3_set_spans(uint32_t *flags, uint32_t ntiles) { emu_span_flags = flags; emu_span_tiles = ntiles; }
+unsigned wm_emu_k3_spans_listed(void) { return emu_span_listed; }
+
 long wm_emu_k3(const uint64_t *geo, const uint32_t *chips0, const uint32_t *chips1, const uint32_t *counts0, const uint32_t *counts1,
                const uint32_t *seen0, const uint32_t *seen1, const uint8_t *rssi, const uint32_t *pending, void *hdr_out, uint32_t hdr_cap,
                uint32_t *words_out, uint32_t words_cap, uint32_t *n_words_out, uint32_t max_blocks)
@@ -76,6 +83,28 @@ long wm_emu_k3(const uint64_t *geo, const uint32_t *chips0, const uint32_t *chip
     const uint32_t n_items = 0xFFFFFFFFu;                  /* the kernel reads the hit count itself, as in the product */
     const uint32_t n_items_host = 4 * g.S + std::min(n_hits, hdr_cap);
     gridDim = {std::max(1u, std::min((n_items_host + 3u) / 4u, max_blocks)), 1, 1};
+    std::vector<uint8_t> masked;
+    if (emu_span_flags) {
+        const uint32_t T = WM_K1_TILE2, nt = emu_span_tiles;
+        std::vector<uint32_t> list(nt);
+        uint32_t n_list = 0;
+        std::fill(emu_span_flags, emu_span_flags + nt, 0u);
+        for (uint32_t b = 0; b < gridDim.x; b++) {
+            blockIdx = {b, 0, 0};
+            block_emu::run_block(256, [&] { k3_spans(k3, T, nt, emu_span_flags, list.data(), &n_list); });
+        }
+        emu_span_listed = n_list;
+        for (uint32_t i = 0; i < n_list; i++) if (list[i] >= nt || !emu_span_flags[list[i]]) return -2;       /* listed = flagged, once each */
+        uint32_t flagged = 0;
+        for (uint32_t tl = 0; tl < nt; tl++) flagged += emu_span_flags[tl] != 0;
+        if (flagged != n_list) return -3;
+        masked.assign(rssi, rssi + 2 * (size_t)g.Mcap);
+        for (uint32_t ch = 0; ch < 2; ch++)
+            for (uint32_t tl = 0; tl < nt; tl++)
+                if (!((emu_span_flags[tl] >> ch) & 1u))
+                    for (uint32_t m = tl * T; m < std::min((tl + 1) * T, g.Mcap); m++) masked[(size_t)ch * g.Mcap + m] = 0;
+        k3.rssi = masked.data();
+    }
     for (uint32_t b = 0; b < gridDim.x; b++) {
         blockIdx = {b, 0, 0};
         block_emu::run_block(256, [&] { k3_bursts(k3, n_items); });

@@ -98,6 +98,13 @@ def test_random_configuration_matches_oracle(wm, oracle, case):
                 oc = truncate_runs(oc)
                 assert len(w) == len(oc), ("chips", ch, al)
                 assert np.array_equal(w & 0xFF, oc["value"]) and np.array_equal((w >> 8) & 0xFF, oc["rssi"]) and np.array_equal(pos, oc["sample"])
+    wants = [ref["text"] if s == c["n_streams"] - 1 else oracle.run(caps[s], oo)["text"] for s in range(c["n_streams"])]
     for s in range(c["n_streams"]):
-        want = ref["text"] if s == c["n_streams"] - 1 else oracle.run(caps[s], oo)["text"]
-        assert texts[s] == want, s
+        assert texts[s] == wants[s], s
+    # the same without the debug views, as the CLI and the batch API open their contexts: the default switches' kernel then
+    # computes the RSSI on demand (the tiles bursts touch, behind the framers) and falls back to the full pass where a
+    # silent stretch leaves a value unproven
+    with wm.Receiver(n_streams=c["n_streams"], max_push_bytes=max(c["push"], 4096), prefilter=c["prefilter"], keep_taps=False, **kw, **c["tune"]) as rx:
+        texts = rx.run(caps, push_bytes=c["push"])
+    for s in range(c["n_streams"]):
+        assert texts[s] == wants[s], ("without taps", s)

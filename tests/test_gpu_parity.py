@@ -285,6 +285,34 @@ def test_signal_followed_by_exact_silence_repairs_the_rssi_filter(wm, oracle, fl
         assert rx.run(cu8, push_bytes=1 << 16)[0] == ref["text"]
 
 
+@pytest.mark.parametrize("flags", [["-v"], ["-s", "-v"]], ids=lambda f: " ".join(f))
+def test_rssi_on_demand_falls_back_to_the_full_pass_where_it_cannot_prove_a_value(wm, oracle, flags):
+    """Contexts without debug views compute the RSSI only for the tiles bursts touch, every lane proving its start by a
+    bracket of two trajectories (wm_k1_demod.h).  Telegrams right behind exact silence / constant input sit on tiles whose
+    brackets stay open: the push is finished by the full pass (slow path), and the text is the oracle's either way."""
+    centres = dict(t1c1_center_khz=325.0, s1_center_khz=-325.0) if "-s" in flags else {}
+    sig, _ = wm.synth_capture(seed=77, n_samples=1 << 20, kinds=15, frames_per_s=400.0, amplitude=50.0, noise_sigma=0.0, **centres)
+    quiet = [np.full(21 * 4096 + 2 * 977 * 2, 128, np.uint8), np.full(64 * 4096, 127, np.uint8), np.tile(np.array([127, 128], np.uint8), 16 * 2048)]
+    parts = []
+    for k in range(12):                                      # signal and silence alternate; without noise the gaps between telegrams are constant input too
+        parts += [sig[k * 40 * 4096 + 2 * 131 * k: (k + 1) * 40 * 4096 + 2 * 131 * k], quiet[k % 3]]
+    cu8 = np.concatenate(parts)
+    cu8 = cu8[: cu8.size // 4096 * 4096]
+    ref = oracle.run(cu8, flags_to_oracle_opts(oracle, flags))
+    assert len(ref["text"].splitlines()) > 10
+    kw = flags_to_kwargs(flags)
+    slow = 0
+    for push in (cu8.size, 1 << 16, 4096 * 5):
+        with wm.Receiver(n_streams=1, max_push_bytes=push, keep_taps=False, **kw) as rx:
+            text = []
+            for off in range(0, cu8.size, push):
+                rx.push([cu8[off:off + push]])
+                text += [ln["text"] for ln in rx.lines()]
+                slow += rx.timing()["slow_path"]
+            assert "".join(text) == ref["text"], push
+    assert slow > 0                                         # the full pass was needed somewhere
+
+
 def test_very_long_exact_silence_does_not_overflow_the_chip_regions(wm, oracle):
     """A run of identical chips as long as the silence before it ends at one edge (the reference's
     loop emits them all: 131 072 chips after a million silent samples).  The kernel materialises

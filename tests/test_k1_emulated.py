@@ -135,3 +135,83 @@ def test_atan2_approximation_options_on_host(emu, oracle, wm, atan_mode, d, extr
     cu8 = wm.synth_capture(seed=900 + d + atan_mode, n_samples=1 << 16, fs_khz=FS[d], kinds=15, frames_per_s=200.0, amplitude=50.0, **kw)[0]
     cu8[cu8.size // 2: cu8.size // 2 + 20000] = 128                       # exact silence: x = y = 0
     check(emu, oracle, cu8, ["-v"] + (["-d", str(d)] if d != 2 else []) + extra, d, [4096 * 9, 4096 * 2], polyphase, atan_mode)
+
+
+def run_on_demand(emu, cu8, d, flags, push_bytes, rng, density):
+    """One capture push by push the RSSI-on-demand way: the first pass without RSSI, then the RSSI of randomly flagged tiles.
+    Returns dphi [2][M], rssi [2][M], read [2][M] bool (samples whose RSSI was asked for), the filter state per push, failures."""
+    emu.wm_emu_k1_od.restype = ctypes.c_long
+    emu.wm_emu_k1_od.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint64, ctypes.c_uint,
+                                 ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    total = cu8.size // 4096 * 4096
+    stride = (HIST + max(push_bytes) + SLACK + 255) // 256 * 256
+    row = np.full(stride, 128, np.uint8)
+    out_d, out_r, out_m, states, n0, off, k, fails = [[], []], [[], []], [[], []], [], 0, 0, 0, 0
+    while off < total:
+        nb = min(push_bytes[k % len(push_bytes)], total - off)
+        k += 1
+        row[HIST:HIST + nb] = cu8[off:off + nb]
+        n_new = nb // 2
+        M = (n0 + n_new) // d - n0 // d
+        ntiles = (M + 975) // 976
+        Mcap = max(256, (ntiles * 976 + 255) // 256 * 256)
+        dphi = np.zeros((2, Mcap), np.float32); rssi = np.full((2, Mcap), 0xEE, np.uint8); state = np.zeros(2, np.float32)
+        tf = (rng.random(ntiles) < density).astype(np.uint32) * rng.integers(1, 4, ntiles).astype(np.uint32)
+        r = emu.wm_emu_k1_od(row.ctypes.data, stride, 1, d, flags, n0, n_new, Mcap, dphi.ctypes.data, rssi.ctypes.data, state.ctypes.data, tf.ctypes.data)
+        assert r in (0, 1), r
+        fails += r
+        for ch in range(2):
+            read = np.repeat((tf >> ch) & 1, 976)[:M].astype(bool)
+            out_d[ch].append(dphi[ch, :M].copy()); out_r[ch].append(rssi[ch, :M].copy()); out_m[ch].append(read)
+        states.append((n0 // d + M - 1, state.copy(), r))
+        row[:HIST] = row[nb:nb + HIST].copy()
+        n0 += n_new; off += nb
+    return [np.concatenate(x) for x in out_d], [np.concatenate(x) for x in out_r], [np.concatenate(x) for x in out_m], states, fails
+
+
+@pytest.mark.parametrize("d,flags_cli", [(2, ["-v"]), (2, ["-v", "-s"]), (3, ["-v", "-d", "3"]), (5, ["-v", "-d", "5", "-s"])])
+def test_rssi_on_demand_matches_the_oracle_where_it_is_read(emu, oracle, wm, d, flags_cli):
+    """RS = 1 leaves the soft symbols as they were; RS = 2 fills in the RSSI of the flagged tiles, every lane proving the
+    state it starts from by a bracket of two trajectories (wm_k1_demod.h), and hands on the filter's state."""
+    rng = np.random.default_rng(77 + d)
+    cu8 = wm.synth_capture(seed=4242 + d, n_samples=1 << 17, kinds=15, frames_per_s=200.0, fs_khz=FS[d])[0]
+    ref = oracle.run(cu8, flags_to_oracle_opts(oracle, flags_cli), taps=True)
+    flags = F_ACCURATE | F_T1C1 | F_S1 | (F_SHIFT if "-s" in flags_cli else 0)
+    for pushes in ([1 << 18], [4096 * 5, 4096 * 16, 4096]):
+        dphi, rssi, read, states, fails = run_on_demand(emu, cu8, d, flags, pushes, rng, 0.3)
+        assert fails == 0                                   # noise and signal: every bracket closes inside the warm-up
+        for ch in (0, 1):
+            m = len(dphi[ch])
+            assert np.array_equal(dphi[ch].view(np.uint32), ref["dphi_fir"][ch][:m].view(np.uint32)), ("soft symbols", ch)
+            want = ref["rssi"][ch][:m].astype(np.uint32).astype(np.uint8)
+            assert read[ch].any() and np.array_equal(rssi[ch][read[ch]], want[read[ch]]), ("rssi", ch)
+            assert np.all(rssi[ch][~read[ch]] == 0xEE)      # nothing else was computed
+        for last, state, _ in states:
+            for ch in (0, 1):
+                assert state[ch].view(np.uint32) == np.float32(ref["rssi"][ch][last]).view(np.uint32), ("carried state", ch, last)
+
+
+def test_rssi_on_demand_reports_what_it_cannot_prove(emu, oracle, wm):
+    """Exact silence after a signal: constant input can keep the bracket open (the filter step has neighbouring fixed
+    points), and the true state decays through a hundred samples while a warm-up from zero is there at once.  The launch
+    must say so (the product then runs the full pass) -- and whatever it does NOT report must be right."""
+    rng = np.random.default_rng(5)
+    cu8 = wm.synth_capture(seed=99, n_samples=1 << 17, kinds=15, frames_per_s=200.0, amplitude=60.0)[0]
+    cu8[2 * 30000:2 * 60000] = 128                           # exact zero input
+    cu8[2 * 80000:2 * 100000:2] = 127; cu8[2 * 80000 + 1:2 * 100000:2] = 128      # constant, not zero
+    ref = oracle.run(cu8, flags_to_oracle_opts(oracle, ["-v"]), taps=True)
+    flags = F_ACCURATE | F_T1C1 | F_S1
+    seen_fail = 0
+    for pushes in ([1 << 18], [4096 * 7], [4096 * 3, 4096 * 11]):
+        dphi, rssi, read, states, fails = run_on_demand(emu, cu8, 2, flags, pushes, rng, 1.0)
+        seen_fail += fails
+        off = 0
+        for last, state, failed in states:
+            if not failed:
+                for ch in (0, 1):
+                    want = ref["rssi"][ch][off:last + 1].astype(np.uint32).astype(np.uint8)
+                    sel = read[ch][off:last + 1]
+                    assert np.array_equal(rssi[ch][off:last + 1][sel], want[sel]), ("rssi", ch, off, last)
+                    assert state[ch].view(np.uint32) == np.float32(ref["rssi"][ch][last]).view(np.uint32)
+            off = last + 1
+    assert seen_fail > 0

@@ -80,9 +80,16 @@ def framers_on_host(emu_clock, emu_rla, ref, seg1=32768, seg0=8192):
     return dict(geo=geo, chips=(chips0, chips1), counts=(counts0, counts1), seen=(seen0, seen1), Mcap=Mcap)
 
 
-def bursts_on_host(emu_k3, fr, rssi_rows, pending=None, max_blocks=256, decode=False):
+def bursts_on_host(emu_k3, fr, rssi_rows, pending=None, max_blocks=256, decode=False, spans=True):
     """decode=False: every burst as chips for the host decoders (hdr, words).  decode=True: as the product runs it --
-    bursts that end inside the push are decoded by the kernel: (hdr, words, pkts, bytes)."""
+    bursts that end inside the push are decoded by the kernel: (hdr, words, pkts, bytes).
+    spans (on in every test): RSSI on demand -- k3_spans flags the demodulation tiles whose RSSI the bursts read, and
+    k3_bursts then sees zeros in every other tile (k3_emu.cpp): what comes out must not change.  The flags of the last call
+    are kept in bursts_on_host.last_spans."""
+    emu_k3.wm_emu_k3_set_spans.argtypes = [ctypes.c_void_p, ctypes.c_uint]
+    flags = np.zeros((int(fr["geo"][0]) + 975) // 976, np.uint32) if spans else None
+    emu_k3.wm_emu_k3_set_spans(flags.ctypes.data if spans else None, flags.size if spans else 0)
+    bursts_on_host.last_spans = flags
     pend = np.zeros(4, np.uint32) if pending is None else np.asarray(pending, np.uint32)
     hdr = np.zeros(1 << 16, HDR); words = np.zeros(1 << 24, np.uint32); nw = ctypes.c_uint(0)
     emu_k3.wm_emu_k3_set_spill(*fr.get("spill", (None, 0, None, None, None)))
@@ -94,8 +101,9 @@ def bursts_on_host(emu_k3, fr, rssi_rows, pending=None, max_blocks=256, decode=F
     n = emu_k3.wm_emu_k3(fr["geo"].ctypes.data, fr["chips"][0].ctypes.data, fr["chips"][1].ctypes.data, fr["counts"][0].ctypes.data,
                          fr["counts"][1].ctypes.data, fr["seen"][0].ctypes.data, fr["seen"][1].ctypes.data, rssi_rows.ctypes.data,
                          pend.ctypes.data, hdr.ctypes.data, hdr.size, words.ctypes.data, words.size, ctypes.byref(nw), max_blocks)
-    assert n >= 0
+    assert n >= 0, n
     emu_k3.wm_emu_k3_set_decode(None, 0, None, None, 0)
+    emu_k3.wm_emu_k3_set_spans(None, 0)
     if decode:
         return hdr[:n], words[:nw.value], pkts[:npk.value], pbytes
     return hdr[:n], words[:nw.value]

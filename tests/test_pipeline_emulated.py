@@ -17,13 +17,19 @@ import test_k3_emulated as K3
 import test_rla_emulated as RE
 
 emu_k1, emu_clock, emu_rla, emu_k3, emu_need = K1.emu, CE.emu, RE.emu, K3.emu_k3, BN.emu
+K1_OD_ARGS = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint64, ctypes.c_uint, ctypes.c_uint,
+              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
 F_SHIFT, F_ACCURATE, F_DC, F_T1C1, F_S1, F_RLA, F_T2A = 1, 2, 4, 8, 16, 32, 64
 
 
 class HostPipeline:
     def __init__(self, libs, d=2, flags=F_ACCURATE | F_T1C1 | F_S1 | F_RLA | F_T2A, seg1=32768, seg0=8192, warm=(12288, 24576), lookback=1024,
-                 max_push=1 << 20, polyphase=0, gpu_decode=True):
+                 max_push=1 << 20, polyphase=0, gpu_decode=True, on_demand=None):
         self.polyphase = polyphase
+        # RSSI on demand, where the product uses it (wm_api.hip wmbus_open: default switches' kernel, d = 2..5, no debug taps)
+        eligible = not polyphase and 2 <= d <= 5 and (flags & (F_ACCURATE | F_T1C1 | F_S1)) == (F_ACCURATE | F_T1C1 | F_S1) and not flags & (128 | 256)
+        self.on_demand = eligible if on_demand is None else (on_demand and eligible)
+        self.od_pushes = self.od_fallbacks = 0
         self.gpu_decode = gpu_decode                              # as the product: bursts inside the push are decoded by k3_bursts
         self.k1, self.clk, self.rla, self.k3, self.dec = libs
         self.d, self.flags, self.seg1, self.seg0, self.warm, self.lookback = d, flags, seg1, seg0, warm, lookback
@@ -64,8 +70,25 @@ class HostPipeline:
         if M > 0:
             Mcap = max(256, ((M + 975) // 976 * 976 + 255) // 256 * 256)
             dphi = np.zeros((2, Mcap), np.float32); rssi = np.zeros((2, Mcap), np.uint8); err = ctypes.c_uint(0)
-            assert self.k1.wm_emu_k1(self.row.ctypes.data, self.stride, 1, d, self.flags & (3 | 128 | 256) | F_T1C1 | F_S1, self.n0, n_new, Mcap, dphi.ctypes.data,
-                                     rssi.ctypes.data, self.ema.ctypes.data, ctypes.byref(err), self.polyphase) >= 0 and err.value == 0
+            k1_flags = self.flags & (3 | 128 | 256) | F_T1C1 | F_S1
+            def k1_full():
+                assert self.k1.wm_emu_k1(self.row.ctypes.data, self.stride, 1, d, k1_flags, self.n0, n_new, Mcap, dphi.ctypes.data,
+                                         rssi.ctypes.data, self.ema.ctypes.data, ctypes.byref(err), self.polyphase) >= 0 and err.value == 0
+            def k1_on_demand(tile_flags):                       # the first pass without the RSSI + the RSSI of the flagged tiles; False: not provable
+                self.k1.wm_emu_k1_od.restype = ctypes.c_long
+                self.k1.wm_emu_k1_od.argtypes = K1_OD_ARGS
+                state = np.zeros(2, np.float32)
+                rssi[:] = 0
+                r = self.k1.wm_emu_k1_od(self.row.ctypes.data, self.stride, 1, d, k1_flags, self.n0, n_new, Mcap, dphi.ctypes.data, rssi.ctypes.data,
+                                         state.ctypes.data, tile_flags.ctypes.data)
+                assert r in (0, 1), r
+                if r == 0:
+                    self.ema[:] = state
+                return r == 0
+            if self.on_demand:
+                assert k1_on_demand(np.zeros((M + 975) // 976, np.uint32)) in (True, False)     # soft symbols (the last tile's RSSI comes with them here)
+            else:
+                k1_full()
             dphi[:, M:] = 0                                     # rows beyond M are scratch for the framers
             nseg1, cap1 = (M + self.seg1 - 1) // self.seg1, self.seg1 // 4 + 8
             bits = np.zeros((2, Mcap // 32), np.uint32); chips1 = np.zeros((2, nseg1, cap1), np.uint32); counts1 = np.zeros((2, nseg1), np.uint32)
@@ -93,6 +116,15 @@ class HostPipeline:
             pending = [self.decs[(ch, al)][1] for al in range(2) for ch in range(2)]          # [algo][chain]
             fr["spill"] = spill
             self.spilled = getattr(self, "spilled", 0) + int(nchain[:2 * nseg0].sum())
+            if self.on_demand:
+                # k3_spans on the settled chips (the RSSI plays no part in it), the listed tiles' RSSI, then the bursts on rows
+                # that hold nothing else; a tile that cannot be proven sends the push through the full pass, as in the product
+                K3.bursts_on_host(self.k3, fr, np.zeros_like(rssi), pending, decode=self.gpu_decode)
+                self.od_pushes += 1
+                if not k1_on_demand(K3.bursts_on_host.last_spans.copy()):
+                    self.od_fallbacks += 1
+                    k1_full()
+                dphi[:, M:] = 0
             if self.gpu_decode:
                 hdr, words, pkts, pbytes = K3.bursts_on_host(self.k3, fr, rssi, pending, decode=True)
                 lines = self.collect(hdr, words, pkts, pbytes)
@@ -162,7 +194,7 @@ class HostPipeline:
         return [r[4] for r in out]
 
 
-def run_capture(libs, cu8, pushes, **kw):
+def run_capture(libs, cu8, pushes, stats=None, **kw):
     p = HostPipeline(libs, **kw)
     text, off, k = [], 0, 0
     total = cu8.size // 4096 * 4096
@@ -170,6 +202,8 @@ def run_capture(libs, cu8, pushes, **kw):
         nb = min(pushes[k % len(pushes)], total - off)
         text += p.push(cu8[off:off + nb])
         off += nb; k += 1
+    if stats is not None:
+        stats["od_pushes"] = stats.get("od_pushes", 0) + p.od_pushes; stats["od_fallbacks"] = stats.get("od_fallbacks", 0) + p.od_fallbacks
     return "".join(text)
 
 
@@ -183,7 +217,10 @@ def test_bundled_capture_through_the_emulated_pipeline(libs, oracle, samples, pu
     cu8 = samples["samples2"][: 1 << 20]
     ref = oracle.run(cu8, flags_to_oracle_opts(oracle, ["-v"]))
     assert len(ref["text"].splitlines()) >= 2
-    assert run_capture(libs, cu8, pushes) == ref["text"]
+    st = {}
+    assert run_capture(libs, cu8, pushes, stats=st) == ref["text"]                 # RSSI on demand, as the product runs these switches
+    assert st["od_pushes"] > 0 and st["od_fallbacks"] == 0
+    assert run_capture(libs, cu8, pushes, on_demand=False) == ref["text"]          # the full pass (contexts with debug taps)
     assert run_capture(libs, cu8, pushes, gpu_decode=False) == ref["text"]        # every burst through the host decoders (WMBUS_GPU_DECODE=0)
 
 

@@ -65,7 +65,7 @@ fetch, write = per_kernel("pmc_fetch_size.csv"), per_kernel("pmc_write_size.csv"
 
 def family(kernel):
     """Kernel name -> the family its numbers are booked under, or None to skip: the list kernels (re-run lists) ride with
-    their first-pass kernels, the option / repair variant of K1 (k1_demod2<D, SHIFT, GEN = true, ..>: empty list launches in
+    their first-pass kernels, the RSSI-on-demand launch of K1 (k1_demod2<.., RS = 2>) is booked as "k1_rssi", the option / repair variant of K1 (k1_demod2<D, SHIFT, GEN = true, ..>: empty list launches in
     the bench) is left out."""
     k = kernel.replace("void ", "").split("(")[0].strip()
     base = k.split("<")[0]
@@ -73,6 +73,8 @@ def family(kernel):
         args = [a.strip() for a in k[k.index("<") + 1:k.rindex(">")].split(",")] if "<" in k else []
         if len(args) >= 3 and args[2] == "true":
             return None
+        if len(args) >= 5 and args[4] == "2":
+            return "k1_rssi"                             # RSSI on demand: the listed tiles' launch (the first pass is the RS = 1 instantiation)
     return {"k2_clock_list": "k2_clock", "k2_rla_list": "k2_rla"}.get(base, base)
 
 
@@ -106,7 +108,7 @@ if os.path.exists(sqp):
             "peak_how": "1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md: SIMD-32, v_fma_f32 2 cyc)",
             "kernels": {}}
     for k, d in per.items():
-        if not any(k.startswith(x) for x in ("k1_demod2", "k2_clock", "k2_rla", "k3_", "k2_verify")):
+        if not any(k.startswith(x) for x in ("k1_demod2", "k1_rssi", "k2_clock", "k2_rla", "k3_", "k2_verify")):
             continue
         valu["kernels"][k] = {"valu_wave_instr_per_step": d.get("SQ_INSTS_VALU", 0) / steps, "salu_per_step": d.get("SQ_INSTS_SALU", 0) / steps,
                               "lds_instr_per_step": d.get("SQ_INSTS_LDS", 0) / steps, "waves_per_step": d.get("SQ_WAVES", 0) / steps,
@@ -141,7 +143,7 @@ if n_k1:
         "algorithmic_bytes_per_input_sample": 2,
         "other_kernels_KB_per_step_as_reported": {},
     }
-    for pre in ("k2_clock", "k2_clock_rla", "k2_rla", "k3_scan", "k3_bursts"):
+    for pre in ("k1_rssi", "k2_clock", "k2_clock_rla", "k2_rla", "k3_scan", "k3_spans", "k3_bursts"):
         traffic["other_kernels_KB_per_step_as_reported"][pre + "_fetch"] = round(pick(fetch, pre)[1] / 2, 1)   # two passes per run
         traffic["other_kernels_KB_per_step_as_reported"][pre + "_write"] = round(pick(write, pre)[1] / 2, 1)
     o = traffic["other_kernels_KB_per_step_as_reported"]
