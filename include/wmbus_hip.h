@@ -62,7 +62,9 @@ typedef struct wmbus_cfg {
     unsigned warmup_s1;         /* IIR warm-up before a segment, S1 chain            */
     unsigned rla_lookback;      /* speculative run-length lookback                   */
     unsigned host_threads;      /* host decoder threads, 0 = auto                    */
-    int keep_taps;              /* 1: wmbus_read_tap may be used (the debug views of the last push) */
+    int keep_taps;              /* 1: wmbus_read_tap may be used (the debug views of the last push).  0: no views -- the context then
+                                   computes the RSSI only for the samples a packet decoder reads (the default switches at
+                                   decimation 2 ... 5): same datagrams, fewer instructions */
     /* Low-pass in front of the decimator.  BOXCAR = the moving averages the reference's main()
      * runs (rtl_wmbus.c:1333-1344): what every reference binary computes, bit for bit.
      * POLYPHASE = lp_ppf_butter_1600kHz_160kHz_200kHz (rtl_wmbus.c:258-294 over ppf.h:46-59), which
