@@ -111,7 +111,7 @@ typedef struct wmbus_timing {
     float demod_ms;             /* front end + discriminator + FIR + RSSI kernel      */
     float clock_ms;             /* IIR clock recovery + time2 framer (incl. re-runs)  */
     float rla_ms;               /* run-length framer (incl. re-runs)                  */
-    float gather_ms;            /* burst extraction                                   */
+    float gather_ms;            /* burst extraction (and, without debug views, the RSSI of the tiles the bursts touch) */
     float d2h_ms;               /* burst copy to pinned host memory                   */
     float gpu_total_ms;         /* first kernel start -> last copy done               */
     float host_decode_ms;       /* packet decoders + formatting (wall clock)          */
@@ -120,7 +120,8 @@ typedef struct wmbus_timing {
     uint64_t bursts;            /* candidate bursts handed to the host decoders       */
     float turn_wait_ms;         /* host time spent waiting for this process's turn in the demodulation kernel */
     unsigned warnings;          /* WMBUS_WARN_* of this push (the push succeeded)     */
-    unsigned slow_path;         /* 1: hand-off verification needed more rounds than run on the device unattended */
+    unsigned slow_path;         /* 1: hand-off verification needed more rounds than run on the device unattended, or an
+                                   RSSI value computed on demand could not be proven and the push took the full pass */
 } wmbus_timing;
 
 /* The reference never gives up on an input (rtl_wmbus.c:729-803 has no bound); neither does a push.  When an
