@@ -141,6 +141,9 @@ def test_bursts_are_the_oracles_chips_after_every_access_code(emu_k3, emu_clock,
         rssi[ch, :ref["m"]] = ref["rssi"][ch].astype(np.uint32).astype(np.uint8)
     hdr, words = bursts_on_host(emu_k3, fr, rssi)
     assert not (hdr["flags"] & 1).any()                    # nothing pending: no continuation bursts
+    sp = bursts_on_host.last_spans                          # RSSI on demand: the tiles k3_spans listed; every other tile read as zero just now
+    print("tiles listed per chain: %d / %d of %d" % (int((sp & 1).astype(bool).sum()), int((sp & 2).astype(bool).sum()), sp.size))
+    assert sp[-1] == 3 and (sp & 3).astype(bool).any() and not ((sp & 1).astype(bool).all() and (sp & 2).astype(bool).all())
     n_checked = 0
     for ch in (0, 1):
         for al in (0, 1):
