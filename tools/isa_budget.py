@@ -6,7 +6,7 @@
                                                                                   either one chain's EMA or half the 11-tap FIR) + certification
 Segment 3 holds every role's code once; a wave executes its own role only, so the dynamic count per wave is given
 separately from the hardware counter pass (profiles/valu.json).
-usage: tools/isa_budget.py > profiles/r03_k1_isa_budget.txt      (compiles wm_api.hip with --save-temps into /tmp)"""
+usage: tools/isa_budget.py > profiles/r04_k1_isa_budget.txt      (compiles wm_api.hip with --save-temps into /tmp)"""
 import collections
 import os
 import re
@@ -31,7 +31,7 @@ GROUPS = [("f32 mul / add / sub (VOP2)", r"v_(mul|add|sub|subrev)_f32_e32$"), ("
 
 def budget(name):
     i = asm.index(name + ":")
-    j = asm.index("s_endpgm", i)
+    j = asm.index(".Lfunc_end", i)                  # the whole function: a kernel may hold several s_endpgm (early returns)
     seg, out = 0, collections.defaultdict(collections.Counter)
     for ln in asm[i:j].splitlines():
         t = ln.strip()
@@ -59,8 +59,11 @@ def budget(name):
 
 
 NAMES = {0: "stage 0", 1: "stage A", 2: "mag rows", 3: "B (all roles)+certify"}
-for title, sym in (("k1_demod2<2, false, false, false>  -- the default switches' first pass, bit-exact", "_Z9k1_demod2ILi2ELb0ELb0ELb0EEv6K1Args"),
-                   ("k1_demod2<2, false, false, true>   -- the same in tolerance mode (polynomial arctangent, FMA low-passes)", "_Z9k1_demod2ILi2ELb0ELb0ELb1EEv6K1Args")):
+for title, sym in (("k1_demod2<2, false, false, false, 0>  -- the default switches' first pass, bit-exact, RSSI of every sample (contexts with debug views)", "_Z9k1_demod2ILi2ELb0ELb0ELb0ELi0EEv6K1Args"),
+                   ("k1_demod2<2, false, false, false, 1>  -- the same without the RSSI (round 4: RSSI on demand; all of stage B is every wave's)", "_Z9k1_demod2ILi2ELb0ELb0ELb0ELi1EEv6K1Args"),
+                   ("k1_demod2<2, false, false, false, 2>  -- the RSSI of one listed tile (stage B = bracketed warm-ups + 16 samples, waves 0 and 1 only)", "_Z9k1_demod2ILi2ELb0ELb0ELb0ELi2EEv6K1Args"),
+                   ("k1_demod2<2, false, false, true, 0>   -- tolerance mode (polynomial arctangent, FMA low-passes), RSSI of every sample", "_Z9k1_demod2ILi2ELb0ELb0ELb1ELi0EEv6K1Args"),
+                   ("k1_demod2<2, false, false, true, 1>   -- tolerance mode without the RSSI", "_Z9k1_demod2ILi2ELb0ELb0ELb1ELi1EEv6K1Args")):
     b = budget(sym)
     print(title)
     keys = ["VALU total"] + [g for g, _ in GROUPS] + sorted({k for s in b.values() for k in s if k.startswith("other")}) + ["SALU total", "LDS total", "VMEM total"]
@@ -73,4 +76,8 @@ print("stage A per thread = 4 decimated samples x 2 chains: 8 discriminators (co
       "reduction, 11-term polynomial, quadrant fix-up: 71 instructions each in the exact kernel) + 8 magnitudes (exact square root: 13 each) + the packed-\n"
       "int16 boxcars.  Stage B is listed with all four wave roles; dynamically a wave runs 4 x 92 (exact) or 4 x 46 (FMA) instructions of the 46-tap FIR\n"
       "plus EITHER one chain's RSSI EMA (48 steps x 3 + 16 byte packs) OR half of the 11-tap FIR (2 x 4 x 22).  Measured per wave (SQ_INSTS_VALU /\n"
-      "SQ_WAVES, profiles/valu.json): see DESIGN.md section 8.")
+      "SQ_WAVES, profiles/valu.json): see DESIGN.md section 8.\n"
+      "RS = 1 (no RSSI): three barriers, so the columns are stage 0, stage A and stage B; stage B holds the 11-tap filter twice (two of the four waves\n"
+      "run it before the 46-tap one, two after): a wave executes 4 x 92 + 4 x 22 of it, a thread 85 + 634 + ~470 = ~1 190 in all.\n"
+      "RS = 2 (the RSSI of a listed tile): the list loop's own barrier shifts the columns by one; its total is what counts (580 VALU static;\n"
+      "waves 2 and 3 skip the EMA).")
