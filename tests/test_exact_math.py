@@ -16,3 +16,32 @@ def test_atan2f_restatement_matches_libm(tmp_path):
         pytest.skip("host libm's atan2f is not the glibc 2.35 generation the exact path restates: " + p.stdout.strip().splitlines()[-1])
     assert p.returncode == 0, p.stdout
     assert " 0 mismatches" in p.stdout and "host libm differs on 0" in p.stdout
+
+
+def test_the_rssi_filter_step_is_monotone_in_its_state():
+    import numpy as np
+    """What RSSI on demand rests on (rtl-wmbus_amd/csrc/wm_k1_demod.h, WM_EMA_UPPER): the filter step
+    y -> fl(fl(al * x) + fl(be * y)) (rtl_wmbus.c:475-495, every operation rounded separately) never reverses the order of two
+    states, so a trajectory started from 0 and one started from 256 bracket the true one for as long as they differ, and where
+    they meet bit for bit the true one is there too.  Also: from any state in [0, 256] the step stays in [0, 256] for
+    magnitudes up to 181 (the largest a cu8 sample pair can produce), and on noise-like input the two trajectories DO meet
+    within the kernel's 32-sample warm-up."""
+    rng = np.random.default_rng(2024)
+    al = np.float32(0.6789); be = np.float32(1.0) - al
+    n = 1 << 20
+    x = rng.uniform(0, 181, n).astype(np.float32)
+    y1 = rng.uniform(0, 256, n).astype(np.float32)
+    y2 = np.nextafter(y1, np.float32(np.inf))                           # neighbours: where monotonicity is tightest
+    step = lambda xx, yy: (al * xx).astype(np.float32) + (be * yy).astype(np.float32)
+    s1, s2 = step(x, y1), step(x, y2)
+    assert np.all(s1 <= s2)
+    y3 = np.maximum(y1, rng.uniform(0, 256, n).astype(np.float32))
+    assert np.all(step(x, y1) <= step(x, y3)) and np.all(step(x, y3) <= np.float32(256.0)) and np.all(s1 >= 0)
+    # bracket closure on noise-like magnitudes (Rayleigh, as the filtered noise of the bench captures)
+    mags = rng.rayleigh(3.0, (4096, 32)).astype(np.float32)
+    lo = np.zeros(4096, np.float32); hi = np.full(4096, 256.0, np.float32)
+    closed_at = np.full(4096, 99)
+    for k in range(32):
+        lo, hi = step(mags[:, k], lo), step(mags[:, k], hi)
+        closed_at = np.where((closed_at == 99) & (lo.view(np.uint32) == hi.view(np.uint32)), k + 1, closed_at)
+    assert closed_at.max() <= 32 and np.median(closed_at) <= 26
