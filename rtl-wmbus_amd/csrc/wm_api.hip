@@ -155,6 +155,8 @@ struct wmbus_ctx {
     bool rs_od = false, rs_full_now = false;            /* rs_full_now: this push has fallen back to the full pass */
     bool rs_this = false;                               /* this push runs on demand (a context whose bursts cover most of its tiles takes the full pass for a while) */
     unsigned rs_pause = 0;                              /* pushes left before on demand is tried again */
+    bool k1_big = false;                                /* the first pass without the RSSI runs on 2000-sample tiles of 512 threads (decimation 2, no -s) */
+    uint32_t k1_tail_pm = 60;                           /* per mille of a push's tiles behind the early hand-over of the K1 turn (enqueue_front_impl) */
     uint32_t *d_rs_flags = nullptr, *d_rs_list = nullptr;   /* [ntiles_cap][S] chains read per (tile, capture); the tiles listed */
     uint32_t *d_ckpt = nullptr; uint32_t nck = 0;       /* clock kernel checkpoints [2][S][nseg_cap][nck][16] */
     uint32_t *d_bad = nullptr;                          /* [2][nseg_cap[0]][S] the run-length verifier's verdict per segment (K2Args.bad) */
@@ -266,23 +268,25 @@ __global__ __launch_bounds__(256) void k_sum_counts(WmPush g, const uint32_t *co
     }
 }
 
-template <int D, bool SHIFT, bool GEN, bool FAST = false, int RS = 0> int launch_k1v3(wmbus_ctx *c, const K1Args &a, dim3 grid, hipStream_t st)
+template <int D, bool SHIFT, bool GEN, bool FAST = false, int RS = 0, int NT = 256> int launch_k1v3(wmbus_ctx *c, const K1Args &a, dim3 grid, hipStream_t st)
 {
-    const size_t sm = K1Geo::smem(D ? D : (int)c->d, SHIFT);
+    const size_t sm = K1GeoT<NT>::smem(D ? D : (int)c->d, SHIFT);
     static std::atomic<size_t> set_for[WM_MAX_DEVICES];     /* per device: the attribute call is not free, a push makes several launches */
     if (set_for[c->cfg.device] < sm) {
-        HIPCHK(c, hipFuncSetAttribute((const void *)k1_demod2<D, SHIFT, GEN, FAST, RS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+        HIPCHK(c, hipFuncSetAttribute((const void *)k1_demod2<D, SHIFT, GEN, FAST, RS, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
         set_for[c->cfg.device] = sm;
     }
-    hipLaunchKernelGGL((k1_demod2<D, SHIFT, GEN, FAST, RS>), grid, dim3(256), sm, st, a);
+    hipLaunchKernelGGL((k1_demod2<D, SHIFT, GEN, FAST, RS, NT>), grid, dim3(NT), sm, st, a);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
 
 /* the default switches' first pass runs the kernel without the option paths (k1_demod2<.., GEN = false>) */
-template <int D, bool SHIFT> int launch_k1v2(wmbus_ctx *c, const K1Args &a, dim3 grid, hipStream_t st, int rs)
+template <int D, bool SHIFT> int launch_k1v2(wmbus_ctx *c, const K1Args &a, dim3 grid, hipStream_t st, int rs, bool big)
 {
     const uint32_t need = WM_F_ACCURATE | WM_F_T1C1 | WM_F_S1, never = WM_F_APPROX1 | WM_F_APPROX2;
+    if (D == 2 && !SHIFT && rs == 1 && big)      /* ... on the 2000-sample tile of 512 threads (the caller's grid counts THOSE tiles; wmbus_ctx.k1_big) */
+        return c->cfg.tolerance_mode ? launch_k1v3<2, false, false, true, 1, 512>(c, a, grid, st) : launch_k1v3<2, false, false, false, 1, 512>(c, a, grid, st);
     if (D != 0 && rs == 1)                       /* RSSI on demand (wmbus_open has checked the switches): the first pass without it */
         return c->cfg.tolerance_mode ? launch_k1v3<D, SHIFT, false, true, 1>(c, a, grid, st) : launch_k1v3<D, SHIFT, false, false, 1>(c, a, grid, st);
     if (D != 0 && rs == 2) return launch_k1v3<D, SHIFT, false, false, 2>(c, a, grid, st);     /* ... and the listed tiles' RSSI (the same in tolerance mode) */
@@ -324,12 +328,7 @@ __global__ void k_selftest(const float *a, const float *b, float *o_sqrt, float 
  * memory-bound framer kernels is complementary).  The order is kept on the GPU: a context's K1 waits for the event
  * behind the K1 launched before it, so no host thread sits in the way (a host-side turn held across the launches of
  * everything behind K1 made the turn 2.9 ms longer than the kernel). */
-/* WMBUS_K1_STREAM=1 (experiment, off): the order is that of ONE shared HIP stream per device which carries nothing but the
- * contexts' demodulation kernels -- the idea was to save the 100-190 us an event wait between two queues costs per hand-off
- * (r03 trace: median gap 128 us between one context's K1 and the next's).  Measured in round 4: 128.8 / 128.3 against
- * 148.6 / 148.9 Gsamples/s -- every K1 then needs TWO cross-queue hand-offs (input ready -> K1 stream, K1 done -> the
- * context's stream) and the ninth stream takes a hardware queue of its own.  The event chain stays. */
-struct K1Chain { std::mutex m; hipEvent_t last = nullptr; const wmbus_ctx *owner = nullptr; hipStream_t stream = nullptr; };
+struct K1Chain { std::mutex m; hipEvent_t last = nullptr; const wmbus_ctx *owner = nullptr; };
 K1Chain k1_chain[WM_MAX_DEVICES];
 
 /* One HIP stream per receiver context (two with cfg.input_windows = 2); ROCm maps streams onto GPU_MAX_HW_QUEUES hardware
@@ -509,6 +508,10 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
         static const bool rs_full = getenv("WMBUS_RSSI_FULL") && atoi(getenv("WMBUS_RSSI_FULL")) != 0;
         c->rs_od = !rs_full && !cfg->keep_taps && cfg->prefilter != WMBUS_PREFILTER_POLYPHASE && c->d >= 2 && c->d <= 5 &&
                    (c->flags & need) == need && !(c->flags & never);
+        /* the larger tile of the first pass: decimation 2 without -s (the LDS of a 512-thread block at d >= 3 or with the -s staging
+         * would cost more occupancy than the halo saves) */
+        c->k1_big = c->rs_od && c->d == 2 && !(c->flags & WM_F_SHIFT) && !(getenv("WMBUS_K1_NT") && atoi(getenv("WMBUS_K1_NT")) == 256);
+        c->k1_tail_pm = cfg->tolerance_mode ? 0u : 60u;
         if (c->rs_od) { A(dalloc(&c->d_rs_flags, (size_t)c->ntiles_cap * c->S)); A(dalloc(&c->d_rs_list, (size_t)c->ntiles_cap * c->S)); }
     }
     const size_t stw[2] = {sizeof(WmRlaState), sizeof(WmClkState)};
@@ -660,16 +663,16 @@ static void *st_carry(wmbus_ctx *c, int algo, bool out)
     return (char *)c->d_st_carry[algo] + (size_t)(c->carry_in ^ (out ? 1u : 0u)) * 2 * c->S * w;
 }
 
-static int launch_k1_any(wmbus_ctx *c, const K1Args &k1, dim3 grid, hipStream_t st = nullptr, int rs = 0)    /* rs: 0 everything, 1 no RSSI, 2 RSSI of the listed tiles */
+static int launch_k1_any(wmbus_ctx *c, const K1Args &k1, dim3 grid, hipStream_t st = nullptr, int rs = 0, bool big = false)    /* rs: 0 everything, 1 no RSSI, 2 RSSI of the listed tiles; big: grid.x counts 2000-sample tiles (rs = 1 only) */
 {
     const bool sh = c->flags & WM_F_SHIFT;
     if (!st) st = c->stream;
     if (c->cfg.prefilter == WMBUS_PREFILTER_POLYPHASE) return launch_k1_ppf(c, k1, grid, st);
-    if (c->d == 2) return sh ? launch_k1v2<2, true>(c, k1, grid, st, rs) : launch_k1v2<2, false>(c, k1, grid, st, rs);
-    if (c->d == 3) return sh ? launch_k1v2<3, true>(c, k1, grid, st, rs) : launch_k1v2<3, false>(c, k1, grid, st, rs);
-    if (c->d == 4) return sh ? launch_k1v2<4, true>(c, k1, grid, st, rs) : launch_k1v2<4, false>(c, k1, grid, st, rs);
-    if (c->d == 5) return sh ? launch_k1v2<5, true>(c, k1, grid, st, rs) : launch_k1v2<5, false>(c, k1, grid, st, rs);
-    return sh ? launch_k1v2<0, true>(c, k1, grid, st, rs) : launch_k1v2<0, false>(c, k1, grid, st, rs);      /* any other rate */
+    if (c->d == 2) return sh ? launch_k1v2<2, true>(c, k1, grid, st, rs, false) : launch_k1v2<2, false>(c, k1, grid, st, rs, big);
+    if (c->d == 3) return sh ? launch_k1v2<3, true>(c, k1, grid, st, rs, false) : launch_k1v2<3, false>(c, k1, grid, st, rs, false);
+    if (c->d == 4) return sh ? launch_k1v2<4, true>(c, k1, grid, st, rs, false) : launch_k1v2<4, false>(c, k1, grid, st, rs, false);
+    if (c->d == 5) return sh ? launch_k1v2<5, true>(c, k1, grid, st, rs, false) : launch_k1v2<5, false>(c, k1, grid, st, rs, false);
+    return sh ? launch_k1v2<0, true>(c, k1, grid, st, rs, false) : launch_k1v2<0, false>(c, k1, grid, st, rs, false);      /* any other rate */
 }
 
 /* EMA hand-offs between tiles (k1_verify), the first uncertified tile of every row into the repair list (k1_collect),
@@ -857,49 +860,34 @@ static int enqueue_front_impl(wmbus_ctx *c, size_t nbytes)
         if (c->rs_pause) c->rs_pause--;
         c->k1a = K1Args{g, c->d_dphi, c->d_rssi, c->d_lut, c->d_lut + 32 * WM_MAX_DECIM, c->d_ema_head, c->d_ema_tail, ntiles, c->d_scalars + SC_ERR,
                         nullptr, ema_carry(c, false), nullptr, 0u, c->d_rs_flags, ema_carry(c, true), c->d_scalars + SC_RS_FAIL};
-        static const int turns = getenv("WMBUS_K1_TURNS") ? atoi(getenv("WMBUS_K1_TURNS")) : 1;      /* 0: no order (A/B) */
-        static const int k1_shared = getenv("WMBUS_K1_STREAM") ? atoi(getenv("WMBUS_K1_STREAM")) : 0;   /* 1: one shared stream carries every context's K1 (r04 A/B: -13 %) */
         int rc;
         {
             K1Chain &kc = k1_chain[c->cfg.device];
-            std::unique_lock<std::mutex> lk(kc.m, std::defer_lock);
-            if (turns) lk.lock();
-            if (turns && k1_shared) {
-                if (!kc.stream) HIPCHK(c, hipStreamCreateWithFlags(&kc.stream, hipStreamNonBlocking));
-                HIPCHK(c, hipEventRecord(c->ev_ready, c->stream));
-                HIPCHK(c, hipStreamWaitEvent(kc.stream, c->ev_ready, 0));
-                HIPCHK(c, hipEventRecord(c->ev[3], kc.stream));
-                rc = launch_k1_any(c, c->k1a, dim3(ntiles, c->S), kc.stream, c->rs_this ? 1 : 0);
+            std::lock_guard<std::mutex> lk(kc.m);
+            if (kc.last && kc.owner != c) HIPCHK(c, hipStreamWaitEvent(c->stream, kc.last, 0));
+            HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+            /* The hand-over of the turn costs 0.15-0.2 ms (the next context's stream sits in an event wait on another
+             * hardware queue; r03 trace: median 128 us between one K1 and the next, eight times per step = 5 % of it).
+             * So the turn is handed over EARLY: a push's tiles leave in two launches, the event the next context waits for
+             * lies behind the first, and the last k1_tail_pm per mille of the tiles run while the hand-over is under
+             * way -- beside the head of the next context's K1 at most.
+             * r04 A/B: exact 152.5 / 153.2 against 149.1 / 150.1 Gsamples/s with 60 per mille (30: 151.6 / 152.0, 120: 151.0 / 152.3, 250:
+             * 148.9 / 147.4); tolerance mode, whose K1 is a third of the length, 170.1 / 171.9 against 171.0 / 173.0: off there */
+            const bool big = c->rs_this && c->k1_big;            /* the first pass without the RSSI on 2000-sample tiles (wm_k1_demod.h K1GeoT) */
+            const uint32_t T1 = big ? (uint32_t)WM_K1_TILE_BIG : T, nt1 = (g.M + T1 - 1) / T1;
+            const uint32_t n_tail = std::min(nt1 - 1u, (uint32_t)((uint64_t)nt1 * c->k1_tail_pm / 1000u));
+            K1Args k1 = c->k1a;
+            const int rs = c->rs_this ? 1 : 0;
+            rc = launch_k1_any(c, k1, dim3(nt1 - n_tail, c->S), nullptr, rs, big);
+            if (rc) return rc;
+            if (n_tail) {
+                HIPCHK(c, hipEventRecord(c->ev_turn, c->stream));
+                k1.tile0 = nt1 - n_tail;
+                rc = launch_k1_any(c, k1, dim3(n_tail, c->S), nullptr, rs, big);
                 if (rc) return rc;
-                HIPCHK(c, hipEventRecord(c->ev[4], kc.stream));
-                HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev[4], 0));
-                kc.last = c->ev[4]; kc.owner = c;
-            } else {
-                if (turns && kc.last && kc.owner != c) HIPCHK(c, hipStreamWaitEvent(c->stream, kc.last, 0));
-                HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-                /* The hand-over of the turn costs 0.15-0.2 ms (the next context's stream sits in an event wait on another
-                 * hardware queue; r03 trace: median 128 us between one K1 and the next, eight times per step = 5 % of it).
-                 * So the turn is handed over EARLY: a push's tiles leave in two launches, the event the next context waits for
-                 * lies behind the first, and the last WMBUS_K1_TAIL per mille of the tiles run while the hand-over is under
-                 * way -- beside the head of the next context's K1 at most. */
-                static const int tail_env = getenv("WMBUS_K1_TAIL") ? atoi(getenv("WMBUS_K1_TAIL")) : -1;
-                /* r04 A/B: exact 152.5 / 153.2 against 149.1 / 150.1 Gsamples/s with 60 per mille (30: 151.6 / 152.0, 120: 151.0 / 152.3, 250:
-                 * 148.9 / 147.4); tolerance mode, whose K1 is a third of the length, 170.1 / 171.9 against 171.0 / 173.0: off there */
-                const uint32_t tail_pm = tail_env >= 0 ? (uint32_t)tail_env : c->cfg.tolerance_mode ? 0u : 60u;
-                const uint32_t n_tail = turns ? std::min(ntiles - 1u, (uint32_t)((uint64_t)ntiles * tail_pm / 1000u)) : 0u;
-                K1Args k1 = c->k1a;
-                const int rs = c->rs_this ? 1 : 0;
-                rc = launch_k1_any(c, k1, dim3(ntiles - n_tail, c->S), nullptr, rs);
-                if (rc) return rc;
-                if (n_tail) {
-                    HIPCHK(c, hipEventRecord(c->ev_turn, c->stream));
-                    k1.tile0 = ntiles - n_tail;
-                    rc = launch_k1_any(c, k1, dim3(n_tail, c->S), nullptr, rs);
-                    if (rc) return rc;
-                }
-                HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
-                if (turns) { kc.last = n_tail ? c->ev_turn : c->ev[4]; kc.owner = c; }
             }
+            HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+            kc.last = n_tail ? c->ev_turn : c->ev[4]; kc.owner = c;
         }
         /* Everything behind K1 is enqueued while it runs -- no step of a push waits for the host any more:
          * hand-off verification makes its first rounds on the device (counters per round), K3 reads its item
@@ -1447,6 +1435,21 @@ int wmbus_selftest_math(int device, const float *a, const float *b, float *o_sqr
     for (auto &p : d) hipFree(p);
     return rc;
 }
+
+#ifdef WM_K1_STAMPS
+/* -DWM_K1_STAMPS builds only (tools/gpu_k1_stamps.py): the stage intervals the demodulation kernel's waves have added up
+ * (wm_k1_demod.h), optionally cleared. */
+int wmbus_debug_k1_stamps(unsigned long long *out8, int reset)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return WMBUS_EDEVICE;
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(wm_k1_stamp_acc), 8 * sizeof(unsigned long long)) != hipSuccess) return WMBUS_EDEVICE;
+    if (reset) {
+        const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(wm_k1_stamp_acc), z, sizeof z) != hipSuccess) return WMBUS_EDEVICE;
+    }
+    return WMBUS_OK;
+}
+#endif
 
 }  // extern "C"
 

@@ -206,6 +206,24 @@ WM_HD void wm_atan_tab_word(int k, float *tab)        /* fills word k of the tab
     }
 }
 
+/* The same table as bit patterns, for a kernel that wants it with ONE coalesced load (word k by lane k) instead of
+ * computing it: the branchy generator above, inlined at the head of the demodulation kernel, cost the first wave of every
+ * block six global loads one after the other (the constant arrays A .. lo), each behind an s_waitcnt vmcnt(0), before
+ * the block's input loads were even issued (round 5, read off the ISA).  tests/exact_math_check.c holds the two against
+ * each other word for word. */
+#if defined(__HIPCC__)
+__device__
+#endif
+static const uint32_t WM_ATAN_TAB_BITS[WM_ATAN_TAB_WORDS] = {
+    0x3f800000u, 0x00000000u, 0x00000000u, 0x3f800000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u,
+    0x40000000u, 0xbf800000u, 0x3f800000u, 0x40000000u, 0x3eed6338u, 0x31ac3769u, 0x00000000u, 0x00000000u,
+    0x3f800000u, 0xbf800000u, 0x3f800000u, 0x3f800000u, 0x3f490fdau, 0x33222168u, 0x00000000u, 0x00000000u,
+    0x3f800000u, 0xbfc00000u, 0x3fc00000u, 0x3f800000u, 0x3f7b985eu, 0x33140fb4u, 0x00000000u, 0x00000000u,
+    0x00000000u, 0xbf800000u, 0x3f800000u, 0x00000000u, 0x3fc90fdau, 0x33a22168u, 0x00000000u, 0x00000000u,
+    0x01010100u, 0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u, 0x02020201u, 0x02020202u, 0x02020202u,
+    0x02020202u, 0x02020202u, 0x02020202u, 0x03020202u, 0x03030303u, 0x03030303u, 0x03030303u, 0x03030303u,
+    0x03030303u, 0x03030303u, 0x03030303u, 0x03030303u, 0x04040404u, 0x04040404u, 0x04040404u, 0x04040404u};
+
 WM_HD float wm_copysign_bits(float mag, uint32_t sign_src) { return wm_u2f((wm_f2u(mag) & 0x7fffffffu) | (sign_src & 0x80000000u)); }
 
 WM_HD float wm_atan2f_tab(float y, float x, const float *tab)

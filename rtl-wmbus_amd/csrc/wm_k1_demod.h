@@ -5,6 +5,23 @@
 
 typedef short wm_s2 __attribute__((ext_vector_type(2)));
 
+/* -DWM_K1_STAMPS (tools/gpu_k1_stamps.py, never in the product build): every wave of the first pass without the RSSI reads
+ * the shader clock (s_memtime) at its stage boundaries and adds the five intervals to wm_k1_stamp_acc -- stage 0 (input
+ * loads + conversion), the wait at the first barrier, stage A, the wait at the second barrier, stage B -- plus [5] the
+ * waves counted and [6] the whole tile as its first wave saw it.  profiles/r05_k1_stage_cycles.txt is made from it. */
+#if defined(WM_K1_STAMPS) && defined(__HIPCC__)
+__device__ unsigned long long wm_k1_stamp_acc[8];
+#define WM_K1_STAMP_DECL unsigned long long k1_t[6] = {0, 0, 0, 0, 0, 0}
+#define WM_K1_STAMP(i) do { if (RS == 1) k1_t[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define WM_K1_STAMP_END(tid) do { if (RS == 1 && ((tid) & 63) == 0) { \
+        for (int i_ = 0; i_ < 5; i_++) atomicAdd(&wm_k1_stamp_acc[i_], k1_t[i_ + 1] - k1_t[i_]); \
+        atomicAdd(&wm_k1_stamp_acc[5], 1ull); if ((tid) == 0) atomicAdd(&wm_k1_stamp_acc[6], k1_t[5] - k1_t[0]); } } while (0)
+#else
+#define WM_K1_STAMP_DECL
+#define WM_K1_STAMP(i)
+#define WM_K1_STAMP_END(tid)
+#endif
+
 /* ---------------------------------------------------------------------------------------------
  * Filter constants (rtl_wmbus.c:372, 384, 338-341, 353-356) as decimal literals, converted by the
  * compiler to the same floats the reference's arrays hold.
@@ -87,8 +104,12 @@ struct K1Args {
  * ===========================================================================================*/
 /* D = the decimation as a compile-time constant (2..5: the rates rtl-wmbus documents) or 0: read it
  * from the push at run time (any 1..WM_MAX_DECIM; same code with loops instead of unrolled runs). */
-struct K1Geo {
-    static constexpr int T = WM_K1_TILE2, NA = T + WM_K1_HALO;
+/* NT = threads per block: a tile is 4 NT - 48 decimated samples (976 on 256 threads; 2000 on 512, round 5: the halo --
+ * 48 samples of discriminators computed again by the next tile -- is 2.4 % of the tile instead of 4.9 %, and the blocks
+ * of a launch are half as many).  Only the first pass without the RSSI (RS = 1) knows the larger tile: it writes nothing
+ * per tile, so the tile size of the RSSI launches, the repair walk and k3_spans stays WM_K1_TILE2. */
+template <int NT> struct K1GeoT {
+    static constexpr int T = 4 * NT - WM_K1_HALO, NA = T + WM_K1_HALO;
     static constexpr int YD = NA + 8, YM = NA + NA / 16 + 4;
     __host__ __device__ static constexpr int nstg(int d) { return (NA * d + 16 + 8 + 7) / 8 * 8 + 8; }   /* 8 slack words in front */
     __host__ __device__ static constexpr int U(int d, bool shift)
@@ -97,6 +118,9 @@ struct K1Geo {
     }
     static constexpr size_t smem(int d, bool shift) { return (size_t)(U(d, shift) + 2 * YD + 256 + WM_ATAN_TAB_WORDS) * 4; }
 };
+using K1Geo = K1GeoT<256>;
+#define WM_K1_TILE_BIG (4 * 512 - WM_K1_HALO)      /* the tile of the 512-thread first pass */
+static_assert(K1Geo::T == WM_K1_TILE2, "the 256-thread tile is the tile of every per-tile record");
 static_assert(K1Geo::NA == 1024, "stage A maps one 4-sample chunk to each of the 256 threads");
 
 /* 8- and 16-tap boxcar sums at the five positions a0-1 .. a0+3 of one chunk from the staged
@@ -199,18 +223,19 @@ __device__ __forceinline__ void k1_fir_s(const K1Args &a, const float *yDrS, con
 #ifndef WM_K1_BALANCED
 #define WM_K1_BALANCED 1
 #endif
-template <bool GEN, bool FAST = false, int RS = 0>
+template <bool GEN, bool FAST = false, int RS = 0, int NT = 256>
 __device__ __forceinline__ void k1_stage_b(const K1Args &a, const int tid, const int tile, const int stream, const int ts, const int tn,
                                            const bool chT, const bool chS, const float *yDrT, const float *yDrS,
                                            const float *yMgT, const float *yMgS, float *sFin, float *sHead)
 {
-    constexpr int T = WM_K1_TILE2;
+    constexpr int T = K1GeoT<NT>::T;
+    static_assert(RS == 1 || NT == 256, "only the first pass without the RSSI runs on the larger tile");
     const WmPush &g = a.g;
-    __syncthreads();                                          /* magnitude rows complete */
+    if (RS != 1) __syncthreads();                             /* magnitude rows complete (RS = 1 writes none: the caller's barrier is the only one) */
     /* The four waves have different jobs here (EMA + the 11-tap FIR: ~520 instructions; the 46-tap FIR:
      * ~870): the jobs rotate with the tile, so that no SIMD of a CU can end up with the heavy job block
      * after block whatever order the hardware places a workgroup's waves in (two instructions). */
-    const int e = tid & 63, wv = ((tid >> 6) + tile) & 3, rt = 64 * wv + e;      /* rt: thread id within the rotated roles */
+    const int e = tid & 63, wv = ((tid >> 6) + tile) & (NT / 64 - 1), rt = 64 * wv + e;      /* rt: thread id within the rotated roles */
     if (RS == 1) {                                            /* no RSSI here: every wave a quarter of each low-pass (4 x 92 + 2 x 44) */
         /* two waves start with the short filter: all four reading their 13 + 4 window vectors at once, right behind the barrier,
          * queued on the CU's one LDS pipe (SQ_WAIT_INST_LDS doubled against the full kernel, whose roles differ by wave; r04 A/B:
@@ -351,10 +376,10 @@ __device__ __forceinline__ void k1_stage_rssi(const K1Args &a, const int tid, co
 /* GEN = false: the kernel of the DEFAULT switches (both chains, cargf arctangent, first pass): the switch tests, the
  * -a / -A / -p paths and the RSSI repair walk are not compiled in, so the default path carries no cost for the options
  * (any other configuration, and every repair launch, runs the GEN = true kernel: same arithmetic, same results). */
-template <int D, bool SHIFT, bool GEN, bool FAST = false, int RS = 0>
+template <int D, bool SHIFT, bool GEN, bool FAST = false, int RS = 0, int NT = 256>
 __device__ __forceinline__ void k1_tile(const K1Args &a, const int tile, const int stream, const int tid)
 {
-    using G = K1Geo;
+    using G = K1GeoT<NT>;
     constexpr int T = G::T, NA = G::NA, YD = G::YD, YM = G::YM;
     const WmPush &g = a.g;
     const int d = D ? D : (int)g.d;
@@ -372,11 +397,11 @@ __device__ __forceinline__ void k1_tile(const K1Args &a, const int tile, const i
     const bool accurate = !GEN || (g.flags & WM_F_ACCURATE);
     const int approx = !GEN ? 0 : (g.flags & WM_F_APPROX1) ? 1 : (g.flags & WM_F_APPROX2) ? 2 : 0;   /* option: atan2.h's approximations */
 
-    if (RS != 2 && tid < WM_ATAN_TAB_WORDS) wm_atan_tab_word(tid, tab);   /* 5 range rows + range LUT */
-
     /* ---- stage 0: one dword (two IQ samples) per lane and pass: coalesced loads, LDS stores at a
      * two-word lane stride (the 16-byte-per-lane variant stored at an 8-word stride: 8-way bank
      * conflicts) ------------------------------------------------------------------------------- */
+    WM_K1_STAMP_DECL;
+    WM_K1_STAMP(0);
     {
         const long r_lo = ((long)(g.m0 + (uint64_t)ts) - WM_K1_HALO) * d - 16 - (long)g.n0;   /* LDS word 0 */
         const long r_al = r_lo & ~1L;
@@ -384,28 +409,35 @@ __device__ __forceinline__ void k1_tile(const K1Args &a, const int tile, const i
         const int NDW = (NA * d + 16 + 1 + 1) / 2;            /* dwords covering the staged samples */
         const uint8_t *base = g.in + (uint64_t)stream * g.in_stride + WM_HIST_BYTES;
         const uint32_t *src = (const uint32_t *)(base + 2 * r_al);
-        constexpr int NP = D ? ((NA * D + 16 + 1 + 1) / 2 + 255) / 256 : 1;     /* loads in flight per lane */
-        const int passes = D ? 1 : (NDW + 255) / 256;
+        constexpr int NP = D ? ((NA * D + 16 + 1 + 1) / 2 + NT - 1) / NT : 1;     /* loads in flight per lane */
+        const int passes = D ? 1 : (NDW + NT - 1) / NT;
         for (int ps = 0; ps < passes; ps++) {
         uint32_t wv[NP];
 #pragma unroll
         for (int it = 0; it < NP; it++) {
-            const int u = tid + 256 * (it + ps);
+            const int u = tid + NT * (it + ps);
             wv[it] = u < NDW ? src[u] : 0u;
         }
+        /* the arctangent's table (5 range rows + range LUT, wm_exact.h): word k by lane k, ONE load issued behind the
+         * input loads and waited for with them (round 4 computed it in place: six dependent global loads in the first
+         * wave of every block before its input loads went out) */
+        uint32_t tabw = 0u;
+        if (RS != 2 && ps == 0 && tid < WM_ATAN_TAB_WORDS) tabw = WM_ATAN_TAB_BITS[tid];
 #pragma unroll
         for (int it = 0; it < NP; it++) {
-            const int u = tid + 256 * (it + ps);
+            const int u = tid + NT * (it + ps);
             if (u < NDW) {
                 const int p = 2 * u - off;
                 if (!SHIFT) {
-                    /* bytes (i,q) -> halfwords, then u - 127 - (u >> 7) per halfword
-                     * (= (int)((float)u - 127.5f), rtl_wmbus.c:1312-1313 + moving_average_filter.h:47) */
+                    /* (int)((float)u - 127.5f) per byte (rtl_wmbus.c:1312-1313 + moving_average_filter.h:47) = u - 127 - (u >> 7):
+                     * the (u >> 7) of all four bytes leaves in ONE subtraction (a byte never borrows: u - (u >> 7) >= 0),
+                     * then bytes (i,q) -> halfwords and - 127 per halfword: 7 instead of 10 instructions per dword */
                     const wm_s2 c127 = {127, 127};
+                    const uint32_t w4 = wv[it] - ((wv[it] >> 7) & 0x01010101u);
 #pragma unroll
                     for (int k = 0; k < 2; k++) {
-                        const uint32_t h = __builtin_amdgcn_perm(0u, wv[it], k ? 0x0c030c02u : 0x0c010c00u);
-                        const wm_s2 q = __builtin_bit_cast(wm_s2, h) - c127 - __builtin_bit_cast(wm_s2, (h >> 7) & 0x00010001u);
+                        const uint32_t h = __builtin_amdgcn_perm(0u, w4, k ? 0x0c030c02u : 0x0c010c00u);
+                        const wm_s2 q = __builtin_bit_cast(wm_s2, h) - c127;
                         stgT[p + k] = __builtin_bit_cast(uint32_t, q);
                     }
                 } else {
@@ -428,9 +460,12 @@ __device__ __forceinline__ void k1_tile(const K1Args &a, const int tile, const i
                 }
             }
         }
+        if (RS != 2 && ps == 0 && tid < WM_ATAN_TAB_WORDS) tab[tid] = wm_u2f(tabw);
         }
     }
+    WM_K1_STAMP(1);
     __syncthreads();
+    WM_K1_STAMP(2);
 
     /* ---- stage A: thread = chunk ------------------------------------------------------------- */
     float mgT[4] = {0.0f, 0.0f, 0.0f, 0.0f}, mgS[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -498,7 +533,9 @@ __device__ __forceinline__ void k1_tile(const K1Args &a, const int tile, const i
             *(float4 *)(yDrS + 4 * c + 4) = make_float4(drS[0], drS[1], drS[2], drS[3]);
         }
     }
-    __syncthreads();                                          /* staging data retired */
+    WM_K1_STAMP(3);
+    __syncthreads();                                          /* staging data retired, discriminator rows complete */
+    WM_K1_STAMP(4);
     if (RS != 1) {   /* element a of a magnitude row lives at word a + a/16 (conflict-free 17-word lane stride in B2) */
         const int qb = 4 * tid + (tid >> 2);
 #pragma unroll
@@ -506,12 +543,15 @@ __device__ __forceinline__ void k1_tile(const K1Args &a, const int tile, const i
     }
 
     if (RS == 2) k1_stage_rssi(a, tid, tile, stream, ts, tn, a.rs_flags[(uint64_t)tile * g.S + stream], yMgT, yMgS, sFin);
-    else k1_stage_b<GEN, FAST, RS>(a, tid, tile, stream, ts, tn, chT, chS, yDrT, yDrS, yMgT, yMgS, sFin, sHead);
+    else k1_stage_b<GEN, FAST, RS, NT>(a, tid, tile, stream, ts, tn, chT, chS, yDrT, yDrS, yMgT, yMgS, sFin, sHead);
+    WM_K1_STAMP(5);
+    WM_K1_STAMP_END(tid);
 }
 
-template <int D, bool SHIFT, bool GEN = true, bool FAST = false, int RS = 0>
-__global__ __launch_bounds__(256, GEN ? 1 : 8) void k1_demod2(K1Args a)          /* first pass: at most 64 VGPRs -- eight waves fill a SIMD's register file exactly */
+template <int D, bool SHIFT, bool GEN = true, bool FAST = false, int RS = 0, int NT = 256>
+__global__ __launch_bounds__(NT, GEN ? 1 : 8) void k1_demod2(K1Args a)          /* first pass: at most 64 VGPRs -- eight waves fill a SIMD's register file exactly */
 {
+    static_assert(NT == 256 || (NT == 512 && RS == 1 && !GEN), "the 512-thread tile is the first pass's without the RSSI");
     /* One tile per block.  (A bounded grid whose blocks walk several tiles made the kernel itself 6 % faster -- fewer block
      * launches, per-thread addresses kept across tiles -- and the whole job 10 % slower: the framer kernels of the other
      * contexts get onto a CU when demodulation blocks retire, and blocks that live twice as long halve their chances; r03
@@ -524,7 +564,7 @@ __global__ __launch_bounds__(256, GEN ? 1 : 8) void k1_demod2(K1Args a)         
         }
         return;
     }
-    if (!GEN || a.relist == nullptr) { k1_tile<D, SHIFT, GEN, FAST, RS>(a, (int)(blockIdx.x + a.tile0), (int)blockIdx.y, (int)threadIdx.x); return; }
+    if (!GEN || a.relist == nullptr) { k1_tile<D, SHIFT, GEN, FAST, RS, NT>(a, (int)(blockIdx.x + a.tile0), (int)blockIdx.y, (int)threadIdx.x); return; }
     /* repair launch: a fixed grid walks the list k1_collect has just written (no host round trip in between) */
     const uint32_t n = *a.n_relist;
     for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {

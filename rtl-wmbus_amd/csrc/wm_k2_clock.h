@@ -3,6 +3,21 @@
 #ifndef WM_K2_CLOCK_H
 #define WM_K2_CLOCK_H
 
+/* the lambdas of a lane take the lane's register sets by reference: one of them left out of line (or inlined late) and the
+ * sets live in scratch memory -- in the re-run kernel that cost every 32-sample block sixteen scratch accesses AND the prefetch
+ * (a block of loads had to arrive before it could be stored away; round 5, read off the ISA) */
+#if defined(__clang__)
+#define WM_LAMBDA_INLINE __attribute__((always_inline))
+#else
+#define WM_LAMBDA_INLINE
+#endif
+
+/* the lane's register sets are NATIVE vectors: a float4 (HIP's struct type) is assigned by a 16-byte memcpy, and in the re-run
+ * kernel -- one load path, no cooperative alternative -- those memcpys survived the optimiser as they were: global -> private
+ * memory -> LDS, i.e. the sets lived in scratch (272 bytes per lane; r04: 576 with the states) and every block of loads had to
+ * ARRIVE before it could be put away, which is the opposite of a prefetch */
+typedef float wm_f4 __attribute__((vector_size(16)));
+
 struct IirCoef { float a1[3], a2[3], b1[3], b2[3]; };
 
 __device__ __forceinline__ IirCoef iir_coef(uint32_t ch)
@@ -40,6 +55,25 @@ __device__ __forceinline__ bool clk_step(WmClkState &s, const IirCoef &c, bool d
         s.h[2 * k + 1] = h1; s.h[2 * k] = h0;
     }
     return wm_mul(v, 1.874981046e-06f) >= 0.0f;
+}
+
+/* A lane state as its twelve words, and two states compared bit for bit -- member by member: viewing the struct through a
+ * uint32_t pointer makes the compiler keep it in memory (scratch) in the re-run kernel, whose chain walk carries a state from
+ * one segment into the next (round 4: 576 bytes of scratch per lane, sixteen scratch accesses inside the 32-sample block loop). */
+__device__ __forceinline__ void clk_state_words(const WmClkState &s, uint32_t (&w)[12])
+{
+#pragma unroll
+    for (int i = 0; i < 6; i++) w[i] = wm_f2u(s.h[i]);
+    w[6] = wm_f2u(s.dc_x); w[7] = wm_f2u(s.dc_y); w[8] = s.clk; w[9] = s.sr; w[10] = s.pad[0]; w[11] = s.pad[1];
+}
+__device__ __forceinline__ bool clk_state_same(const WmClkState &a, const WmClkState &b)
+{
+    uint32_t x[12], y[12];
+    clk_state_words(a, x); clk_state_words(b, y);
+    bool same = true;
+#pragma unroll
+    for (int i = 0; i < 12; i++) same &= x[i] == y[i];
+    return same;
 }
 
 #define WM_CLK_XROW 36           /* words per lane in the clock kernel's soft-symbol buffer: 32 + 4 (rows stay 16-byte
@@ -185,11 +219,11 @@ template <int W> struct ClkLds {         /* per block: W independent waves */
  * a grid-stride loop the first pass needed 254 VGPRs + 16 AGPRs and ran at one wave per SIMD, round 2). */
 /* One segment of one (chain, capture): returns 0 when the lane ran to the segment's end (`fin` = its end state, also written to
  * st_final), 1 when a re-run left early at a checkpoint it reproduced (the end state in st_final was exact already), 2 when
- * there was nothing to do.  `from`: the exact state a re-run starts from when the caller has it at hand (nullptr: the
- * predecessor's record / the carried state). */
+ * there was nothing to do.  `from` (with have_from): the exact state a re-run starts from when the caller has it at hand (else: the
+ * predecessor's record / the carried state).  By value, not by pointer: a pointer that may name the caller's `fin` kept both in scratch. */
 template <bool DC, int W, bool LEAN, int PASS>
 __device__ __forceinline__ int clock_segment(const K2Args &a, ClkLds<W> &lds, const uint32_t wv, const uint32_t ln, const bool rerun,
-                                             const uint32_t ch, const uint32_t stream, const uint32_t seg, const WmClkState *from, WmClkState &fin)
+                                             const uint32_t ch, const uint32_t stream, const uint32_t seg, const bool have_from, const WmClkState &from, WmClkState &fin)
 {
     float *s_x = lds.x[wv];
     uint32_t *s_chip = lds.chip[wv], *s_bits = lds.bits[wv];
@@ -213,7 +247,7 @@ __device__ __forceinline__ int clock_segment(const K2Args &a, ClkLds<W> &lds, co
 
     WmClkState s;
     uint32_t m;
-    if (rerun) { s = from ? *from : seg ? stF[sidx - 1] : stC[row]; m = mb; }
+    if (rerun) { if (have_from) s = from; else s = seg ? stF[sidx - 1] : stC[row]; m = mb; }
     else {
         const uint32_t w = g.warm[ch];
         if (mb <= w) { s = stC[row]; m = 0; }            /* exact: run from the push start  */
@@ -234,7 +268,7 @@ __device__ __forceinline__ int clock_segment(const K2Args &a, ClkLds<W> &lds, co
 
     /* chips of one 32-sample block: walk the set bits of the sample mask (ragged tail, shift
      * register upkeep during warm-up) */
-    auto emit_block = [&](uint32_t m0, uint32_t smask, uint32_t bitw, bool emit) {
+    auto emit_block = [&](uint32_t m0, uint32_t smask, uint32_t bitw, bool emit) WM_LAMBDA_INLINE {
         while (smask) {
             const uint32_t k = (uint32_t)__ffs((int)smask) - 1u;
             smask &= smask - 1u;
@@ -262,24 +296,24 @@ __device__ __forceinline__ int clock_segment(const K2Args &a, ClkLds<W> &lds, co
 #define WM_CLK_PREFETCH 2          /* blocks of loads in flight per lane; 1 = build-time experiment (32 VGPRs fewer) */
 #endif
     constexpr uint32_t AHEAD = 32u * WM_CLK_PREFETCH;
-    float4 gxA[8], gxB[8];
-    auto fetch_x = [&](float4 (&gx)[8], uint32_t mm) {
+    wm_f4 gxA[8], gxB[8];
+    auto fetch_x = [&](wm_f4 (&gx)[8], uint32_t mm) WM_LAMBDA_INLINE {
         if (coop) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) gx[i] = *(const float4 *)(xc + i * xc_step + mm);
+            for (int i = 0; i < 8; i++) gx[i] = *(const wm_f4 *)(xc + i * xc_step + mm);
         } else {
 #pragma unroll
-            for (int i = 0; i < 8; i++) gx[i] = *(const float4 *)(x + mm + 4 * i);
+            for (int i = 0; i < 8; i++) gx[i] = *(const wm_f4 *)(x + mm + 4 * i);
         }
     };
     /* registers -> LDS rows (coop: the pieces I fetched for other lanes' rows; else my own row) */
     const uint32_t xw = coop ? (ln >> 3) * WM_CLK_XROW + 4u * (ln & 7u) : ln * WM_CLK_XROW;
     const uint32_t xw_step = coop ? 8u * WM_CLK_XROW : 4u;
     const float *xrow = s_x + ln * WM_CLK_XROW;
-    auto put_x = [&](const float4 (&gx)[8]) {
+    auto put_x = [&](const wm_f4 (&gx)[8]) WM_LAMBDA_INLINE {
         __builtin_amdgcn_wave_barrier();                     /* the previous block's reads are done */
 #pragma unroll
-        for (int i = 0; i < 8; i++) *(float4 *)(s_x + xw + i * xw_step) = gx[i];
+        for (int i = 0; i < 8; i++) *(wm_f4 *)(s_x + xw + i * xw_step) = gx[i];
         __builtin_amdgcn_wave_barrier();
     };
     const uint32_t m_last = me_full >= 32u ? me_full - 32u : 0u;      /* clamp for prefetches past the end */
@@ -287,7 +321,7 @@ __device__ __forceinline__ int clock_segment(const K2Args &a, ClkLds<W> &lds, co
     /* ---- phase 1: warm-up blocks [m, mb): soft symbols only; no store is issued in this loop, so
      * waiting for a block in flight never waits for anything else (gfx950's vmcnt counts loads
      * and stores in one in-order queue) --------------------------------------------------------- */
-    auto warm_block = [&](float4 (&gx)[8]) {
+    auto warm_block = [&](wm_f4 (&gx)[8]) WM_LAMBDA_INLINE {
         put_x(gx);
         fetch_x(gx, min(m + AHEAD, m_last));
         uint32_t bitw, smask;
@@ -316,7 +350,7 @@ __device__ __forceinline__ int clock_segment(const K2Args &a, ClkLds<W> &lds, co
         if (m < mb) warm_block(gxB);
         else {                                               /* keep "A = next block" for phase 2 */
 #pragma unroll
-            for (int i = 0; i < 8; i++) { const float4 t = gxA[i]; gxA[i] = gxB[i]; gxB[i] = t; }
+            for (int i = 0; i < 8; i++) { const wm_f4 t = gxA[i]; gxA[i] = gxB[i]; gxB[i] = t; }
         }
     }
     stS[sidx] = s;                                       /* state the main loop starts from */
@@ -328,7 +362,7 @@ __device__ __forceinline__ int clock_segment(const K2Args &a, ClkLds<W> &lds, co
      * 131 072 lanes with private output regions become read-modify-write traffic) */
     uint32_t *my_chip = s_chip + ln * WM_CLK_CROW;
     uint32_t pend = 0, n_fl = 0;
-    auto flush8 = [&]() {
+    auto flush8 = [&]() WM_LAMBDA_INLINE {
         uint32_t w[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) w[i] = my_chip[i];
@@ -340,7 +374,7 @@ __device__ __forceinline__ int clock_segment(const K2Args &a, ClkLds<W> &lds, co
     };
     /* slicer words leave in aligned groups of 8 as well (one word per 32 samples and lane) */
     uint32_t *my_bits = s_bits + ln * WM_CLK_BROW;
-    auto main_block = [&](float4 (&gx)[8]) {
+    auto main_block = [&](wm_f4 (&gx)[8]) WM_LAMBDA_INLINE {
         put_x(gx);
         fetch_x(gx, min(m + AHEAD, m_last));
         uint32_t bitw, smask;
@@ -382,7 +416,8 @@ __device__ __forceinline__ int clock_segment(const K2Args &a, ClkLds<W> &lds, co
         }
         if (m < me_full && j < nck) {                    /* interior checkpoint j */
             uint32_t *q = ck + 16u * j;
-            const uint32_t *sw = (const uint32_t *)&s;
+            uint32_t sw[12];
+            clk_state_words(s, sw);
             if (!rerun) {
                 *(uint4 *)(q) = make_uint4(sw[0], sw[1], sw[2], sw[3]);
                 *(uint4 *)(q + 4) = make_uint4(sw[4], sw[5], sw[6], sw[7]);
@@ -476,27 +511,24 @@ __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t bloc
     uint32_t ch, stream, seg;
     lane_decode(g, 1, lane, ch, stream, seg);
     if (!(g.flags & (ch ? WM_F_S1 : WM_F_T1C1))) return;
-    WmClkState fin;
+    WmClkState fin, from{};
     const bool chains = rerun && a.bad != nullptr && !(ch == 1u && g.s1_span == 2u);
-    if (!chains) { clock_segment<DC, W, LEAN, PASS>(a, lds, wv, ln, rerun, ch, stream, seg, nullptr, fin); return; }
+    if (!chains) { clock_segment<DC, W, LEAN, PASS>(a, lds, wv, ln, rerun, ch, stream, seg, false, from, fin); return; }
     const uint64_t row = (uint64_t)ch * g.S + stream;
     const uint32_t *bad = a.bad + (uint64_t)ch * g.nseg_cap[1] * g.S + stream;       /* verdict of segment j at bad[j * S] */
     const WmClkState *stS = (const WmClkState *)a.st_start, *stF = (const WmClkState *)a.st_final;
     if (seg > 0u && bad[(uint64_t)(seg - 1u) * g.S]) return;            /* the head of my run covers me */
-    const WmClkState *from = nullptr;
+    bool have_from = false;
     for (;;) {
-        const int how = clock_segment<DC, W, LEAN, PASS>(a, lds, wv, ln, true, ch, stream, seg, from, fin);
+        const int how = clock_segment<DC, W, LEAN, PASS>(a, lds, wv, ln, true, ch, stream, seg, have_from, from, fin);
         const uint64_t sidx = row * g.nseg_cap[1] + seg;
         if (how == 1) fin = stF[sidx];                     /* left at a checkpoint: the recorded end state was exact */
         if (how == 2 || seg + 1u >= g.nseg[1]) return;
-        const uint32_t *x = (const uint32_t *)&fin, *y = (const uint32_t *)&stS[sidx + 1u];
-        bool same = true;
-#pragma unroll
-        for (int k = 0; k < (int)(sizeof(WmClkState) / 4); k++) same &= x[k] == y[k];
-        if (same) return;                                  /* the next segment started from exactly this state */
+        const WmClkState next = stS[sidx + 1u];
+        if (clk_state_same(fin, next)) return;             /* the next segment started from exactly this state */
         if (bad[(uint64_t)(seg + 1u) * g.S] && !bad[(uint64_t)seg * g.S]) return;      /* it is listed and has a lane of its own in this launch: next round */
         seg++;
-        from = &fin;
+        from = fin; have_from = true;
     }
 }
 

@@ -51,6 +51,8 @@ int main(int argc, char **argv)
     const long n = argc > 1 ? atol(argv[1]) : 10000000;
     long bad = 0, tot = 0;
     for (int k = 0; k < WM_ATAN_TAB_WORDS; k++) wm_atan_tab_word(k, TAB);
+    for (int k = 0; k < WM_ATAN_TAB_WORDS; k++)           /* the table the kernels load is the table the generator makes */
+        if (wm_f2u(TAB[k]) != WM_ATAN_TAB_BITS[k]) { printf("WM_ATAN_TAB_BITS[%d] = %08x, generator %08x\n", k, WM_ATAN_TAB_BITS[k], wm_f2u(TAB[k])); bad++; }
     if (argc > 2 && known_answers(argv[2], &bad)) {
         printf("HOST LIBM DIFFERS from glibc 2.35's atan2f: the reference itself would print other soft symbols on this host\n");
         return bad ? 1 : 77;

@@ -59,11 +59,12 @@ def budget(name):
 
 
 NAMES = {0: "stage 0", 1: "stage A", 2: "mag rows", 3: "B (all roles)+certify"}
-for title, sym in (("k1_demod2<2, false, false, false, 0>  -- the default switches' first pass, bit-exact, RSSI of every sample (contexts with debug views)", "_Z9k1_demod2ILi2ELb0ELb0ELb0ELi0EEv6K1Args"),
-                   ("k1_demod2<2, false, false, false, 1>  -- the same without the RSSI (round 4: RSSI on demand; all of stage B is every wave's)", "_Z9k1_demod2ILi2ELb0ELb0ELb0ELi1EEv6K1Args"),
-                   ("k1_demod2<2, false, false, false, 2>  -- the RSSI of one listed tile (stage B = bracketed warm-ups + 16 samples, waves 0 and 1 only)", "_Z9k1_demod2ILi2ELb0ELb0ELb0ELi2EEv6K1Args"),
-                   ("k1_demod2<2, false, false, true, 0>   -- tolerance mode (polynomial arctangent, FMA low-passes), RSSI of every sample", "_Z9k1_demod2ILi2ELb0ELb0ELb1ELi0EEv6K1Args"),
-                   ("k1_demod2<2, false, false, true, 1>   -- tolerance mode without the RSSI", "_Z9k1_demod2ILi2ELb0ELb0ELb1ELi1EEv6K1Args")):
+for title, sym in (("k1_demod2<2, false, false, false, 0>  -- the default switches' first pass, bit-exact, RSSI of every sample (contexts with debug views)", "_Z9k1_demod2ILi2ELb0ELb0ELb0ELi0ELi256EEv6K1Args"),
+                   ("k1_demod2<2, false, false, false, 1>  -- the same without the RSSI (round 4: RSSI on demand; all of stage B is every wave's)", "_Z9k1_demod2ILi2ELb0ELb0ELb0ELi1ELi256EEv6K1Args"),
+                   ("k1_demod2<2, false, false, false, 1, 512>  -- the same on the 2000-sample tile of 512 threads (round 5: the product's first pass at decimation 2)", "_Z9k1_demod2ILi2ELb0ELb0ELb0ELi1ELi512EEv6K1Args"),
+                   ("k1_demod2<2, false, false, false, 2>  -- the RSSI of one listed tile (stage B = bracketed warm-ups + 16 samples, waves 0 and 1 only)", "_Z9k1_demod2ILi2ELb0ELb0ELb0ELi2ELi256EEv6K1Args"),
+                   ("k1_demod2<2, false, false, true, 0>   -- tolerance mode (polynomial arctangent, FMA low-passes), RSSI of every sample", "_Z9k1_demod2ILi2ELb0ELb0ELb1ELi0ELi256EEv6K1Args"),
+                   ("k1_demod2<2, false, false, true, 1>   -- tolerance mode without the RSSI", "_Z9k1_demod2ILi2ELb0ELb0ELb1ELi1ELi256EEv6K1Args")):
     b = budget(sym)
     print(title)
     keys = ["VALU total"] + [g for g, _ in GROUPS] + sorted({k for s in b.values() for k in s if k.startswith("other")}) + ["SALU total", "LDS total", "VMEM total"]
