@@ -77,6 +77,10 @@ def parse():
     ap.add_argument("--no-legs", action="store_true", help="skip the informational legs behind the main measurement (configs[1] / configs[2], the CLI's own rate)")
     ap.add_argument("--quick", action="store_true", help="A/B runs: --no-check --no-cpu-baseline --no-legs --no-tolerance-leg")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
+                    help="A/B runs: a tuning field of wmbus_cfg for the main batch (k1_small_tile=1, rssi_full=1, rssi_dense_pm=500, rounds_on_host=1 ...); repeatable")
+    ap.add_argument("--details", default=os.path.join(ROOT, "gpurun_out", "bench_details.json"),
+                    help="where the full record goes (per-context stage times, every leg with its sub-measurements); the stdout line is the compact one")
     return ap.parse_args()
 
 
@@ -179,19 +183,31 @@ def leg_c3_batch(wm, O, shard, S, n, device, steps, **tune):
     try:
         for s_ in range(S):
             b.stage(s_, caps[s_])
+        def texts():
+            per = collections.defaultdict(list)
+            for rx, first, _c in b.contexts:
+                for ln in rx.lines():
+                    per[first + ln["stream"]].append(ln["text"])
+            return per
         b.run_resident(2 * n, 1)
-        per = collections.defaultdict(list)
-        for rx, first, _c in b.contexts:
-            for ln in rx.lines():
-                per[first + ln["stream"]].append(ln["text"])
-        picks = sorted({(j * (S - 1)) // 15 for j in range(16)}) if S > 1 else [0]
-        want = O.run_many([caps[s_] for s_ in picks], O.make_opts(decimation=5, simultaneous=1))
+        per = texts()
+        # 128 captures (16, first pass only): sixteen of every context, first pass AND the last one -- this leg is where
+        # RSSI on demand pauses itself (31 % of the tiles listed), so the hand-over on demand -> full pass -> on demand of the
+        # filter's carried state is inside the pushes that are compared
+        picks = last_pass_picks([(first, cnt) for _rx, first, cnt in b.contexts], 1, per_wave=8) if S >= 64 else list(range(S))
+        opts = O.make_opts(decimation=5, simultaneous=1)
+        want = O.run_many([caps[s_] for s_ in picks], opts)
         bad = [s_ for s_, w in zip(picks, want) if "".join(per[s_]) != w]
+        modes = collections.Counter()
         b.run_resident(2 * n, 2)
         tims = []
         t0 = time.perf_counter()
-        b.run_resident(2 * n, steps, lambda _f, _c, _l, tm: tims.append(tm), want_lines=False)
+        b.run_resident(2 * n, steps, lambda _f, _c, _l, tm: (tims.append(tm), modes.update([tm["rssi_mode"]])), want_lines=False)
         dt = time.perf_counter() - t0
+        passes_c3 = 3 + steps
+        per = texts()
+        want_l = O.run_many([caps[s_] for s_ in picks], opts, passes=passes_c3)
+        bad_l = [s_ for s_, w in zip(picks, want_l) if "".join(per[s_]) != w]
         alone = []
         for rx, _f, _c in b.contexts:
             rx.process(2 * n); rx.collect(); alone.append(rx.timing()["demod_ms"])
@@ -203,7 +219,9 @@ def leg_c3_batch(wm, O, shard, S, n, device, steps, **tune):
                 "value": round(S * n * steps / dt / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps,
                 "contexts_per_gpu": len(b.contexts), "kernel": "k1_demod2<5, true, false, false>", "k1_alone_ms": round(k1, 3),
                 "k1_hbm_frac": round(BYTES_PER_SAMPLE * spl / (k1 / 1e3) / 1e9 / HBM_PEAK_GBPS, 4),
-                "parity": {"captures_compared": len(picks), "mismatches": len(bad), "datagrams": sum(len(w.splitlines()) for w in want)}}
+                "rssi_modes_timed_pushes": {str(k): v for k, v in sorted(modes.items())},
+                "parity": {"captures_compared": len(picks), "mismatches": len(bad), "datagrams": sum(len(w.splitlines()) for w in want),
+                           "last_pass": {"pass_number": passes_c3, "captures_compared": len(picks), "mismatches": len(bad_l)}}}
     finally:
         b.close()
 
@@ -337,7 +355,11 @@ def main():
     nctx_guess = nctx_req or min(12 if a.tolerance_mode else 8, max(1, S // 64))
     # host decoder threads per context: ranks x contexts x threads within the host's hardware threads
     host_threads = a.host_threads or shard.host_threads_per_context(world, nctx_guess)
-    batch = wm.Batch(n_streams=S, contexts=nctx_req, max_push_bytes=push_bytes, device=local, seg_len=a.seg_len, rla_seg_len=a.rla_seg_len,
+    tune = {}
+    for kv in a.tune:
+        k_, _, v_ = kv.partition("=")
+        tune[k_] = [int(x) for x in v_.split(":")] if ":" in v_ else int(v_)
+    batch = wm.Batch(n_streams=S, contexts=nctx_req, max_push_bytes=push_bytes, device=local, seg_len=a.seg_len, rla_seg_len=a.rla_seg_len, **tune,
                      warmup_s1=a.warmup_s1, warmup_t1c1=a.warmup_t1c1, rla_lookback=a.rla_lookback, show_algorithm=True, fixed_timestamp=True,
                      host_threads=host_threads, input_windows=2 if a.from_host else 1, tolerance_mode=int(a.tolerance_mode),
                      rla=not a.no_rla, time2=not a.no_time2)
@@ -430,18 +452,22 @@ def main():
     # share of the GPU, not its speed.  After the timed region every context therefore makes one more
     # pass ALONE (still HIP events on the library's stream): that duration is the kernel's own.
     samples_per_launch = S * n / nctx
-    alone_ms = []
+    alone_ms, alone_rssi_ms, alone_mode = [], [], []
     if a.from_host:
         for s_ in range(S):
             batch.stage(s_, host_caps[s_])
     for rx, _first, _cnt in batch.contexts:
         rx.process(push_bytes)
         rx.collect()
-        alone_ms.append(rx.timing()["demod_ms"])
+        tm_ = rx.timing()
+        alone_ms.append(tm_["demod_ms"]); alone_rssi_ms.append(tm_["rssi_ms"]); alone_mode.append(tm_["rssi_mode"])
     passes_done += 1
     k1_avg_s = sum(alone_ms) / max(1, len(alone_ms)) / 1e3
     k1_concurrent_ms = demod_ms / max(1, k1_launches)
     achieved = BYTES_PER_SAMPLE * samples_per_launch / k1_avg_s / 1e9 if k1_avg_s > 0 else 0.0
+    on_demand = bool(alone_mode) and all(m_ == wm.RSSI_ON_DEMAND for m_ in alone_mode)
+    rssi_avg_ms = sum(alone_rssi_ms) / max(1, len(alone_rssi_ms))
+    frac_with_rssi = BYTES_PER_SAMPLE * samples_per_launch / max(k1_avg_s + rssi_avg_ms / 1e3, 1e-12) / 1e9 / HBM_PEAK_GBPS
     traffic, traffic_from = None, None
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tf):
@@ -605,10 +631,11 @@ def main():
                                              "achieved": round(BYTES_PER_SAMPLE * samples_per_launch / max(k1_concurrent_ms, 1e-9) / 1e6, 1),
                                              "frac": round(BYTES_PER_SAMPLE * samples_per_launch / max(k1_concurrent_ms, 1e-9) / 1e6 / HBM_PEAK_GBPS, 4)},
                          "valu": valu,
-                         "dominant": "k1_demod2 is the largest kernel of the job by work (two thirds of its VALU instructions; 20 of the 45 ms the "
-                                     "kernels take one after the other, profiles/*_single_context_kernel_stats.csv) and the one the roofline is quoted "
-                                     "for; in this 8-context configuration the framer kernels (k2_clock, k2_rla) are RESIDENT longer (about 60 % of "
-                                     "the summed kernel durations, profiles/*_bench_kernel_stats.csv) because they are latency-bound and overlap it",
+                         "rssi": "on demand: NOT in the timed launch (a second launch computes it for the tiles the bursts touch)" if on_demand
+                                 else "in the timed launch (every sample)",
+                         "rssi_launch_ms": round(rssi_avg_ms, 3), "frac_with_rssi_launch": round(frac_with_rssi, 4),
+                         "dominant": "k1_demod2: two thirds of the job's VALU instructions (profiles/valu.json); the framer kernels are resident longer "
+                                     "(latency-bound, they overlap it: profiles/*_bench_kernel_stats.csv)",
                          "how": "HIP events around k1_demod2 on the library's stream, one context at a time after the timed "
                                 "region (inside it a launch runs beside the other contexts' kernels: avg %.3f ms each)" % k1_concurrent_ms},
             "stage_ms_last_step": [rnd(t) for t in (tim_acc[-1] if tim_acc else [])],
@@ -643,7 +670,61 @@ def main():
                                    f"across {nctx} contexts (pass {lp['pass_number']}, carried state) identical to the oracle"
                                    if parity["ok"] else "MISMATCH")
             ok = bool(parity["ok"]) or a.tolerance_mode          # tolerance mode is informational: its differences are reported, not fatal
-        print(json.dumps(out), flush=True)
+        # ---- the record in full goes to a side file; stdout carries ONE compact line (the 12 KB line of round 4 was
+        # cut off in the driver's record, and with it every leg but the headline)
+        try:
+            os.makedirs(os.path.dirname(a.details), exist_ok=True)
+            with open(a.details, "w") as f_:
+                json.dump(out, f_)
+            details = os.path.relpath(a.details, ROOT)
+        except Exception as e:
+            details = f"not written: {e!r}"
+
+        def pick(d, *keys):
+            return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+        rl, vl = out["roofline"], out["roofline"].get("valu") or {}
+        line = pick(out, "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+        line["config"] = {"workload": f"{S}x{n} IQ samples, 1.6 MS/s cu8, T1+C1 bursts, default switches, HBM-resident", "contexts_per_gpu": nctx,
+                          "parallelism": f"file-per-GPU x{world}, no collective"}
+        line["roofline"] = dict(pick(rl, "bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "rssi_launch_ms", "frac_with_rssi_launch"),
+                                rssi="on demand, not in the timed launch" if on_demand else "in the timed launch",
+                                in_region_ms=rl["in_timed_region"]["avg_launch_ms"], in_region_frac=rl["in_timed_region"]["frac"])
+        if "cpu_baseline" in out and out["cpu_baseline"]:
+            cb = out["cpu_baseline"]
+            line["cpu_baseline"] = dict(pick(cb, "value", "unit", "cores", "kind", "single_core_msamples_s"), sample=str(cb.get("sample", ""))[:110])
+        if parity is not None:
+            fp, lp = parity["first_pass"], parity["last_pass"]
+            line["parity"] = {"ok": parity["ok"], "first_pass": f"{fp['captures_compared'] - fp['mismatches']}/{fp['captures_compared']}",
+                              "last_pass": f"{lp['captures_compared'] - lp['mismatches']}/{lp['captures_compared']} (pass {lp['pass_number']})"}
+        sm = {"hbm_pct_job": out["hbm_roofline_pct_whole_job"], "valu_frac_k1": vl.get("frac"), "valu_frac_job": (vl.get("whole_job") or {}).get("frac")}
+        if tol is not None:
+            tl = tol.get("last_pass") or {}
+            sm.update(tol=tol.get("value"), tol_diff_lines=tol.get("differing_lines"), tol_last_diff=tl.get("differing_lines"), tol_k1_ms=tol.get("k1_alone_ms"))
+            if tol.get("error"):
+                sm["tol_error"] = tol["error"][:80]
+        for key, short in (("c2_single_stream", "c2"), ("c3_single_stream", "c3_single")):
+            if key in legs:
+                sm[short] = legs[key].get("value")
+                sm[short + "_ok"] = legs[key].get("parity_ok", legs[key].get("error", "")[:60] if legs[key].get("error") else None)
+        if "c3_batch" in legs:
+            cb3 = legs["c3_batch"]
+            sm["c3_batch"] = cb3.get("value")
+            if "parity" in cb3:
+                p3 = cb3["parity"]
+                sm["c3_batch_parity"] = f"{p3['captures_compared'] - p3['mismatches']}/{p3['captures_compared']} first, " \
+                                        f"{p3['last_pass']['captures_compared'] - p3['last_pass']['mismatches']}/{p3['last_pass']['captures_compared']} pass {p3['last_pass']['pass_number']}"
+                sm["c3_k1_ms"] = cb3.get("k1_alone_ms")
+            elif cb3.get("error"):
+                sm["c3_batch_error"] = cb3["error"][:80]
+        if "cli" in legs:
+            sm["cli"] = legs["cli"].get("value"); sm["cli_setup"] = legs["cli"].get("with_setup_msamples_s")
+            if legs["cli"].get("error"):
+                sm["cli_error"] = legs["cli"]["error"][:80]
+        if "cli_1024" in legs:
+            sm["cli_1024"] = legs["cli_1024"].get("value"); sm["cli_1024_setup"] = legs["cli_1024"].get("with_setup_msamples_s")
+        line["summary"] = sm
+        line["details"] = details
+        print(json.dumps(line, separators=(",", ":")), flush=True)
     elif parity is not None:
         ok = bool(parity["ok"]) or a.tolerance_mode
     if batch is not None:

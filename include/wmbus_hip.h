@@ -90,6 +90,19 @@ typedef struct wmbus_cfg {
      * [-1, 1]) instead of bit for bit; RSSI, clock recovery and framers stay exact on those symbols.  A telegram whose
      * decision hangs on the last bits of a soft symbol may decode differently (DESIGN.md section 12 counts them). */
     int tolerance_mode;
+    /* Tuning and test knobs, 0 = the library's default.  (Rounds 1-4 read these from WMBUS_* environment variables inside the
+     * push path; as configuration two contexts of one process can differ, and nothing in a push calls getenv.) */
+    unsigned rounds_on_host;    /* 1: no hand-off rounds are enqueued unattended: every hand-off failure is finished by the host-driven
+                                   path of wmbus_collect (wmbus_timing.slow_path); the GPU test suites run once with it */
+    unsigned rssi_full;         /* 1: the RSSI of every sample in the demodulation kernel even without debug views (A/B of RSSI on demand) */
+    unsigned rssi_dense_pm;     /* RSSI on demand pauses for 16 pushes when more than this many per mille of a push's tiles were listed
+                                   (0: 200; configs[2] lists 310 and is faster on the full pass) */
+    unsigned bursts_to_host;    /* 1: every burst travels to the host packet decoders as chips (round 1's path) instead of being decoded
+                                   on the GPU where it lies inside the push */
+    unsigned burst_caps[4];     /* tests: burst storage {headers, chip words, packets, bytes} (0: sized from the batch), to reach the
+                                   WMBUS_WARN_BURSTS_DROPPED paths */
+    unsigned k1_small_tile;     /* 1: the first pass of the demodulation kernel on 976-sample tiles even where the 2000-sample tile of
+                                   512 threads is available (decimation 2, no -s, RSSI on demand); A/B */
 } wmbus_cfg;
 
 enum { WMBUS_PREFILTER_BOXCAR = 0, WMBUS_PREFILTER_POLYPHASE = 1 };
@@ -122,7 +135,17 @@ typedef struct wmbus_timing {
     unsigned warnings;          /* WMBUS_WARN_* of this push (the push succeeded)     */
     unsigned slow_path;         /* 1: hand-off verification needed more rounds than run on the device unattended, or an
                                    RSSI value computed on demand could not be proven and the push took the full pass */
+    float rssi_ms;              /* RSSI on demand: the launch over the listed tiles (part of gather_ms); 0 otherwise */
+    unsigned rssi_mode;         /* WMBUS_RSSI_*: how this push got its RSSI */
+    unsigned rssi_tiles;        /* RSSI on demand: (tile, capture) pairs listed in this push */
+    unsigned clock_round[4], rla_round[4];   /* segments re-run in the unattended rounds, round by round (beyond the rounds enqueued: 0) */
 } wmbus_timing;
+
+/* wmbus_timing.rssi_mode.  EVERY_SAMPLE: in the demodulation kernel (contexts with debug views, option kernels, cfg.rssi_full).
+ * ON_DEMAND: only where a packet decoder reads it.  PAUSED: an on-demand context whose bursts
+ * cover most of its tiles takes the full pass for sixteen pushes.  FELL_BACK: a value read could not be proven, the push was
+ * finished by the full pass (slow_path is set too). */
+enum { WMBUS_RSSI_EVERY_SAMPLE = 0, WMBUS_RSSI_ON_DEMAND = 1, WMBUS_RSSI_PAUSED = 2, WMBUS_RSSI_FELL_BACK = 3 };
 
 /* The reference never gives up on an input (rtl_wmbus.c:729-803 has no bound); neither does a push.  When an
  * interferer makes the run-length framer emit more chips than even the spill arena holds, or more candidate bursts
@@ -153,7 +176,10 @@ int  wmbus_stage(wmbus_ctx *ctx, unsigned stream, const uint8_t *cu8, size_t nby
  * rate and asynchronously; any other host pointer works too, through the driver's bounce buffer. */
 void *wmbus_alloc_pinned(size_t nbytes);
 void  wmbus_free_pinned(void *p);
-/* Same for HBM-resident producers: device address of the stream's input window. */
+/* Same for HBM-resident producers: device address of the stream's input window.  With one input window (the default) the
+ * window of a push in flight must stay untouched until wmbus_collect has returned: the rare slow paths of a push (a hand-off
+ * repair, the full RSSI pass behind an unprovable on-demand value) read it again at collect time.  wmbus_stage enforces that;
+ * a producer that writes through this pointer has to keep to it itself, or open the context with cfg.input_windows = 2. */
 void *wmbus_device_input(wmbus_ctx *ctx, unsigned stream);
 
 /* Replaces the sample loop rtl_wmbus.c:1310-1356 for `nbytes` staged bytes of every stream:
@@ -174,7 +200,8 @@ long wmbus_read_tap(wmbus_ctx *ctx, const char *what, int chain, unsigned stream
                     void *dst, size_t max_elems);
 /* All chips of the last push for one stream/chain/algo as u32 words
  * [15:8] rssi, [7:0] value (bit0 data, bit1 sync, bit2 framer reset
- * before this chip); `pos` (optional) receives the global decimated-sample index per chip. */
+ * before this chip); `pos` (optional) receives the global decimated-sample index per chip.  A context
+ * opened without cfg.keep_taps computes the RSSI only where a packet decoder reads it: the rssi field is 0 then. */
 long wmbus_read_chips(wmbus_ctx *ctx, int chain, int algo, unsigned stream,
                       uint32_t *dst, uint64_t *pos, size_t max_elems);
 

@@ -43,7 +43,10 @@ class Cfg(ctypes.Structure):
                 ("warmup_t1c1", ctypes.c_uint),
                 ("warmup_s1", ctypes.c_uint), ("rla_lookback", ctypes.c_uint), ("host_threads", ctypes.c_uint),
                 ("keep_taps", ctypes.c_int), ("prefilter", ctypes.c_int), ("atan_mode", ctypes.c_int), ("spill_words", ctypes.c_uint), ("dedup_twins", ctypes.c_int), ("only_crc_ok", ctypes.c_int),
-                ("input_windows", ctypes.c_uint), ("tolerance_mode", ctypes.c_int)]
+                ("input_windows", ctypes.c_uint), ("tolerance_mode", ctypes.c_int),
+                # tuning and test knobs (0 = default), wmbus_hip.h
+                ("rounds_on_host", ctypes.c_uint), ("rssi_full", ctypes.c_uint), ("rssi_dense_pm", ctypes.c_uint), ("bursts_to_host", ctypes.c_uint),
+                ("burst_caps", ctypes.c_uint * 4), ("k1_small_tile", ctypes.c_uint)]
 
 
 class Line(ctypes.Structure):
@@ -57,13 +60,20 @@ class Timing(ctypes.Structure):
                 ("gather_ms", ctypes.c_float), ("d2h_ms", ctypes.c_float), ("gpu_total_ms", ctypes.c_float),
                 ("host_decode_ms", ctypes.c_float), ("clock_reruns", ctypes.c_uint), ("rla_reruns", ctypes.c_uint),
                 ("ema_retries", ctypes.c_uint), ("chips", (ctypes.c_uint64 * 2) * 2), ("bursts", ctypes.c_uint64),
-                ("turn_wait_ms", ctypes.c_float), ("warnings", ctypes.c_uint), ("slow_path", ctypes.c_uint)]
+                ("turn_wait_ms", ctypes.c_float), ("warnings", ctypes.c_uint), ("slow_path", ctypes.c_uint),
+                ("rssi_ms", ctypes.c_float), ("rssi_mode", ctypes.c_uint), ("rssi_tiles", ctypes.c_uint),
+                ("clock_round", ctypes.c_uint * 4), ("rla_round", ctypes.c_uint * 4)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k in ("demod_ms", "clock_ms", "rla_ms", "gather_ms", "d2h_ms", "gpu_total_ms",
-                                           "host_decode_ms", "clock_reruns", "rla_reruns", "ema_retries", "bursts", "turn_wait_ms", "warnings", "slow_path")}
+                                           "host_decode_ms", "clock_reruns", "rla_reruns", "ema_retries", "bursts", "turn_wait_ms", "warnings", "slow_path",
+                                           "rssi_ms", "rssi_mode", "rssi_tiles")}
         d["chips"] = [[int(self.chips[ch][al]) for al in range(2)] for ch in range(2)]      # [chain][algo]
+        d["clock_round"] = [int(v) for v in self.clock_round]; d["rla_round"] = [int(v) for v in self.rla_round]
         return d
+
+
+RSSI_EVERY_SAMPLE, RSSI_ON_DEMAND, RSSI_PAUSED, RSSI_FELL_BACK = 0, 1, 2, 3            # wmbus_timing.rssi_mode
 
 
 FILL_FN = ctypes.CFUNCTYPE(ctypes.c_size_t, ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t)
@@ -160,9 +170,14 @@ def selftest_math(a, b, device=0):
 def _make_cfg(n_streams=1, max_push_bytes=4 << 20, decimation=2, simultaneous=False, accurate_atan=True,
               remove_dc=False, t1c1=True, s1=True, rla=True, time2=True, show_algorithm=True, device=0,
               seg_len=0, rla_seg_len=0, warmup_t1c1=0, warmup_s1=0, rla_lookback=0, host_threads=0, fixed_timestamp=True,
-              prefilter=0, atan_mode=0, keep_taps=True, spill_words=0, input_windows=1, dedup_twins=False, only_crc_ok=False, tolerance_mode=0):
+              prefilter=0, atan_mode=0, keep_taps=True, spill_words=0, input_windows=1, dedup_twins=False, only_crc_ok=False, tolerance_mode=0,
+              rounds_on_host=False, rssi_full=False, rssi_dense_pm=0, bursts_to_host=False, burst_caps=None, k1_small_tile=False):
     c = Cfg()
     lib().wmbus_default_cfg(ctypes.byref(c))
+    # test campaigns (tests/README.md): the whole GPU suite once with every hand-off failure finished by the host-driven path,
+    # once with every burst through the host packet decoders -- defaults of THIS wrapper, the library reads no environment
+    rounds_on_host = rounds_on_host or os.environ.get("WMBUS_TEST_ROUNDS_ON_HOST") == "1"
+    bursts_to_host = bursts_to_host or os.environ.get("WMBUS_TEST_BURSTS_TO_HOST") == "1"
     c.decimation, c.simultaneous, c.accurate_atan, c.remove_dc = decimation, int(simultaneous), int(accurate_atan), int(remove_dc)
     c.t1c1_enabled, c.s1_enabled, c.rla_enabled, c.time2_enabled = int(t1c1), int(s1), int(rla), int(time2)
     c.show_algorithm, c.fixed_timestamp = int(show_algorithm), int(fixed_timestamp)
@@ -171,6 +186,9 @@ def _make_cfg(n_streams=1, max_push_bytes=4 << 20, decimation=2, simultaneous=Fa
     c.rla_lookback, c.host_threads = rla_lookback, host_threads
     c.keep_taps, c.prefilter, c.atan_mode, c.spill_words, c.input_windows = int(keep_taps), prefilter, atan_mode, spill_words, input_windows
     c.dedup_twins, c.only_crc_ok, c.tolerance_mode = int(dedup_twins), int(only_crc_ok), int(tolerance_mode)
+    c.rounds_on_host, c.rssi_full, c.rssi_dense_pm, c.bursts_to_host, c.k1_small_tile = int(rounds_on_host), int(rssi_full), int(rssi_dense_pm), int(bursts_to_host), int(k1_small_tile)
+    for i, v in enumerate(burst_caps or ()):
+        c.burst_caps[i] = int(v)
     return c
 
 

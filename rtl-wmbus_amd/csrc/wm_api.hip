@@ -111,11 +111,9 @@ struct wmbus_ctx {
     char err[256] = {0};
     hipStream_t stream = nullptr;                      /* every kernel of the context */
     hipStream_t copy_stream = nullptr;                 /* wmbus_stage's H2D copies (north_star: "pinned hipMemcpyAsync on a side stream") */
-    hipStream_t side_stream = nullptr;                 /* run-length framer beside the clock kernel's re-run rounds (see enqueue_front_impl); nullptr: one stream */
-    hipEvent_t ev[11] = {};                            /* [9], [10]: side-stream interval (timing) */
+    hipEvent_t ev[11] = {};                            /* [9], [10]: the RSSI launch over the listed tiles (timing) */
     hipEvent_t ev_staged = nullptr;                    /* recorded on copy_stream at process(): the push's input is in HBM */
     hipEvent_t ev_turn = nullptr;                       /* behind the main part of this context's K1: the next context's K1 waits for it */
-    hipEvent_t ev_ready = nullptr, ev_fork = nullptr, ev_join = nullptr;   /* cross-stream order only (no timing): input ready for K1; fork / join of the side stream */
     uint32_t n_win = 1, fill = 0;                      /* input windows (cfg.input_windows) and the one wmbus_stage fills now */
     /* geometry */
     uint32_t d = 2, S = 1, C[2] = {8192, 32768}, Mcap = 0, nseg_cap[2] = {0, 0}, ntiles_cap = 0, T = WM_K1_TILE2;
@@ -147,11 +145,12 @@ struct wmbus_ctx {
     unsigned ema_rounds = 1, fr_rounds = 2, rla_rounds = 3;   /* hand-off rounds enqueued unattended, see WM_MAX_ROUNDS; the run-length framer's
                                                           counters start at index 1 (its list rounds: 1 .. rla_rounds - 1) */
     unsigned rla_fin = 3;                               /* this push: index of the run-length framer's last (unattended) verification */
+    bool opt_rounds = true;                             /* hand-off rounds are enqueued unattended (cfg.rounds_on_host = 0) */
     bool poisoned = false, gpu_decode = true;                              /* an internal error left the carried state undefined */
     uint32_t *d_first_bad = nullptr;                    /* [2][S] first uncertified EMA tile of a row, or ~0 */
     /* RSSI on demand (wm_k1_demod.h): the first pass leaves the RSSI out, k3_spans lists the tiles whose RSSI is read, an
      * RS = 2 launch computes those.  Off for contexts with debug taps (they show every sample's RSSI) and for the option
-     * kernels; WMBUS_RSSI_FULL=1 turns it off for A/Bs. */
+     * kernels; cfg.rssi_full turns it off for A/Bs. */
     bool rs_od = false, rs_full_now = false;            /* rs_full_now: this push has fallen back to the full pass */
     bool rs_this = false;                               /* this push runs on demand (a context whose bursts cover most of its tiles takes the full pass for a while) */
     unsigned rs_pause = 0;                              /* pushes left before on demand is tried again */
@@ -161,7 +160,7 @@ struct wmbus_ctx {
     uint32_t *d_ckpt = nullptr; uint32_t nck = 0;       /* clock kernel checkpoints [2][S][nseg_cap][nck][16] */
     uint32_t *d_bad = nullptr;                          /* [2][nseg_cap[0]][S] the run-length verifier's verdict per segment (K2Args.bad) */
     uint32_t *d_bad_clk = nullptr;                      /* [2][nseg_cap[1]][S] the clock verifier's */
-    bool rla_chains = false;                            /* the chain walk is in use (switched on by the first push whose unattended rounds did not suffice) */
+    bool rla_chains = true;                             /* the run-length re-run lanes walk chains from their second list round on (K2Args.bad) */
     uint2 *d_hits = nullptr; uint32_t hits_cap = 0;
     uint32_t *d_pending = nullptr;
     uint32_t hdr_cap = 0, words_cap = 0, pkts_cap = 0, bytes_cap = 0;
@@ -172,7 +171,7 @@ struct wmbus_ctx {
     WmPkt *h_pkts = nullptr; uint8_t *h_bytes = nullptr;
     void *dv_hdr = nullptr, *dv_words = nullptr, *dv_pkts = nullptr, *dv_bytes = nullptr;    /* their device views */
     uint32_t n_hdr = 0, n_words = 0, n_pkts = 0;
-    K1Args k1a{}; K2Args k2clk{}, k2rla{}; uint32_t ntiles = 0; bool fused = false, forked = false;    /* this push's launch arguments (collect's slow path re-uses them) */
+    K1Args k1a{}; K2Args k2clk{}, k2rla{}; uint32_t ntiles = 0;    /* this push's launch arguments (collect's slow path re-uses them) */
     std::vector<HostDecoder> decs;                      /* [stream][chain][algo] */
     std::vector<wm_twin> twins;                         /* [stream][chain][2]: the last lines printed (cfg.dedup_twins) */
     std::unique_ptr<WorkerPool> pool;                   /* packet-decoder workers, created on first use */
@@ -214,10 +213,8 @@ enum { WM_MAX_DEVICES = 64 };                    /* per-device tables (K1 order,
  * workload: clock re-runs 1400, then < 10, then 0; run-length 2300, then 0; a third costs every push 0.2 ms of empty launches).
  * A small batch is bound by its chain of dependent launches and by every host round trip in it, and its short segments
  * (wmbus_open) cascade further: it enqueues more rounds, so that the host-driven path (0.5 ms per round) stays the exception. */
-enum { WM_MAX_ROUNDS = 6 };                     /* counters per kind: rounds + 1 <= 8 (SC_* below) */
-/* debugging aid: WMBUS_OPT_ROUNDS=0 skips the unattended re-run launches (the counters of the rounds stay zero), so
- * that every hand-off failure is finished by the host-driven path */
-static const bool opt_rounds = !(getenv("WMBUS_OPT_ROUNDS") && atoi(getenv("WMBUS_OPT_ROUNDS")) == 0);
+enum { WM_MAX_ROUNDS = 6 };
+enum { WM_K3_BLOCKS = 64, WM_RS_BLOCKS = 2048 };   /* bounded grids of the burst kernels and of the RSSI launch over the listed tiles (launch_k3) */                     /* counters per kind: rounds + 1 <= 8 (SC_* below) */
 enum { SC_ERR = 0, SC_NHITS = 1, SC_NHDR = 2, SC_NWORDS = 3, SC_NPKTS = 4, SC_NBYTES = 5, SC_SLOW = 6, SC_CHIPS = 8 /* [algo][chain] */,
        SC_RS_N = 12 /* tiles listed for the RSSI-on-demand launch */, SC_RS_FAIL = 13 /* a lane that is read could not prove its value */,
        SC_EMA = 16 /* [ema_rounds + 1] */, SC_CLK = 24 /* [fr_rounds + 1] */, SC_RLA = 32 /* [rla_rounds + 1] */, SC_COUNT = 40 };
@@ -376,7 +373,9 @@ void wmbus_close(wmbus_ctx *c)
 {
     if (!c) return;
     if (c->stream) hipStreamSynchronize(c->stream);
-    {
+    /* an open that was refused before it had a stream (bad device ordinal, bad geometry: the caller closes the handle it reads
+     * the message from) never took part in the K1 order, and its cfg.device may lie outside the table */
+    if (c->stream && c->cfg.device >= 0 && c->cfg.device < WM_MAX_DEVICES) {
         K1Chain &kc = k1_chain[c->cfg.device];
         std::lock_guard<std::mutex> lk(kc.m);
         if (kc.owner == c) { kc.last = nullptr; kc.owner = nullptr; }      /* nobody may wait on an event that is about to go */
@@ -389,8 +388,7 @@ void wmbus_close(wmbus_ctx *c)
     void *host[] = {c->h_scalars, c->h_hdr, c->h_words, c->h_pending, c->h_pkts, c->h_bytes};
     for (void *p : host) if (p) hipHostFree(p);
     for (auto &e : c->ev) if (e) hipEventDestroy(e);
-    for (hipEvent_t e : {c->ev_staged, c->ev_ready, c->ev_fork, c->ev_join, c->ev_turn}) if (e) hipEventDestroy(e);
-    if (c->side_stream) { hipStreamSynchronize(c->side_stream); hipStreamDestroy(c->side_stream); }
+    for (hipEvent_t e : {c->ev_staged, c->ev_turn}) if (e) hipEventDestroy(e);
     if (c->copy_stream && c->copy_stream != c->stream) { hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); }
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -447,7 +445,7 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
                (cfg->t1c1_enabled ? WM_F_T1C1 : 0) | (cfg->s1_enabled ? WM_F_S1 : 0) | (cfg->rla_enabled ? WM_F_RLA : 0) |
                (cfg->time2_enabled ? WM_F_T2A : 0);
     if (c->S < 64u) { c->ema_rounds = 2; c->fr_rounds = 5; }
-    if (const char *r_ = getenv("WMBUS_FR_ROUNDS")) c->fr_rounds = std::min<unsigned>(std::max(1, atoi(r_)), WM_MAX_ROUNDS);      /* tuning aid */
+    c->opt_rounds = !cfg->rounds_on_host;
     /* the run-length framer gets as many list rounds as the clock kernel (round 3: one fewer -- enough for 1.6 MS/s captures,
      * "2300 re-runs, then 0", but configs[2] (-d 5 -s) leaves 750 lanes after the first round and fell to the host-driven
      * path on EVERY push: 64 ms per step instead of 25) */
@@ -480,19 +478,7 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
     if (c->n_win == 2) A(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking)); else c->copy_stream = c->stream;
     for (auto &ev : c->ev) A(hipEventCreate(&ev));
     A(hipEventCreateWithFlags(&c->ev_staged, hipEventDisableTiming));
-    A(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
     A(hipEventCreateWithFlags(&c->ev_turn, hipEventDisableTiming));
-    A(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    A(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-    {
-        /* the run-length framer beside the clock kernel's re-run rounds (second stream, see enqueue_front_impl): shortens a
-         * context's chain of dependent launches by 4-5 ms -- and doubles the streams that compete for the hardware queues.
-         * Round 4 A/B (one box visit): exact 8 contexts 114 against 128, tolerance mode 12 contexts 117 against 148, with
-         * GPU_MAX_HW_QUEUES=24 no better.  OFF; WMBUS_RLA_SIDE=1 turns it on for experiments. */
-        const char *e_ = getenv("WMBUS_RLA_SIDE");
-        const bool side = e_ ? atoi(e_) != 0 : false;
-        if (side && cfg->rla_enabled && !cfg->remove_dc) A(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
-    }
     A(dalloc(&c->d_in, (size_t)c->in_stride * c->S * c->n_win));
     A(dalloc(&c->d_hist, (size_t)WM_HIST_BYTES * c->S));
     A(dalloc(&c->d_dphi, (size_t)rows * c->Mcap));
@@ -505,12 +491,11 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
     A(dalloc(&c->d_first_bad, (size_t)rows));
     {
         const uint32_t need = WM_F_ACCURATE | WM_F_T1C1 | WM_F_S1, never = WM_F_APPROX1 | WM_F_APPROX2;
-        static const bool rs_full = getenv("WMBUS_RSSI_FULL") && atoi(getenv("WMBUS_RSSI_FULL")) != 0;
-        c->rs_od = !rs_full && !cfg->keep_taps && cfg->prefilter != WMBUS_PREFILTER_POLYPHASE && c->d >= 2 && c->d <= 5 &&
+        c->rs_od = !cfg->rssi_full && !cfg->keep_taps && cfg->prefilter != WMBUS_PREFILTER_POLYPHASE && c->d >= 2 && c->d <= 5 &&
                    (c->flags & need) == need && !(c->flags & never);
         /* the larger tile of the first pass: decimation 2 without -s (the LDS of a 512-thread block at d >= 3 or with the -s staging
          * would cost more occupancy than the halo saves) */
-        c->k1_big = c->rs_od && c->d == 2 && !(c->flags & WM_F_SHIFT) && !(getenv("WMBUS_K1_NT") && atoi(getenv("WMBUS_K1_NT")) == 256);
+        c->k1_big = c->rs_od && c->d == 2 && !(c->flags & WM_F_SHIFT) && !cfg->k1_small_tile;
         c->k1_tail_pm = cfg->tolerance_mode ? 0u : 60u;
         if (c->rs_od) { A(dalloc(&c->d_rs_flags, (size_t)c->ntiles_cap * c->S)); A(dalloc(&c->d_rs_list, (size_t)c->ntiles_cap * c->S)); }
     }
@@ -546,33 +531,24 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
     /* bursts that still travel as chips are the ones whose plan reaches past the end of the push (every such hit is
      * shipped with the chips up to the end, at most 16 x 290 + 1 of them) and the continuations of those the decoders
      * took: room for two longest bursts per (capture, chain, framer); beyond that bursts are dropped with a warning */
-    c->gpu_decode = !(getenv("WMBUS_GPU_DECODE") && atoi(getenv("WMBUS_GPU_DECODE")) == 0);    /* 0: every burst to the host decoders as chips (A/B, tests) */
+    c->gpu_decode = !cfg->bursts_to_host;                /* else: every burst to the host decoders as chips (A/B, tests) */
     c->words_cap = c->gpu_decode ? (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1u << 20, 4ull * c->S * 2 * WM_MAXCHIPS_S1), 1u << 28)
                                  : (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1u << 20, dec_total / 8), 1u << 29);
     c->pkts_cap = c->hdr_cap;
     c->bytes_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1u << 20, dec_total / 64), 1u << 30);
-    if (const char *caps = getenv("WMBUS_DEBUG_BURST_CAPS")) {     /* tests: "hdr:words:pkts:bytes" -- tiny burst storage, to reach the overflow paths */
-        unsigned v[4] = {c->hdr_cap, c->words_cap, c->pkts_cap, c->bytes_cap};
-        if (sscanf(caps, "%u:%u:%u:%u", &v[0], &v[1], &v[2], &v[3]) == 4) { c->hdr_cap = v[0]; c->words_cap = v[1]; c->pkts_cap = v[2]; c->bytes_cap = v[3]; }
-    }
+    if (cfg->burst_caps[0]) { c->hdr_cap = cfg->burst_caps[0]; c->hits_cap = std::max(c->hits_cap, c->hdr_cap); }      /* tests: tiny burst storage, to reach the overflow paths */
+    if (cfg->burst_caps[1]) c->words_cap = cfg->burst_caps[1];
+    if (cfg->burst_caps[2]) c->pkts_cap = cfg->burst_caps[2];
+    if (cfg->burst_caps[3]) c->bytes_cap = cfg->burst_caps[3];
     A(dalloc(&c->d_hits, (size_t)c->hits_cap));
     A(dalloc(&c->d_pending, (size_t)4 * c->S));
-    {
-        /* WMBUS_RLA_CHAINS: 0 = every listed segment on its own (r03), 1 = the chain walk switched on by need, 2 (default) = from
-         * the first push (r04 A/B, bench workload: 148.3 / 150.2 | 149.3 / 149.5 | 147.3 / 149.7 Gsamples/s for 1 | 0 | 2: no difference).  (Zeroed on the context's own stream: a synchronous hipMemset runs on the NULL stream, whose hardware
-         * queue then takes part in the round-robin of streams onto queues -- eight contexts lost 5 % to that in this round's A/Bs.) */
-        static const int chains = getenv("WMBUS_RLA_CHAINS") ? atoi(getenv("WMBUS_RLA_CHAINS")) : 2;
-        if (chains) {
-            A(dalloc(&c->d_bad, (size_t)rows * c->nseg_cap[0]));
-            if (e == hipSuccess) A(hipMemsetAsync(c->d_bad, 0, (size_t)rows * c->nseg_cap[0] * sizeof(uint32_t), c->stream));
-            c->rla_chains = chains == 2;
-        }
-        static const bool clk_chains = !(getenv("WMBUS_CLK_CHAINS") && atoi(getenv("WMBUS_CLK_CHAINS")) == 0);
-        if (clk_chains) {
-            A(dalloc(&c->d_bad_clk, (size_t)rows * c->nseg_cap[1]));
-            if (e == hipSuccess) A(hipMemsetAsync(c->d_bad_clk, 0, (size_t)rows * c->nseg_cap[1] * sizeof(uint32_t), c->stream));
-        }
-    }
+    /* the verifiers' verdict per segment, for the chain walk of the re-run lanes (K2Args.bad).  Zeroed on the context's own stream: a
+     * synchronous hipMemset runs on the NULL stream, whose hardware queue then takes part in the round-robin of streams onto
+     * queues -- eight contexts lost 5 % to that in round 4's A/Bs. */
+    A(dalloc(&c->d_bad, (size_t)rows * c->nseg_cap[0]));
+    if (e == hipSuccess) A(hipMemsetAsync(c->d_bad, 0, (size_t)rows * c->nseg_cap[0] * sizeof(uint32_t), c->stream));
+    A(dalloc(&c->d_bad_clk, (size_t)rows * c->nseg_cap[1]));
+    if (e == hipSuccess) A(hipMemsetAsync(c->d_bad_clk, 0, (size_t)rows * c->nseg_cap[1] * sizeof(uint32_t), c->stream));
     A(hipHostMalloc((void **)&c->h_scalars, SC_COUNT * sizeof(uint32_t)));
     A(hipHostMalloc((void **)&c->h_hdr, (size_t)c->hdr_cap * sizeof(WmBurstHdr)));
     A(hipHostMalloc((void **)&c->h_words, (size_t)c->words_cap * sizeof(uint32_t)));
@@ -735,20 +711,6 @@ static void fr_launch(wmbus_ctx *c, int algo, uint32_t cnt, hipStream_t st = nul
     else hipLaunchKernelGGL(k2_clock_list<false>, dim3(grid), dim3(B), 0, st, a);
 }
 
-/* the fused launch: clock re-run list (scalar cnt_c) + run-length framer, all lanes (cnt_r == ~0) or its list */
-static void fr_launch_fused(wmbus_ctx *c, uint32_t cnt_c, uint32_t cnt_r)
-{
-    K2Args ca = c->k2clk, ra = c->k2rla;
-    ca.list = c->d_list; ca.n_ptr = c->d_scalars + cnt_c; ca.n_lanes = 0;
-    const uint32_t lanes_r = 2u * ra.g.nseg[0] * ra.g.S, Br = 64 * WM_RLA_WPB;
-    const bool all = cnt_r == 0xFFFFFFFFu;
-    ra.list = all ? nullptr : c->d_list2; ra.n_lanes = lanes_r; ra.n_ptr = all ? nullptr : c->d_scalars + cnt_r;
-    const uint32_t lanes_c = 2u * ca.g.nseg[1] * ca.g.S;
-    const uint32_t cb = std::max(32u, (lanes_c / 64u) * 3u / 16u);           /* one clock wave per block here; blocks for 3/16 of the lanes */
-    const uint32_t rb = all ? (lanes_r + Br - 1) / Br : std::max(16u, (lanes_r / Br) * 3u / 16u);
-    hipLaunchKernelGGL(k2_clock_rla, dim3(cb + rb), dim3(Br), 0, c->stream, ca, ra, cb);
-}
-
 static void fr_carry(wmbus_ctx *c)
 {
     const uint32_t rows = 2u * c->S;
@@ -792,20 +754,19 @@ static int launch_k3(wmbus_ctx *c, bool again)
         /* RSSI on demand: which tiles do the bursts touch (k3_spans), then their RSSI (an RS = 2 launch of the demodulation
          * kernel over the list, a fixed grid), then the bursts */
         HIPCHK(c, hipMemsetAsync(c->d_rs_flags, 0, (size_t)c->ntiles * c->S * sizeof(uint32_t), c->stream));
-        static const uint32_t span_blocks = getenv("WMBUS_K3_BLOCKS") ? (uint32_t)atoi(getenv("WMBUS_K3_BLOCKS")) : 64u;
-        hipLaunchKernelGGL(k3_spans, dim3(std::max(1u, std::min((4 * c->S + c->hits_cap + 3u) / 4u, span_blocks))), dim3(256), 0, c->stream, k3, c->T, c->ntiles,
+        hipLaunchKernelGGL(k3_spans, dim3(std::max(1u, std::min((4 * c->S + c->hits_cap + 3u) / 4u, (uint32_t)WM_K3_BLOCKS))), dim3(256), 0, c->stream, k3, c->T, c->ntiles,
                            c->d_rs_flags, c->d_rs_list, c->d_scalars + SC_RS_N);
         K1Args k1 = c->k1a;
         k1.relist = c->d_rs_list; k1.n_relist = c->d_scalars + SC_RS_N;
-        static const uint32_t rs_blocks = getenv("WMBUS_RS_BLOCKS") ? (uint32_t)atoi(getenv("WMBUS_RS_BLOCKS")) : 2048u;
-        const int rc = launch_k1_any(c, k1, dim3(std::max(1u, std::min(rs_blocks, c->ntiles * c->S)), 1), nullptr, 2);
+        HIPCHK(c, hipEventRecord(c->ev[9], c->stream));
+        const int rc = launch_k1_any(c, k1, dim3(std::max(1u, std::min((uint32_t)WM_RS_BLOCKS, c->ntiles * c->S)), 1), nullptr, 2);    /* r04 A/B: 512 / 1024 / 2048 / 4096 blocks: no difference */
         if (rc) return rc;
+        HIPCHK(c, hipEventRecord(c->ev[10], c->stream));
     }
     /* Few blocks: a latency-bound wave parked on a SIMD costs the demodulation kernel one of its eight wave slots there
      * for as long as it lives; 256 blocks put one on every SIMD of the chip (r02 sweep: 256 -> 64 blocks + 6 %, 16 blocks - 9 %: then the kernel itself becomes the longest link of the chain) */
-    static const uint32_t max_blocks = getenv("WMBUS_K3_BLOCKS") ? (uint32_t)atoi(getenv("WMBUS_K3_BLOCKS")) : 64u;
     const uint32_t most = 4 * c->S + c->hits_cap;
-    hipLaunchKernelGGL(k3_bursts, dim3(std::max(1u, std::min((most + 3u) / 4u, max_blocks))), dim3(256), 0, c->stream, k3, 0xFFFFFFFFu);
+    hipLaunchKernelGGL(k3_bursts, dim3(std::max(1u, std::min((most + 3u) / 4u, (uint32_t)WM_K3_BLOCKS))), dim3(256), 0, c->stream, k3, 0xFFFFFFFFu);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -831,8 +792,7 @@ static int enqueue_front_impl(wmbus_ctx *c, size_t nbytes)
         g.seg_len[al] = c->C[al]; g.nseg[al] = (g.M + c->C[al] - 1) / c->C[al]; g.nseg_cap[al] = c->nseg_cap[al]; g.cap[al] = c->cap[al];
     }
     g.warm[0] = c->cfg.warmup_t1c1; g.warm[1] = c->cfg.warmup_s1; g.lookback = c->cfg.rla_lookback;
-    static const uint32_t s1_span = getenv("WMBUS_S1_SPAN") ? (uint32_t)atoi(getenv("WMBUS_S1_SPAN")) : 1u;    /* tuning aid, see WmPush.s1_span */
-    g.s1_span = s1_span;
+    g.s1_span = 1u;                                     /* (2: S1 clock lanes over two segments -- built and measured in rounds 2-4, -2 %: the kernels keep the form) */
     g.sp.arena = c->d_spill; g.sp.arena_words = c->spill_words; g.sp.chain = c->d_chain; g.sp.nchain = c->d_nchain;
     g.sp.used = c->d_nchain + (size_t)2 * c->S * c->nseg_cap[0];
     c->last = g; c->have_last = true;
@@ -852,7 +812,7 @@ static int enqueue_front_impl(wmbus_ctx *c, size_t nbytes)
         const uint32_t T = c->T, ntiles = (g.M + T - 1) / T;
         c->ntiles = ntiles;
         /* on demand pays while the bursts touch a minority of the tiles (an RS = 2 tile costs a third of a full one, and the
-         * first pass saves a seventh): a context that has just listed more than WMBUS_RS_MAX per mille of them (configs[2]: S1
+         * first pass saves a seventh): a context that has just listed more than cfg.rssi_dense_pm per mille of them (configs[2]: S1
          * telegrams of 30-100 ms in both chains) takes the full pass for the next sixteen pushes, then looks again
          * (r04 visit: configs[2] lists 31 % of its tiles and loses 7 % on demand -- its front end, five input samples per decimated one
          * through the -s rotation, is most of the kernel; the bench workload lists 11 % and gains 5-7 %) */
@@ -894,7 +854,7 @@ static int enqueue_front_impl(wmbus_ctx *c, size_t nbytes)
          * count there, the results land in pinned host memory.  wmbus_collect looks at the last counters. */
         c->rs_full_now = false;
         if (!c->rs_this) {                                      /* (on demand: the RSSI comes behind the framers, launch_k3) */
-            for (unsigned r = 0; r < c->ema_rounds && opt_rounds; r++) {
+            for (unsigned r = 0; r < c->ema_rounds && c->opt_rounds; r++) {
                 ema_verify(c, SC_EMA + r);
                 rc = ema_repair(c, SC_EMA + r);
                 if (rc) return rc;
@@ -916,49 +876,21 @@ static int enqueue_front_impl(wmbus_ctx *c, size_t nbytes)
         kr.algo = WMBUS_ALGO_RLA; kr.bad = c->rla_chains ? c->d_bad : nullptr;
         kr.chips = c->d_chips[0]; kr.counts = c->d_counts[0]; kr.sync_seen = c->d_sync_seen[0];
         kr.st_start = c->d_st_start[0]; kr.st_final = c->d_st_final[0]; kr.st_carry = st_carry(c, 0, false);
-        /* fused framer launches (clock re-run lanes + run-length framer in one launch) were worth 4 ms of a context's
-         * dependent chain while every round cost a host round trip; with the rounds enqueued unattended the plain
-         * sequence is 6 % faster for the whole job (r02 sweep: 144.6 / 140.8 against 135.2 / 133.6 Gsamples/s) */
-        static const bool fuse = getenv("WMBUS_FUSE_FRAMERS") && atoi(getenv("WMBUS_FUSE_FRAMERS")) != 0;   /* tuning aid */
+        /* One stream, one launch after the other: clock first pass, its unattended re-run rounds, then the run-length framer and its
+         * rounds.  (Rounds 2-4 built and measured the alternatives -- the clock re-run lanes and the run-length framer fused into one
+         * launch; the run-length framer on a side stream beside the clock rounds -- both shorten a context's chain of launches by
+         * 4-5 ms and both LOSE: the job is bound by the ring of demodulation kernels, and more streams or fatter launches only
+         * get in its way; DESIGN_HISTORY.md.) */
         const bool rla = c->flags & WM_F_RLA;
-        c->fused = rla && !(c->flags & WM_F_DC) && fuse;
-        c->forked = false;
         HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
         fr_launch(c, WMBUS_ALGO_T2A, 0xFFFFFFFFu);                 /* the clock kernel's first pass */
-        if (c->fused) {
-            /* Without the DC remover the slicer words are final after the clock kernel's FIRST pass, so the run-length
-             * framer (main pass, then its own re-run lists) rides in the launches that carry the clock re-run lanes. */
-            for (unsigned r = 0; r < (opt_rounds ? (unsigned)c->fr_rounds : 1u); r++) {     /* round 0 carries the run-length framer's main pass */
-                fr_verify(c, WMBUS_ALGO_T2A, SC_CLK + r);
-                if (r) fr_verify(c, WMBUS_ALGO_RLA, SC_RLA + r);
-                fr_launch_fused(c, SC_CLK + r, r ? SC_RLA + r : 0xFFFFFFFFu);
-            }
-            HIPCHK(c, hipEventRecord(c->ev[8], c->stream));
-        } else if (rla && c->side_stream && !(c->flags & WM_F_DC)) {
-            /* Without the DC remover the slicer words are final after the clock kernel's FIRST pass (the sign of a soft
-             * symbol carries no state), so the run-length framer and its re-run round need not wait for the clock
-             * kernel's re-run rounds: they run beside them on the context's side stream, 4-5 ms off the context's chain
-             * of dependent launches. */
-            HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
-            HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
-            HIPCHK(c, hipEventRecord(c->ev[9], c->side_stream));
-            fr_launch(c, WMBUS_ALGO_RLA, 0xFFFFFFFFu, c->side_stream);
-            for (unsigned r = 1; r < c->rla_rounds && opt_rounds; r++) { fr_verify(c, WMBUS_ALGO_RLA, SC_RLA + r, c->side_stream); fr_launch(c, WMBUS_ALGO_RLA, SC_RLA + r, c->side_stream); }
-            HIPCHK(c, hipEventRecord(c->ev[10], c->side_stream));
-            HIPCHK(c, hipEventRecord(c->ev_join, c->side_stream));
-            for (unsigned r = 0; r < c->fr_rounds && opt_rounds; r++) { fr_verify(c, WMBUS_ALGO_T2A, SC_CLK + r); fr_launch(c, WMBUS_ALGO_T2A, SC_CLK + r); }
-            HIPCHK(c, hipEventRecord(c->ev[8], c->stream));
-            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
-            c->forked = true;
-        } else {
-            for (unsigned r = 0; r < c->fr_rounds && opt_rounds; r++) { fr_verify(c, WMBUS_ALGO_T2A, SC_CLK + r); fr_launch(c, WMBUS_ALGO_T2A, SC_CLK + r); }
-            HIPCHK(c, hipEventRecord(c->ev[8], c->stream));
-            if (rla) {
-                fr_launch(c, WMBUS_ALGO_RLA, 0xFFFFFFFFu);
-                for (unsigned r = 1; r < c->rla_rounds && opt_rounds; r++) { fr_verify(c, WMBUS_ALGO_RLA, SC_RLA + r); fr_launch(c, WMBUS_ALGO_RLA, SC_RLA + r); }
-            } else HIPCHK(c, hipMemsetAsync(c->d_counts[0], 0, (size_t)2 * c->S * c->nseg_cap[0] * sizeof(uint32_t), c->stream));
-        }
-        c->rla_fin = c->fused ? c->fr_rounds : c->rla_rounds;
+        for (unsigned r = 0; r < c->fr_rounds && c->opt_rounds; r++) { fr_verify(c, WMBUS_ALGO_T2A, SC_CLK + r); fr_launch(c, WMBUS_ALGO_T2A, SC_CLK + r); }
+        HIPCHK(c, hipEventRecord(c->ev[8], c->stream));
+        if (rla) {
+            fr_launch(c, WMBUS_ALGO_RLA, 0xFFFFFFFFu);
+            for (unsigned r = 1; r < c->rla_rounds && c->opt_rounds; r++) { fr_verify(c, WMBUS_ALGO_RLA, SC_RLA + r); fr_launch(c, WMBUS_ALGO_RLA, SC_RLA + r); }
+        } else HIPCHK(c, hipMemsetAsync(c->d_counts[0], 0, (size_t)2 * c->S * c->nseg_cap[0] * sizeof(uint32_t), c->stream));
+        c->rla_fin = c->rla_rounds;
         fr_verify(c, WMBUS_ALGO_T2A, SC_CLK + c->fr_rounds);
         if (rla) fr_verify(c, WMBUS_ALGO_RLA, SC_RLA + c->rla_fin);
         HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
@@ -1212,9 +1144,9 @@ static int wait_gpu(wmbus_ctx *c)
         float ms = 0;
         hipEventElapsedTime(&ms, c->ev[3], c->ev[4]); c->tim.demod_ms = ms;
         hipEventElapsedTime(&ms, c->ev[2], c->ev[3]); c->tim.turn_wait_ms = ms;  /* on the GPU: behind the other contexts' demodulation kernels */
-        hipEventElapsedTime(&ms, c->ev[0], c->ev[8]); c->tim.clock_ms = ms;      /* fused: every framer launch; else the clock kernel's */
-        if (c->forked) { hipEventElapsedTime(&ms, c->ev[9], c->ev[10]); c->tim.rla_ms = ms; }   /* side stream: beside the clock kernel's re-run rounds */
-        else { hipEventElapsedTime(&ms, c->ev[8], c->ev[1]); c->tim.rla_ms = ms; }                /* un-fused: the run-length framer's launches */
+        hipEventElapsedTime(&ms, c->ev[0], c->ev[8]); c->tim.clock_ms = ms;      /* the clock kernel's launches */
+        hipEventElapsedTime(&ms, c->ev[8], c->ev[1]); c->tim.rla_ms = ms;        /* the run-length framer's */
+        if (c->rs_this) { hipEventElapsedTime(&ms, c->ev[9], c->ev[10]); c->tim.rssi_ms = ms; }
         hipEventElapsedTime(&ms, c->ev[5], c->ev[6]); c->tim.gather_ms = ms;
         hipEventElapsedTime(&ms, c->ev[6], c->ev[7]); c->tim.d2h_ms = ms;
         hipEventElapsedTime(&ms, c->ev[2], c->ev[7]); c->tim.gpu_total_ms = ms;
@@ -1224,25 +1156,21 @@ static int wait_gpu(wmbus_ctx *c)
         for (unsigned r = 0; r < c->rla_fin; r++) c->tim.rla_reruns += hs[SC_RLA + r];
         const bool ema_left = hs[SC_EMA + c->ema_rounds], clk_left = hs[SC_CLK + c->fr_rounds], rla_left = hs[SC_RLA + c->rla_fin];
         const bool rs_left = c->rs_this && hs[SC_RS_FAIL] != 0;
-        static const bool dbg_rounds = getenv("WMBUS_DEBUG_ROUNDS") != nullptr;
-        if (dbg_rounds)
-            fprintf(stderr, "rounds: ema %u %u | clock %u %u %u %u | rla %u %u %u %u\n", hs[SC_EMA], hs[SC_EMA + 1], hs[SC_CLK], hs[SC_CLK + 1], hs[SC_CLK + 2],
-                    hs[SC_CLK + 3], hs[SC_RLA], hs[SC_RLA + 1], hs[SC_RLA + 2], hs[SC_RLA + 3]);   /* entries beyond the rounds compiled in stay 0 */
-        /* The chain walk of the run-length re-run lanes (rla_lanes) is switched on by need: a stream whose bursts outlast a
-         * segment (configs[2]: every push) leaves lanes listed behind the unattended rounds ONCE, and from its next push on the
-         * second list round walks chains and settles them on the device.  A stream that never does (the bench workload) never
-         * pays for the verdict flags -- measured with them always on: 142 against 150 Gsamples/s, although the kernels' own
-         * durations did not move (r04, visits q / p). */
-        if (rla_left && c->d_bad) c->rla_chains = true;
+        for (unsigned r = 0; r < 4; r++) {
+            c->tim.clock_round[r] = r < c->fr_rounds ? hs[SC_CLK + r] : 0u;
+            c->tim.rla_round[r] = r + 1u < c->rla_fin ? hs[SC_RLA + 1u + r] : 0u;     /* the run-length framer's counters start at index 1 */
+        }
+        c->tim.rssi_mode = c->rs_this ? WMBUS_RSSI_ON_DEMAND : c->rs_od ? WMBUS_RSSI_PAUSED : WMBUS_RSSI_EVERY_SAMPLE;
         if (c->rs_this) {
-            static const uint32_t rs_max = getenv("WMBUS_RS_MAX") ? (uint32_t)atoi(getenv("WMBUS_RS_MAX")) : 200u;
-            if ((uint64_t)hs[SC_RS_N] * 1000u > (uint64_t)rs_max * c->ntiles * c->S) c->rs_pause = 16;
-            if (dbg_rounds) fprintf(stderr, "rssi on demand: %u of %u tiles listed%s\n", hs[SC_RS_N], c->ntiles * c->S, hs[SC_RS_FAIL] ? ", unproven: full pass" : "");
+            c->tim.rssi_tiles = hs[SC_RS_N];
+            const uint32_t dense_pm = c->cfg.rssi_dense_pm ? c->cfg.rssi_dense_pm : 200u;
+            if ((uint64_t)hs[SC_RS_N] * 1000u > (uint64_t)dense_pm * c->ntiles * c->S) c->rs_pause = 16;
         }
         if (ema_left || clk_left || rla_left || rs_left) {
             const int rc = finish_slowly(c, ema_left, clk_left, rla_left, rs_left);
             if (rc) { c->poisoned = true; return rc; }
             c->tim.slow_path = 1;
+            if (c->rs_full_now) c->tim.rssi_mode = WMBUS_RSSI_FELL_BACK;
         }
         const uint32_t err = hs[SC_ERR];
         if (err & WM_ERR_CHIP_OVERFLOW) {            /* a time2 region over its proven bound: a defect, not an input property */
@@ -1406,8 +1334,10 @@ long wmbus_read_chips(wmbus_ctx *c, int chain, int algo, unsigned stream, uint32
         hipFree(d_dst); hipFree(d_pos); hipFree(d_n);            /* hipFree(nullptr) is a no-op */
         return WMBUS_ENOMEM;
     }
+    /* a context without debug views computes the RSSI only in the tiles a packet decoder reads (RSSI on demand): elsewhere its rows hold
+     * nothing, so this view shows 0 there instead of what an earlier push left */
     hipLaunchKernelGGL(k4_flatten, dim3(1), dim3(1), 0, c->stream, c->last, (uint32_t)algo, c->d_chips[algo], c->d_counts[algo],
-                       c->d_rssi, c->cap[algo], (uint32_t)chain, stream, d_dst, d_pos, (uint32_t)max_elems, d_n);
+                       c->rs_od ? (const uint8_t *)nullptr : c->d_rssi, c->cap[algo], (uint32_t)chain, stream, d_dst, d_pos, (uint32_t)max_elems, d_n);
     uint32_t n = 0;
     hipStreamSynchronize(c->stream);
     hipMemcpy(&n, d_n, 4, hipMemcpyDeviceToHost);

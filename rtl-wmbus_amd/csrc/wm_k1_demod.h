@@ -549,7 +549,7 @@ __device__ __forceinline__ void k1_tile(const K1Args &a, const int tile, const i
 }
 
 template <int D, bool SHIFT, bool GEN = true, bool FAST = false, int RS = 0, int NT = 256>
-__global__ __launch_bounds__(NT, GEN ? 1 : 8) void k1_demod2(K1Args a)          /* first pass: at most 64 VGPRs -- eight waves fill a SIMD's register file exactly */
+__global__ __launch_bounds__(NT, GEN ? 1 : RS == 2 ? 4 : 8) void k1_demod2(K1Args a)          /* first pass: at most 64 VGPRs -- eight waves fill a SIMD's register file exactly; the RSSI launch over the listed tiles is small and latency-bound: 128 (its -s forms spilled up to 48 registers at 64) */
 {
     static_assert(NT == 256 || (NT == 512 && RS == 1 && !GEN), "the 512-thread tile is the first pass's without the RSSI");
     /* One tile per block.  (A bounded grid whose blocks walk several tiles made the kernel itself 6 % faster -- fewer block

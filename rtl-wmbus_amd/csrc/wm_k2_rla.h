@@ -332,6 +332,10 @@ __device__ __forceinline__ void rla_lanes(const K2Args &a, const uint32_t block_
     const uint64_t row = (uint64_t)ch * g.S + stream;
     const uint32_t *bad = a.bad + (uint64_t)ch * g.nseg_cap[0] * g.S + stream;       /* verdict of segment j at bad[j * S] */
     if (seg > 0u && bad[(uint64_t)(seg - 1u) * g.S]) return;            /* the head of my run covers me */
+    /* (A walker that runs past the end of its run into an unlisted segment X rewrites X's end-state record while the lane of a
+     * listed segment X + 1 -- listed behind an unlisted one, so it has a lane of its own in this launch -- may be reading that
+     * record as its start state: a torn read can drive that lane's whole segment from a mixed state.  Benign: the next k2_verify
+     * sees the mismatch and lists it again, so the result stays exact; it costs a round where it happens.  ADVICE r4.) */
     for (;;) {
         rla_segment<PASS>(a, lds, true, ch, stream, seg);
         if (seg + 1u >= g.nseg[0]) return;

@@ -429,7 +429,7 @@ __global__ void k4_flatten(WmPush g, uint32_t algo, const uint32_t *chips, const
         for (uint32_t k = 0; k < c; k++, n++)
             if (n < max_out) {
                 const uint32_t w = *wm_chip_ptr(g, chips, algo, row * g.nseg_cap[algo] + s, k);
-                dst[n] = WM_CHIP_VAL(w) | ((uint32_t)rssi[row * g.Mcap + s * g.seg_len[algo] + WM_CHIP_POS(w)] << 8);
+                dst[n] = WM_CHIP_VAL(w) | (rssi ? (uint32_t)rssi[row * g.Mcap + s * g.seg_len[algo] + WM_CHIP_POS(w)] << 8 : 0u);   /* rssi == nullptr: no RSSI rows to show */
                 if (pos) pos[n] = g.m0 + (uint64_t)s * g.seg_len[algo] + WM_CHIP_POS(w);
             }
     }

@@ -36,38 +36,6 @@
 #include "wm_k2_clock.h"
 #include "wm_k2_rla.h"
 
-/* One launch for two independent pieces of work: the clock kernel's re-run lanes (few, long) and
- * the run-length framer (its main pass or its own re-run list).  Without the DC remover the slicer
- * words are final after the clock kernel's FIRST pass (sign of the soft symbol, no state), so the
- * run-length framer need not wait for the clock re-runs; sharing a launch keeps both on the
- * context's one stream (more streams than hardware queues serialise against each other).
- * Every block of a launch gets the same LDS allocation, and a block that needs a quarter of a CU's
- * LDS cannot be placed while K1 refills the CU with its small blocks (and, once placed, costs K1
- * three of its eight blocks): the few clock blocks of this launch therefore run ONE wave each, in
- * the footprint of a run-length block (17 KB instead of 63 KB). */
-/* Build-time experiments for this kernel's register footprint, both off: */
-#ifndef WM_FUSED_WAVES_PER_SIMD
-#define WM_FUSED_WAVES_PER_SIMD 1      /* 4: at most 128 VGPRs (the clock lanes spill a little) */
-#endif
-#ifndef WM_FUSED_LEAN_CLOCK
-#define WM_FUSED_LEAN_CLOCK 0          /* 1: the clock re-run lanes take the per-sample path */
-#endif
-__global__ __launch_bounds__(64 * WM_RLA_WPB, WM_FUSED_WAVES_PER_SIMD) void k2_clock_rla(K2Args clk, K2Args rla, uint32_t clk_blocks)
-{
-    wm_framer_prio();
-    __shared__ __attribute__((aligned(16))) union { ClkLds<1> c; RlaLds r; } lds;
-    /* both parts walk their lane lists with the blocks they were given (the counts may live on the device) */
-    if (blockIdx.x < clk_blocks) {
-        const uint32_t n = k2_lane_count(clk);
-        for (uint32_t b = blockIdx.x; (uint64_t)b * 64u < n; b += clk_blocks) clock_lanes<false, 1, WM_FUSED_LEAN_CLOCK != 0, 1>(clk, b, lds.c);
-    } else {
-        rla_lds_init(lds.r, threadIdx.x, 64 * WM_RLA_WPB);     /* the whole block is on this side */
-        __syncthreads();
-        const uint32_t n = k2_lane_count(rla), nb = gridDim.x - clk_blocks;
-        for (uint32_t b = blockIdx.x - clk_blocks; (uint64_t)b * (64u * WM_RLA_WPB) < n; b += nb) rla_lanes(rla, b, lds.r);
-    }
-}
-
 /* start[seg] must equal final[seg-1]; mismatching lanes are appended to `list`. */
 __global__ void k2_verify(WmPush g, uint32_t algo, const uint32_t *st_start, const uint32_t *st_final, uint32_t words,
                           uint32_t *list, uint32_t *n_list, uint32_t *bad)

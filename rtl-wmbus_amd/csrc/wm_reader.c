@@ -63,10 +63,18 @@ int wm_reader_run(const wm_reader_cfg *cfg, wm_reader_push_fn push, void *user)
         if (n < 0) { if (errno == EINTR || errno == EAGAIN) continue; rc = WM_READER_ERROR; break; }
         if (n == 0) { PUSH_WHOLE_BLOCKS(); break; }            /* end of input: the partial tail is dropped */
         const long long t_now = now_ms();
-        if ((total + (unsigned long long)n) / WM_BLOCK != total / WM_BLOCK) t_data = t_now;     /* a block has been completed */
+        const int block_done = (total + (unsigned long long)n) / WM_BLOCK != total / WM_BLOCK;
+        if (block_done) t_data = t_now;                        /* a block has been completed */
         total += (unsigned long long)n;
         if (have == 0) t_first = t_now;
         have += (size_t)n;
+        /* a source that always has a byte ready never lets poll() time out: the -f test has to be made here too (the reference's
+         * alarm(2) fires around ONE fread however steadily single bytes arrive) */
+        if (!block_done && cfg->flow_timeout_ms && t_now - t_data >= (long long)cfg->flow_timeout_ms) {
+            PUSH_WHOLE_BLOCKS();
+            rc = WM_READER_FLOW_STOPPED;
+            break;
+        }
         if (have == cfg->max_push) PUSH_WHOLE_BLOCKS();
         else if (cfg->max_latency_ms && have >= WM_BLOCK && t_now - t_first >= (long long)cfg->max_latency_ms) PUSH_WHOLE_BLOCKS();
     }

@@ -52,6 +52,20 @@ def test_batch_needs_a_device_too(wm):
         wm.Batch(n_streams=128)
 
 
+def test_a_refused_open_can_be_closed_whatever_its_device_ordinal(wm):
+    """ADVICE r4: wmbus_open hands back the handle of a refused open (the caller reads the message, then closes it);
+    wmbus_close used to index a per-device table with the ordinal that had just been refused."""
+    for dev in (64, -1, 1 << 20):
+        with pytest.raises(wm.WmbusError, match="device must be"):
+            wm.Receiver(n_streams=1, device=dev)
+    for dev in (64, -1):                                       # through the batch API too (wmbus_batch_open closes what it opened)
+        with pytest.raises(wm.WmbusError):
+            wm.Batch(n_streams=64, device=dev)
+    for bad in (dict(decimation=0), dict(decimation=17), dict(max_push_bytes=4097), dict(n_streams=0)):
+        with pytest.raises(wm.WmbusError):
+            wm.Receiver(**{"n_streams": 1, **bad})
+
+
 def test_cli_usage_and_exit_codes(wm):
     import subprocess
     # unknown option (the reference's getopt string has no 'h'): usage on stdout, exit 1

@@ -342,13 +342,13 @@ def test_exhausted_burst_storage_is_a_warning_and_never_hands_out_garbage(wm, or
         "wm = importlib.import_module('rtl-wmbus_amd')\n"
         "cu8 = wm.synth_capture(seed=4242, n_samples=1 << 20, kinds=15, frames_per_s=150.0)[0]\n"
         "out, warn = [], 0\n"
-        "with wm.Receiver(n_streams=1, max_push_bytes=1 << 18) as rx:\n"
+        "with wm.Receiver(n_streams=1, max_push_bytes=1 << 18, burst_caps=CAPS) as rx:\n"
         "    for off in range(0, cu8.size, 1 << 18):\n"
         "        out.append(rx.push([cu8[off:off + (1 << 18)]]))\n"
         "        warn |= rx.timing()['warnings']\n"
         "print('RESULT ' + json.dumps({'text': ''.join(out), 'warn': warn}))\n")
     import sys
-    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, WMBUS_DEBUG_BURST_CAPS=caps))
+    p = subprocess.run([sys.executable, "-c", code.replace("CAPS", repr([int(v) for v in caps.split(":")]))], capture_output=True, text=True, timeout=300)   # cfg.burst_caps
     assert p.returncode == 0, p.stderr[-2000:]
     r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][0][7:])
     got = r["text"].splitlines()
@@ -356,6 +356,110 @@ def test_exhausted_burst_storage_is_a_warning_and_never_hands_out_garbage(wm, or
     assert 0 < len(got) < len(want)
     it = iter(want)
     assert all(any(g == w for w in it) for g in got), "a line that the reference does not print, or out of order"
-    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    p = subprocess.run([sys.executable, "-c", code.replace("CAPS", "None")], capture_output=True, text=True, timeout=300)
     r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][0][7:])
     assert r["warn"] == 0 and r["text"].splitlines() == want
+
+
+# ---- the product configuration (no debug views: RSSI on demand, the 2000-sample first pass) at BASELINE shape ----
+
+def _batch_texts(b):
+    per = {}
+    for rx, first, _cnt in b.contexts:
+        for ln in rx.lines():
+            per.setdefault(first + ln["stream"], []).append(ln["text"])
+    return per
+
+
+def test_full_size_batch_in_the_product_configuration_matches_the_oracle(wm, oracle):
+    """BASELINE configs[3] at an eighth of its width, the way bench.py, the CLI and wmbus_batch run it: 128 captures x 2^22 IQ
+    samples in ONE context of a wm.Batch (keep_taps = 0: the first pass without the RSSI on 2000-sample tiles, k3_spans, the RSSI
+    of the listed tiles).  Every capture's first push against the oracle; the third push of sixteen of them against an oracle
+    fed the capture three times (the RSSI filter's state travels through `ema_out`, the framers' through their carries)."""
+    n_streams, n = 128, 1 << 22
+    caps = [wm.synth_capture(seed=0xC0FFEE + s, n_samples=n, kinds=7, frames_per_s=20.0)[0] for s in range(n_streams)]
+    want = oracle.run_many(caps, oracle.make_opts())
+    tims = []
+    with wm.Batch(n_streams=n_streams, contexts=1, max_push_bytes=2 * n) as b:
+        assert len(b.contexts) == 1
+        for s in range(n_streams):
+            b.stage(s, caps[s])
+        b.run_resident(2 * n, 1, on_push=lambda f, c, recs, tm: tims.append(tm), want_lines=False)
+        got = _batch_texts(b)
+        assert ["".join(got.get(s, [])) for s in range(n_streams)] == want
+        b.run_resident(2 * n, 2, on_push=lambda f, c, recs, tm: tims.append(tm), want_lines=False)
+        got3 = _batch_texts(b)
+    picks = list(range(0, n_streams, 8))
+    want3 = oracle.run_many([caps[s] for s in picks], oracle.make_opts(), passes=3)
+    assert ["".join(got3.get(s, [])) for s in picks] == want3
+    assert all(t["rssi_mode"] == wm.RSSI_ON_DEMAND and t["warnings"] == 0 for t in tims)      # a tenth of the tiles listed: never paused
+    assert all(0 < t["rssi_tiles"] < 0.2 * n_streams * ((n // 2 + 975) // 976) for t in tims)
+    if os.environ.get("WMBUS_TEST_ROUNDS_ON_HOST", "0") != "1":
+        assert all(t["slow_path"] == 0 for t in tims)
+
+
+def test_c3_configuration_in_the_product_configuration(wm, oracle):
+    """BASELINE configs[2] (4.0 MS/s, -d 5 -s, S1 + T1 + C1 concurrently, 2^22 IQ samples) without debug views: whole and in
+    eight ragged pushes -- this capture lists more than a fifth of its tiles, so the eight-push run goes on demand ->
+    paused, and the text is the oracle's either way."""
+    flags = ["-d", "5", "-s", "-v"]
+    cu8 = wm.synth_capture(seed=20260, n_samples=1 << 22, fs_khz=4000, kinds=15, frames_per_s=60.0, amplitude=60.0,
+                           t1c1_center_khz=325.0, s1_center_khz=-325.0)[0]
+    ref = oracle.run(cu8, flags_to_oracle_opts(oracle, flags))
+    kw = dict(decimation=5, simultaneous=True, show_algorithm=True, keep_taps=False)
+    with wm.Receiver(n_streams=1, max_push_bytes=cu8.size, **kw) as rx:
+        assert rx.run(cu8)[0] == ref["text"]
+        assert rx.timing()["rssi_mode"] in (wm.RSSI_ON_DEMAND, wm.RSSI_FELL_BACK)
+    modes, text = [], []
+    with wm.Receiver(n_streams=1, max_push_bytes=1 << 20, **kw) as rx:
+        for off in range(0, cu8.size, 1 << 20):
+            text.append(rx.push([cu8[off:off + (1 << 20)]]))
+            modes.append(rx.timing()["rssi_mode"])
+    assert "".join(text) == ref["text"]
+    assert modes[0] in (wm.RSSI_ON_DEMAND, wm.RSSI_FELL_BACK) and wm.RSSI_PAUSED in modes, modes
+
+
+def test_rssi_on_demand_goes_dense_pauses_and_comes_back(wm, oracle):
+    """The state machine of RSSI on demand over 44 pushes of a stream whose bursts cover most of its tiles: on demand ->
+    (more than a fifth of the tiles listed) sixteen pushes on the full pass -> on demand again ..., the RSSI filter's state
+    handed over exactly each way.  wmbus_timing.rssi_mode says which path a push took, so a regression that silently
+    disabled on demand, or never left the pause, fails here although the text would still be right.  A stretch of exact
+    silence in the middle of the traffic cannot be proven by a tile computed on its own: with the pause switched off
+    (rssi_dense_pm = 1000) the push that holds it must take the full pass (FELL_BACK, slow_path) -- and print the same text."""
+    push, n_push, tiles_per_push = 1 << 16, 44, 17                    # 32768 IQ samples = 16384 decimated = 17 tiles of 976 per push
+    cu8 = wm.synth_capture(seed=515, n_samples=n_push * push // 2, kinds=15, frames_per_s=400.0, amplitude=50.0)[0].copy()
+    k_silent = 20
+    cu8[k_silent * push + push // 4: k_silent * push + push // 2] = 128         # exact zero input, signal on both sides
+    want = oracle.run(cu8, flags_to_oracle_opts(oracle, ["-v"]))["text"]
+    assert len(want.splitlines()) > 100
+    OD, PA, FB = wm.RSSI_ON_DEMAND, wm.RSSI_PAUSED, wm.RSSI_FELL_BACK
+
+    def run(**kw):
+        text, tims = [], []
+        with wm.Receiver(n_streams=1, max_push_bytes=push, keep_taps=False, **kw) as rx:
+            for k in range(n_push):
+                text.append(rx.push([cu8[k * push:(k + 1) * push]]))
+                tims.append(rx.timing())
+        return "".join(text), tims
+
+    text, tims = run()
+    assert text == want
+    modes = [t["rssi_mode"] for t in tims]
+    pause, periods = 0, 0
+    for k, t in enumerate(tims):                                      # the rule of wait_gpu (wm_api.hip), replayed on what the pushes reported
+        if pause:
+            assert t["rssi_mode"] == PA and t["rssi_tiles"] == 0 and t["rssi_ms"] == 0.0, (k, modes)
+            pause -= 1
+        else:
+            assert t["rssi_mode"] in (OD, FB) and t["rssi_tiles"] > 0, (k, modes)
+            assert (t["rssi_mode"] == FB) == bool(t["slow_path"]) or os.environ.get("WMBUS_TEST_ROUNDS_ON_HOST") == "1", (k, modes)
+            if t["rssi_tiles"] * 1000 > 200 * tiles_per_push:
+                pause, periods = 16, periods + 1
+    assert modes[0] == OD and modes[1:17] == [PA] * 16 and modes[17] in (OD, FB)      # dense from the first push on
+    assert periods >= 2                                               # ... and it came back and went again
+
+    text, tims = run(rssi_dense_pm=1000)                              # never pause: every push on demand
+    assert text == want
+    assert all(t["rssi_mode"] in (OD, FB) for t in tims)
+    assert tims[k_silent]["rssi_mode"] == FB and tims[k_silent]["slow_path"] == 1
+    assert sum(t["rssi_mode"] == OD for t in tims) >= n_push - 6      # the fall-back is the exception

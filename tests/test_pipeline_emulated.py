@@ -221,7 +221,7 @@ def test_bundled_capture_through_the_emulated_pipeline(libs, oracle, samples, pu
     assert run_capture(libs, cu8, pushes, stats=st) == ref["text"]                 # RSSI on demand, as the product runs these switches
     assert st["od_pushes"] > 0 and st["od_fallbacks"] == 0
     assert run_capture(libs, cu8, pushes, on_demand=False) == ref["text"]          # the full pass (contexts with debug taps)
-    assert run_capture(libs, cu8, pushes, gpu_decode=False) == ref["text"]        # every burst through the host decoders (WMBUS_GPU_DECODE=0)
+    assert run_capture(libs, cu8, pushes, gpu_decode=False) == ref["text"]        # every burst through the host decoders (cfg.bursts_to_host)
 
 
 def test_synthetic_captures_through_the_emulated_pipeline(libs, oracle, wm):

@@ -44,8 +44,7 @@ def stamps(reset):
 
 
 def run(caps, S, contexts, passes, nt):
-    os.environ["WMBUS_K1_NT"] = str(nt)
-    with wm.Batch(n_streams=S, contexts=contexts, max_push_bytes=2 * N) as b:
+    with wm.Batch(n_streams=S, contexts=contexts, max_push_bytes=2 * N, k1_small_tile=nt == 256) as b:
         for s in range(S):
             b.stage(s, caps[s % len(caps)])
         b.run_resident(2 * N, 1, want_lines=False)            # warm-up: code objects, first pass from the zero state
