@@ -438,7 +438,13 @@ def main():
     shard.barrier(group)
     elapsed = time.perf_counter() - t0
     passes_done += a.steps
+    try:
+        n_threads = len(os.listdir("/proc/self/task"))        # this rank's threads right behind the timed region (workers, decoder pools, runtime)
+    except OSError:
+        n_threads = 0
     elapsed = shard.max_over_ranks(group, elapsed)
+    threads_all = shard.gather(group, [n_threads])
+    hd_all = shard.gather(group, [round(sum(tm["host_decode_ms"] for tims in tim_by_ctx.values() for tm in tims) / max(1, sum(len(t_) for t_ in tim_by_ctx.values())), 3)])
     lines_total = int(shard.sum_over_ranks(group, stats["lines"]))
     tim_ctx = [tim_by_ctx.get(first, []) for _, first, _ in batch.contexts]
     demod_ms = sum(tm["demod_ms"] for tims in tim_ctx for tm in tims)
@@ -598,6 +604,7 @@ def main():
                                                            dict(seed=0xC3C3, fs_khz=4000, kinds=15, frames_per_s=50.0, t1c1_center_khz=325.0, s1_center_khz=-325.0))),
             ("c3_batch", lambda: leg_c3_batch(wm, O, shard, S, n, local, max(3, a.steps // 4))),
             ("cli", lambda: leg_cli(wm)),
+            ("cli_1024", lambda: leg_cli(wm, n_files=1024)),
         ):
             try:
                 t_l = time.perf_counter()
@@ -641,12 +648,14 @@ def main():
             "stage_ms_last_step": [rnd(t) for t in (tim_acc[-1] if tim_acc else [])],
             "stage_ms_mid_step": [rnd(t) for t in (tim_acc[a.steps // 2] if tim_acc else [])],
             "setup_s": {"generate": round(t_gen, 1), "alloc_and_h2d": round(t_h2d, 1)},
+            "host": {"cpu_count": os.cpu_count(), "threads_per_rank": [t_[0] for t_ in threads_all], "host_decode_ms_mean_per_rank": [h_[0] for h_ in hd_all],
+                     "generator_threads_per_rank": max(1, min((os.cpu_count() or 1) // world, 64)), "oracle_threads_per_rank": o_threads},
             "input": "staged from pinned host memory inside every step (PCIe-inclusive, informational)" if a.from_host else "resident in HBM",
             "tolerance_mode": bool(a.tolerance_mode),
         }
         if tol is not None:
             out["tolerance_mode_leg"] = tol
-        for key in ("c2_single_stream", "c3_single_stream", "c3_batch", "cli"):
+        for key in ("c2_single_stream", "c3_single_stream", "c3_batch", "cli", "cli_1024"):
             if key in legs:
                 out[key] = legs[key]
         if "cli" not in legs:                                  # not measured in this run: say where the number comes from

@@ -1367,15 +1367,21 @@ int wmbus_selftest_math(int device, const float *a, const float *b, float *o_sqr
 }
 
 #ifdef WM_K1_STAMPS
-/* -DWM_K1_STAMPS builds only (tools/gpu_k1_stamps.py): the stage intervals the demodulation kernel's waves have added up
- * (wm_k1_demod.h), optionally cleared. */
+/* -DWM_K1_STAMPS builds only (tools/gpu_k1_stamps.py): the stage intervals the demodulation kernel's waves have left
+ * (wm_k1_demod.h), summed over the slots into out8[0 .. 6], optionally cleared. */
 int wmbus_debug_k1_stamps(unsigned long long *out8, int reset)
 {
     if (hipDeviceSynchronize() != hipSuccess) return WMBUS_EDEVICE;
-    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(wm_k1_stamp_acc), 8 * sizeof(unsigned long long)) != hipSuccess) return WMBUS_EDEVICE;
+    const size_t n = (size_t)WM_K1_STAMP_SLOTS * 8u;
+    if (out8) {
+        std::vector<unsigned int> h(n);
+        if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(wm_k1_stamp_buf), n * sizeof(unsigned int)) != hipSuccess) return WMBUS_EDEVICE;
+        for (int k = 0; k < 8; k++) out8[k] = 0;
+        for (size_t i = 0; i < n; i++) out8[i & 7u] += h[i];
+    }
     if (reset) {
-        const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(wm_k1_stamp_acc), z, sizeof z) != hipSuccess) return WMBUS_EDEVICE;
+        void *p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(wm_k1_stamp_buf)) != hipSuccess || hipMemset(p, 0, n * sizeof(unsigned int)) != hipSuccess) return WMBUS_EDEVICE;
     }
     return WMBUS_OK;
 }

@@ -47,6 +47,16 @@ WM_HD float wm_div(float a, float b) { return a / b; }
 WM_HD float wm_sqrt(float a) { return sqrtf(a); }
 #endif
 
+/* a*b + c and a*b - c*d for products that are EXACT (integers below 2^24, powers of two times a float): one rounding either
+ * way, so the fused form returns the very bits of the separately rounded one -- zero signs included: an exactly-zero sum of
+ * opposite-signed terms is +0 under round-to-nearest fused or not, and a zero product carries the sign of its factors in both.
+ * One instruction instead of two (round 5: the discriminator's complex product and the arctangent's numerator). */
+#if defined(__HIP_DEVICE_COMPILE__)
+WM_HD float wm_fma_exact(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+#else
+WM_HD float wm_fma_exact(float a, float b, float c) { return wm_add(wm_mul(a, b), c); }      /* the host states the claim; the device tests compare */
+#endif
+
 /* Correctly rounded divide and square root for TAME operands (no subnormal, infinite or NaN
  * operand or result, exponents far from the limits): the same Newton/FMA refinement the compiler
  * emits for `/` and sqrtf under -fhip-fp32-correctly-rounded-divide-sqrt, without its range
@@ -230,12 +240,13 @@ WM_HD float wm_atan2f_tab(float y, float x, const float *tab)
 {
     const uint32_t hx = wm_f2u(x), hy = wm_f2u(y);
     const float pi = wm_u2f(0x40490fdbu), pi_o_2 = wm_u2f(0x3fc90fdbu), pi_lo = wm_u2f(0xb3bbbd2eu);
-    const float t = wm_u2f(wm_f2u(wm_div_dom(y, x)) & 0x7fffffffu);       /* fabsf(y/x) */
-    int j = (int)(wm_f2u(t) >> 18) - (int)(WM_ATAN_U0 - 1u);
+    const float qt = wm_div_dom(y, x);
+    const float t = wm_u2f(wm_f2u(qt) & 0x7fffffffu);                     /* fabsf(y/x) */
+    int j = (int)((wm_f2u(qt) >> 18) & 0x1FFFu) - (int)(WM_ATAN_U0 - 1u);  /* exponent and five mantissa bits in one bit-field extract */
     j = j < 0 ? 0 : (j > WM_ATAN_LUT_BYTES - 1 ? WM_ATAN_LUT_BYTES - 1 : j);
     const uint32_t idx = ((const uint8_t *)(tab + WM_ATAN_RANGES * WM_ATAN_ROW_WORDS))[j];
     const float *e = tab + WM_ATAN_ROW_WORDS * idx;
-    const float num = wm_add(wm_mul(e[0], t), e[1]);
+    const float num = wm_fma_exact(e[0], t, e[1]);                        /* A in {0, 1, 2}: A*t is exact */
     const float den = wm_add(wm_mul(e[2], t), e[3]);
     const float r = wm_div_dom(num, den);
 
@@ -261,8 +272,12 @@ WM_HD float wm_atan2f_tab(float y, float x, const float *tab)
     /* quadrant (e_atan2f.c): x >= 0: +-z ; x < 0: +-(pi - (z - pi_lo)) ; sign of y */
     const float zq = (hx >> 31) ? wm_sub(pi, wm_sub(z, pi_lo)) : z;
     float res = wm_copysign_bits(zq, hy);
-    res = (hx << 1) == 0u ? wm_copysign_bits(pi_o_2, hy) : res;           /* x == +-0            */
-    res = (hy << 1) == 0u ? ((hx >> 31) ? wm_copysign_bits(pi, hy) : y) : res;   /* y == +-0 first */
+    /* Special cases of e_atan2f.c.  y == +-0 with x != 0 needs none here: t = 0 takes the first range's row (A = 1, B = 0, C = 0,
+     * D = 1, hi = lo = 0) to z = +0 exactly, so the quadrant step returns +-0 for x > 0 and +-fl(pi - 8.74e-8) = +-pi for x < 0 --
+     * what the original's `case 0 / 1: return y; case 2: return pi + tiny; case 3: return -pi - tiny` returns.  Only x == +-0
+     * (the quotient is not a number then) has to be overridden: +-pi/2, or for y == +-0 too what the sign of x says. */
+    const float at0 = (hy << 1) != 0u ? pi_o_2 : ((hx >> 31) ? pi : 0.0f);
+    res = (hx << 1) == 0u ? wm_copysign_bits(at0, hy) : res;
     return res;
 }
 
@@ -271,9 +286,11 @@ WM_HD float wm_atan2f_tab(float y, float x, const float *tab)
  * signs of zero products are those of the reference's operands, and y/x is scale-free. */
 WM_HD float wm_discriminator_tab(float i, float q, float pi_, float pq_, const float *tab)
 {
+    /* re = i c - q d, im = i d + q c with (c, d) = (i', -q'): every product an exact integer (sums of at most sixteen samples
+     * of magnitude <= 180: below 2^24), so each component is one product and one fused multiply-add */
     const float c = pi_, d = -pq_;
-    const float re = wm_sub(wm_mul(i, c), wm_mul(q, d));
-    const float im = wm_add(wm_mul(i, d), wm_mul(q, c));
+    const float re = wm_fma_exact(i, c, -wm_mul(q, d));
+    const float im = wm_fma_exact(i, d, wm_mul(q, c));
     return wm_mul(wm_atan2f_tab(im, re, tab), wm_u2f(0x3ea2f983u));    /* (float)M_1_PI */
 }
 
@@ -287,8 +304,8 @@ WM_HD float wm_discriminator_tab(float i, float q, float pi_, float pq_, const f
 WM_HD float wm_discriminator_tol(float i, float q, float pi_, float pq_)
 {
     const float c = pi_, d = -pq_;
-    const float re = wm_sub(wm_mul(i, c), wm_mul(q, d));                /* exact integers either way */
-    const float im = wm_add(wm_mul(i, d), wm_mul(q, c));
+    const float re = wm_fma_exact(i, c, -wm_mul(q, d));                 /* exact integers either way */
+    const float im = wm_fma_exact(i, d, wm_mul(q, c));
     const uint32_t hx = wm_f2u(re), hy = wm_f2u(im);
     const float ax = wm_u2f(hx & 0x7fffffffu), ay = wm_u2f(hy & 0x7fffffffu);
     const float mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;

@@ -4,18 +4,28 @@
 #define WM_K1_DEMOD_H
 
 typedef short wm_s2 __attribute__((ext_vector_type(2)));
+#if defined(__HIPCC__)
+#define WM_LDS_STATIC __shared__
+#else
+#define WM_LDS_STATIC static              /* host emulation: one block at a time */
+#endif
 
 /* -DWM_K1_STAMPS (tools/gpu_k1_stamps.py, never in the product build): every wave of the first pass without the RSSI reads
- * the shader clock (s_memtime) at its stage boundaries and adds the five intervals to wm_k1_stamp_acc -- stage 0 (input
- * loads + conversion), the wait at the first barrier, stage A, the wait at the second barrier, stage B -- plus [5] the
- * waves counted and [6] the whole tile as its first wave saw it.  profiles/r05_k1_stage_cycles.txt is made from it. */
+ * the shader clock (s_memtime) at its stage boundaries and leaves the five intervals -- stage 0 (input loads + conversion), the
+ * wait at the first barrier, stage A, the wait at the second barrier, stage B -- in a slot of its own (the wave's number in the
+ * launch, modulo the buffer: a first version added everything into seven words, and 30 million atomics on seven addresses
+ * made the kernel forty times slower).  [5] counts the waves that met in a slot, [6] is the whole tile as its first wave saw
+ * it.  profiles/r05_k1_stage_cycles.txt is made from it. */
 #if defined(WM_K1_STAMPS) && defined(__HIPCC__)
-__device__ unsigned long long wm_k1_stamp_acc[8];
+#define WM_K1_STAMP_SLOTS (1u << 21)
+__device__ unsigned int wm_k1_stamp_buf[WM_K1_STAMP_SLOTS * 8u];
 #define WM_K1_STAMP_DECL unsigned long long k1_t[6] = {0, 0, 0, 0, 0, 0}
 #define WM_K1_STAMP(i) do { if (RS == 1) k1_t[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #define WM_K1_STAMP_END(tid) do { if (RS == 1 && ((tid) & 63) == 0) { \
-        for (int i_ = 0; i_ < 5; i_++) atomicAdd(&wm_k1_stamp_acc[i_], k1_t[i_ + 1] - k1_t[i_]); \
-        atomicAdd(&wm_k1_stamp_acc[5], 1ull); if ((tid) == 0) atomicAdd(&wm_k1_stamp_acc[6], k1_t[5] - k1_t[0]); } } while (0)
+        const unsigned wv_ = ((blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + ((tid) >> 6)) & (WM_K1_STAMP_SLOTS - 1u); \
+        unsigned int *q_ = wm_k1_stamp_buf + 8u * wv_; \
+        for (int i_ = 0; i_ < 5; i_++) atomicAdd(q_ + i_, (unsigned int)(k1_t[i_ + 1] - k1_t[i_])); \
+        atomicAdd(q_ + 5, 1u); if ((tid) == 0) atomicAdd(q_ + 6, (unsigned int)(k1_t[5] - k1_t[0])); } } while (0)
 #else
 #define WM_K1_STAMP_DECL
 #define WM_K1_STAMP(i)
@@ -116,8 +126,15 @@ template <int NT> struct K1GeoT {
     {
         return nstg(d) * (shift ? 2 : 1) > 2 * YM ? nstg(d) * (shift ? 2 : 1) : 2 * YM;
     }
-    static constexpr size_t smem(int d, bool shift) { return (size_t)(U(d, shift) + 2 * YD + 256 + WM_ATAN_TAB_WORDS) * 4; }
+    static constexpr size_t smem(int d, bool shift) { return (size_t)U(d, shift) * 4; }     /* the DYNAMIC part: staging / magnitude rows */
 };
+/* The rest of a block's LDS is static: discriminator rows, the EMA hand-off scratch, the arctangent's table.  A static array has
+ * its address at compile time -- the address of the dynamic (extern) one is only resolved after instruction selection, and the
+ * byte fetch of the range LUT, eight per thread, carried an add of that "unknown" base (round 5, read off the ISA).  One struct,
+ * so that the table sits BEHIND the rows: the LUT index arrives biased by bits(7/16) >> 18 = 4024, and only a non-negative
+ * remainder fits the instruction's offset field. */
+template <int NT> struct K1LdsT { float yDr[2 * K1GeoT<NT>::YD]; float sFin[128], sHead[128]; float tab[WM_ATAN_TAB_WORDS]; };
+static_assert(sizeof(K1LdsT<256>) - sizeof(float) * WM_ATAN_TAB_WORDS >= 4096, "the LUT's offset must absorb the index bias");
 using K1Geo = K1GeoT<256>;
 #define WM_K1_TILE_BIG (4 * 512 - WM_K1_HALO)      /* the tile of the 512-thread first pass */
 static_assert(K1Geo::T == WM_K1_TILE2, "the 256-thread tile is the tile of every per-tile record");
@@ -388,8 +405,9 @@ __device__ __forceinline__ void k1_tile(const K1Args &a, const int tile, const i
     uint32_t *stgT = (uint32_t *)smem + 8;                /* word 0 of a row = oldest sample of the tile */
     uint32_t *stgS = SHIFT ? stgT + NSTG : stgT;
     float *yMgT = (float *)smem, *yMgS = yMgT + YM;       /* overlay the staging rows (see stage A) */
-    float *yDrT = (float *)smem + G::U(d, SHIFT), *yDrS = yDrT + YD;
-    float *sFin = yDrS + YD, *sHead = sFin + 128, *tab = sHead + 128;
+    WM_LDS_STATIC __attribute__((aligned(16))) K1LdsT<NT> lds;        /* see K1LdsT */
+    float *yDrT = lds.yDr, *yDrS = yDrT + YD;
+    float *sFin = lds.sFin, *sHead = lds.sHead, *tab = lds.tab;
 
     const int ts = tile * T;
     const int tn = min(T, (int)g.M - ts);
@@ -491,14 +509,14 @@ __device__ __forceinline__ void k1_tile(const K1Args &a, const int tile, const i
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const float iT = fT[j + 1][0], qT = fT[j + 1][1];
-                    mgT[j] = wm_mul(wm_sqrt_dom(wm_add(wm_mul(iT, iT), wm_mul(qT, qT))), 0.125f);
+                    mgT[j] = wm_mul(wm_sqrt_dom(wm_fma_exact(iT, iT, wm_mul(qT, qT))), 0.125f);
                 }
             }
             if (mask & 2u) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const float iS = fS[j + 1][0], qS = fS[j + 1][1];
-                    mgS[j] = wm_mul(wm_sqrt_dom(wm_add(wm_mul(iS, iS), wm_mul(qS, qS))), 0.0625f);
+                    mgS[j] = wm_mul(wm_sqrt_dom(wm_fma_exact(iS, iS, wm_mul(qS, qS))), 0.0625f);
                 }
             }
         } else if (accurate && chT && chS && !approx) {      /* default switches: no branch between the eight */
@@ -510,8 +528,8 @@ __device__ __forceinline__ void k1_tile(const K1Args &a, const int tile, const i
 #pragma unroll
             for (int j = 0; j < 4 && RS == 0; j++) {
                 const float iT = fT[j + 1][0], qT = fT[j + 1][1], iS = fS[j + 1][0], qS = fS[j + 1][1];
-                mgT[j] = wm_mul(wm_sqrt_dom(wm_add(wm_mul(iT, iT), wm_mul(qT, qT))), 0.125f);
-                mgS[j] = wm_mul(wm_sqrt_dom(wm_add(wm_mul(iS, iS), wm_mul(qS, qS))), 0.0625f);
+                mgT[j] = wm_mul(wm_sqrt_dom(wm_fma_exact(iT, iT, wm_mul(qT, qT))), 0.125f);
+                mgS[j] = wm_mul(wm_sqrt_dom(wm_fma_exact(iS, iS, wm_mul(qS, qS))), 0.0625f);
             }
         } else {
 #pragma unroll
@@ -521,8 +539,8 @@ __device__ __forceinline__ void k1_tile(const K1Args &a, const int tile, const i
                                                 : wm_mul(wm_discriminator_fast(iT, qT, fT[j][0], fT[j][1]), 0.015625f);
                 drS[j] = !chS ? 0.0f : accurate ? (approx ? wm_discriminator_approx(iS, qS, fS[j][0], fS[j][1], approx) : wm_discriminator_tab(iS, qS, fS[j][0], fS[j][1], tab))
                                                 : wm_mul(wm_discriminator_fast(iS, qS, fS[j][0], fS[j][1]), 0.00390625f);
-                mgT[j] = chT ? wm_mul(wm_sqrt_dom(wm_add(wm_mul(iT, iT), wm_mul(qT, qT))), 0.125f) : 0.0f;
-                mgS[j] = chS ? wm_mul(wm_sqrt_dom(wm_add(wm_mul(iS, iS), wm_mul(qS, qS))), 0.0625f) : 0.0f;
+                mgT[j] = chT ? wm_mul(wm_sqrt_dom(wm_fma_exact(iT, iT, wm_mul(qT, qT))), 0.125f) : 0.0f;
+                mgS[j] = chS ? wm_mul(wm_sqrt_dom(wm_fma_exact(iS, iS, wm_mul(qS, qS))), 0.0625f) : 0.0f;
                 /* before the first sample of the stream the FIR's delay line holds zeros, not the discriminator
                  * of zero input -- the same thing for cargf and -a, but atan2_approximation(0, 0) is not 0 */
                 if (approx && (long)(g.m0 + (uint64_t)ts) + 4 * c + j < (long)WM_K1_HALO) { drT[j] = 0.0f; drS[j] = 0.0f; }

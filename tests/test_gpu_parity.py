@@ -453,12 +453,16 @@ def test_bench_runs_two_ranks_through_the_hip_library(wm, tmp_path):
     env = dict(os.environ, WMBUS_BENCH_BACKEND="gloo", WMBUS_BENCH_DEVICE="0")
     env.pop("WORLD_SIZE", None); env.pop("RANK", None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--streams", "128",
-                        "--samples", str(1 << 20), "--contexts", "2", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=900)
+                        "--samples", str(1 << 20), "--contexts", "2", "--no-cpu-baseline", "--details", str(tmp_path / "details.json")],
+                       capture_output=True, text=True, env=env, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
-    line = json.loads(p.stdout.strip().splitlines()[-1])
-    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
-    assert line["parity"]["ok"] and line["parity"]["ranks"] == 2 and line["parity"]["first_pass"]["captures_compared"] == 64 and line["parity"]["all_ranks"]["first_pass_captures"] == 128
-    assert line["datagrams_per_step"] > 100
+    line = json.loads(p.stdout.strip().splitlines()[-1])                       # the compact line the driver records ...
+    assert len(p.stdout.strip().splitlines()[-1]) < 2000
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0 and line["parity"]["ok"] and line["parity"]["first_pass"] == "64/64"
+    full = json.load(open(tmp_path / "details.json"))                          # ... and the full record beside it
+    assert full["value"] == line["value"]
+    assert full["parity"]["ok"] and full["parity"]["ranks"] == 2 and full["parity"]["first_pass"]["captures_compared"] == 64 and full["parity"]["all_ranks"]["first_pass_captures"] == 128
+    assert full["datagrams_per_step"] > 100 and len(full["host"]["threads_per_rank"]) == 2
 
 
 @pytest.mark.gpu

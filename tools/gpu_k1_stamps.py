@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 wm = importlib.import_module("rtl-wmbus_amd")
 
 # dynamic VALU instructions per wave and stage, from the ISA (tools/isa_budget.py; stage B: 4 x 92 + 4 x 22 + addressing)
-INSTR = {256: (41, 634, 470), 512: (45, 634, 470)}
+INSTR = {256: (30, 586, 470), 512: (34, 586, 470)}
 N = 1 << 22
 
 
