@@ -155,6 +155,7 @@ struct wmbus_ctx {
     bool rs_this = false;                               /* this push runs on demand (a context whose bursts cover most of its tiles takes the full pass for a while) */
     unsigned rs_pause = 0;                              /* pushes left before on demand is tried again */
     bool k1_big = false;                                /* the first pass without the RSSI runs on 2000-sample tiles of 512 threads (decimation 2, no -s) */
+    uint32_t k1_tpb = 1;                                /* tiles per block of the first pass without the RSSI (cfg.k1_tiles_per_block) */
     uint32_t k1_tail_pm = 60;                           /* per mille of a push's tiles behind the early hand-over of the K1 turn (enqueue_front_impl) */
     uint32_t *d_rs_flags = nullptr, *d_rs_list = nullptr;   /* [ntiles_cap][S] chains read per (tile, capture); the tiles listed */
     uint32_t *d_ckpt = nullptr; uint32_t nck = 0;       /* clock kernel checkpoints [2][S][nseg_cap][nck][16] */
@@ -214,7 +215,8 @@ enum { WM_MAX_DEVICES = 64 };                    /* per-device tables (K1 order,
  * A small batch is bound by its chain of dependent launches and by every host round trip in it, and its short segments
  * (wmbus_open) cascade further: it enqueues more rounds, so that the host-driven path (0.5 ms per round) stays the exception. */
 enum { WM_MAX_ROUNDS = 6 };
-enum { WM_K3_BLOCKS = 64, WM_RS_BLOCKS = 2048 };   /* bounded grids of the burst kernels and of the RSSI launch over the listed tiles (launch_k3) */                     /* counters per kind: rounds + 1 <= 8 (SC_* below) */
+enum { WM_K3_BLOCKS = 64, WM_RS_BLOCKS = 2048 };
+enum { WM_K1_TPB_DEFAULT = 2 };                /* tiles per block of the demodulation kernel's first pass (RSSI on demand), see enqueue_front_impl */   /* bounded grids of the burst kernels and of the RSSI launch over the listed tiles (launch_k3) */                     /* counters per kind: rounds + 1 <= 8 (SC_* below) */
 enum { SC_ERR = 0, SC_NHITS = 1, SC_NHDR = 2, SC_NWORDS = 3, SC_NPKTS = 4, SC_NBYTES = 5, SC_SLOW = 6, SC_CHIPS = 8 /* [algo][chain] */,
        SC_RS_N = 12 /* tiles listed for the RSSI-on-demand launch */, SC_RS_FAIL = 13 /* a lane that is read could not prove its value */,
        SC_EMA = 16 /* [ema_rounds + 1] */, SC_CLK = 24 /* [fr_rounds + 1] */, SC_RLA = 32 /* [rla_rounds + 1] */, SC_COUNT = 40 };
@@ -497,6 +499,7 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
          * would cost more occupancy than the halo saves) */
         c->k1_big = c->rs_od && c->d == 2 && !(c->flags & WM_F_SHIFT) && !cfg->k1_small_tile;
         c->k1_tail_pm = cfg->tolerance_mode ? 0u : 60u;
+        c->k1_tpb = cfg->k1_tiles_per_block ? std::min(cfg->k1_tiles_per_block, 64u) : WM_K1_TPB_DEFAULT;
         if (c->rs_od) { A(dalloc(&c->d_rs_flags, (size_t)c->ntiles_cap * c->S)); A(dalloc(&c->d_rs_list, (size_t)c->ntiles_cap * c->S)); }
     }
     const size_t stw[2] = {sizeof(WmRlaState), sizeof(WmClkState)};
@@ -838,12 +841,16 @@ static int enqueue_front_impl(wmbus_ctx *c, size_t nbytes)
             const uint32_t n_tail = std::min(nt1 - 1u, (uint32_t)((uint64_t)nt1 * c->k1_tail_pm / 1000u));
             K1Args k1 = c->k1a;
             const int rs = c->rs_this ? 1 : 0;
-            rc = launch_k1_any(c, k1, dim3(nt1 - n_tail, c->S), nullptr, rs, big);
+            /* the first pass without the RSSI takes several consecutive tiles per block: the input of a block's next tile is on
+             * its way while the current one is computed (wm_k1_demod.h, K1Args.tpb) */
+            const uint32_t tpb = c->rs_this && c->d >= 2 && c->d <= 5 ? c->k1_tpb : 1u;
+            k1.tpb = tpb; k1.tile_end = nt1 - n_tail;
+            rc = launch_k1_any(c, k1, dim3((nt1 - n_tail + tpb - 1u) / tpb, c->S), nullptr, rs, big);
             if (rc) return rc;
             if (n_tail) {
                 HIPCHK(c, hipEventRecord(c->ev_turn, c->stream));
-                k1.tile0 = nt1 - n_tail;
-                rc = launch_k1_any(c, k1, dim3(n_tail, c->S), nullptr, rs, big);
+                k1.tile0 = nt1 - n_tail; k1.tile_end = nt1;
+                rc = launch_k1_any(c, k1, dim3((n_tail + tpb - 1u) / tpb, c->S), nullptr, rs, big);
                 if (rc) return rc;
             }
             HIPCHK(c, hipEventRecord(c->ev[4], c->stream));

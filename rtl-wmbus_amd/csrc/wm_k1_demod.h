@@ -73,6 +73,9 @@ struct K1Args {
     const uint32_t *rs_flags;/* [ntiles][S] bit 0: the T1/C1 chain's RSSI is read in this tile, bit 1: the S1 chain's */
     float *ema_out;          /* [2][S] the EMA after the push's last sample (the last tile of every capture is always listed) */
     uint32_t *rs_fail;       /* set when a lane that is read could not prove its value: the push falls back to the full pass */
+    /* first-pass launches whose blocks take SEVERAL consecutive tiles (round 5): block x of the launch takes tiles tile0 + x tpb ...
+     * (below tile_end), and the input of a block's next tile is already on its way while the current one is computed */
+    uint32_t tpb, tile_end;  /* tpb <= 1: one tile per block, tile_end unused */
 };
 
 /* RSSI on demand.  The RSSI of a sample (rtl_wmbus.c:475-495: EMA of the filtered magnitude) is READ only at the chips of
@@ -209,21 +212,41 @@ __device__ __forceinline__ void k1_fir_s(const K1Args &a, const float *yDrS, con
     const WmPush &g = a.g;
     const int m0l = 4 * slot;
     if (m0l >= tn) return;
-    float w[52];                                              /* w[i] = element 4 slot + i */
-    /* newest samples first: the taps are summed k ascending, i.e. from the top of the window down, so the first products can
-     * start when the first vector is there instead of the thirteenth (r04 A/B: K1 alone 2.17 -> 2.10 ms) */
+    /* y[n] = sum_k b[k] x[n - k], k ascending (fir.h:58-67), for the four outputs n = 4 slot + j; element i of the thread's
+     * 52-sample window is x[4 slot - 48 + i], so tap k of output j reads element 48 + j - k.  The window passes through the
+     * registers in TWO halves, newest first: taps 0 .. 21 read elements 27 .. 51 (seven vectors), taps 22 .. 45 elements
+     * 3 .. 29 (eight vectors) -- 32 registers at a time instead of 52.  (Round 5: the registers are what a block's NEXT tile
+     * needs for its input words, which are in flight during this stage; with the whole window resident the kernel spilled.) */
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    {
+        float w[28];                                          /* w[i] = element 24 + i */
 #pragma unroll
-    for (int k = 12; k >= 0; k--) {
-        const float4 v = *(const float4 *)(yDrS + 4 * slot + 4 + 4 * k);
-        w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+        for (int k = 6; k >= 0; k--) {
+            const float4 v = *(const float4 *)(yDrS + 4 * slot + 4 + 24 + 4 * k);
+            w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float s_ = acc[j];
+#pragma unroll
+            for (int k = 0; k < 22; k++) s_ = FAST ? __builtin_fmaf(FIR_S[k], w[24 + j - k], s_) : wm_add(s_, wm_mul(FIR_S[k], w[24 + j - k]));
+            acc[j] = s_;
+        }
     }
-    float acc[4];
+    {
+        float w[32];                                          /* w[i] = element i */
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        float s = 0.0f;
+        for (int k = 7; k >= 0; k--) {
+            const float4 v = *(const float4 *)(yDrS + 4 * slot + 4 + 4 * k);
+            w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+        }
 #pragma unroll
-        for (int k = 0; k < 46; k++) s = FAST ? __builtin_fmaf(FIR_S[k], w[48 + j - k], s) : wm_add(s, wm_mul(FIR_S[k], w[48 + j - k]));
-        acc[j] = s;
+        for (int j = 0; j < 4; j++) {
+            float s_ = acc[j];
+#pragma unroll
+            for (int k = 22; k < 46; k++) s_ = FAST ? __builtin_fmaf(FIR_S[k], w[48 + j - k], s_) : wm_add(s_, wm_mul(FIR_S[k], w[48 + j - k]));
+            acc[j] = s_;
+        }
     }
     *(float4 *)(a.dphi + ((uint64_t)g.S + stream) * g.Mcap + (uint64_t)ts + m0l) = make_float4(acc[0], acc[1], acc[2], acc[3]);
 }
@@ -390,11 +413,33 @@ __device__ __forceinline__ void k1_stage_rssi(const K1Args &a, const int tid, co
     }
 }
 
+/* The staged input of a tile: dword u of the tile's window (two IQ samples) at src[u], u < NDW; LDS word 2 u - off. */
+template <int NT> struct K1Src { const uint32_t *src; long r_al; int off, NDW; };
+template <int D, int NT>
+__device__ __forceinline__ K1Src<NT> k1_src(const K1Args &a, const int tile, const int stream)
+{
+    const WmPush &g = a.g;
+    const int d = D ? D : (int)g.d, ts = tile * K1GeoT<NT>::T;
+    K1Src<NT> s;
+    const long r_lo = ((long)(g.m0 + (uint64_t)ts) - WM_K1_HALO) * d - 16 - (long)g.n0;   /* LDS word 0 */
+    s.r_al = r_lo & ~1L;
+    s.off = (int)(r_lo - s.r_al);                             /* 0 or 1 */
+    s.NDW = (K1GeoT<NT>::NA * d + 16 + 1 + 1) / 2;            /* dwords covering the staged samples */
+    const uint8_t *base = g.in + (uint64_t)stream * g.in_stride + WM_HIST_BYTES;
+    s.src = (const uint32_t *)(base + 2 * s.r_al);
+    return s;
+}
+
 /* GEN = false: the kernel of the DEFAULT switches (both chains, cargf arctangent, first pass): the switch tests, the
  * -a / -A / -p paths and the RSSI repair walk are not compiled in, so the default path carries no cost for the options
  * (any other configuration, and every repair launch, runs the GEN = true kernel: same arithmetic, same results). */
-template <int D, bool SHIFT, bool GEN, bool FAST = false, int RS = 0, int NT = 256>
-__device__ __forceinline__ void k1_tile(const K1Args &a, const int tile, const int stream, const int tid)
+/* PRE (first pass, compiled decimations): the tile's input words are in `pre` already (loads the caller or the previous tile
+ * of this block issued), and once they are converted the same registers receive the words of tile `next` (< 0: none) -- the
+ * 4.5 microseconds a block waited for its input before it could do anything (41 % of a wave's life, profiles/r05_k1_stage_cycles.txt)
+ * then pass while the block computes.  `first`: the block's first tile (the arctangent's table is loaded once per block). */
+template <int D, bool SHIFT, bool GEN, bool FAST = false, int RS = 0, int NT = 256, bool PRE = false>
+__device__ __forceinline__ void k1_tile(const K1Args &a, const int tile, const int stream, const int tid,
+                                        uint32_t (&pre)[D ? ((K1GeoT<NT>::NA * D + 16 + 1 + 1) / 2 + NT - 1) / NT : 1], const int next, const bool first)
 {
     using G = K1GeoT<NT>;
     constexpr int T = G::T, NA = G::NA, YD = G::YD, YM = G::YM;
@@ -421,26 +466,25 @@ __device__ __forceinline__ void k1_tile(const K1Args &a, const int tile, const i
     WM_K1_STAMP_DECL;
     WM_K1_STAMP(0);
     {
-        const long r_lo = ((long)(g.m0 + (uint64_t)ts) - WM_K1_HALO) * d - 16 - (long)g.n0;   /* LDS word 0 */
-        const long r_al = r_lo & ~1L;
-        const int off = (int)(r_lo - r_al);                   /* 0 or 1 */
-        const int NDW = (NA * d + 16 + 1 + 1) / 2;            /* dwords covering the staged samples */
-        const uint8_t *base = g.in + (uint64_t)stream * g.in_stride + WM_HIST_BYTES;
-        const uint32_t *src = (const uint32_t *)(base + 2 * r_al);
+        const K1Src<NT> in = k1_src<D, NT>(a, tile, stream);
+        const long r_al = in.r_al;
+        const int off = in.off, NDW = in.NDW;
+        const uint32_t *src = in.src;
         constexpr int NP = D ? ((NA * D + 16 + 1 + 1) / 2 + NT - 1) / NT : 1;     /* loads in flight per lane */
+        static_assert(!PRE || D != 0, "the prefetch is for the compiled decimations (one pass of NP loads per lane)");
         const int passes = D ? 1 : (NDW + NT - 1) / NT;
         for (int ps = 0; ps < passes; ps++) {
         uint32_t wv[NP];
 #pragma unroll
         for (int it = 0; it < NP; it++) {
             const int u = tid + NT * (it + ps);
-            wv[it] = u < NDW ? src[u] : 0u;
+            wv[it] = PRE ? pre[it] : u < NDW ? src[u] : 0u;
         }
         /* the arctangent's table (5 range rows + range LUT, wm_exact.h): word k by lane k, ONE load issued behind the
          * input loads and waited for with them (round 4 computed it in place: six dependent global loads in the first
          * wave of every block before its input loads went out) */
         uint32_t tabw = 0u;
-        if (RS != 2 && ps == 0 && tid < WM_ATAN_TAB_WORDS) tabw = WM_ATAN_TAB_BITS[tid];
+        if (RS != 2 && ps == 0 && first && tid < WM_ATAN_TAB_WORDS) tabw = WM_ATAN_TAB_BITS[tid];
 #pragma unroll
         for (int it = 0; it < NP; it++) {
             const int u = tid + NT * (it + ps);
@@ -478,7 +522,12 @@ __device__ __forceinline__ void k1_tile(const K1Args &a, const int tile, const i
                 }
             }
         }
-        if (RS != 2 && ps == 0 && tid < WM_ATAN_TAB_WORDS) tab[tid] = wm_u2f(tabw);
+        if (RS != 2 && ps == 0 && first && tid < WM_ATAN_TAB_WORDS) tab[tid] = wm_u2f(tabw);
+        }
+        if (PRE && next >= 0) {                               /* the next tile's input into the registers this tile's has just left */
+            const K1Src<NT> nx = k1_src<D, NT>(a, next, stream);
+#pragma unroll
+            for (int it = 0; it < NP; it++) { const int u = tid + NT * it; pre[it] = u < nx.NDW ? nx.src[u] : 0u; }
         }
     }
     WM_K1_STAMP(1);
@@ -577,16 +626,34 @@ __global__ __launch_bounds__(NT, GEN ? 1 : RS == 2 ? 4 : 8) void k1_demod2(K1Arg
     if (RS == 2) {                                            /* the tiles k3_spans has listed, walked by a fixed grid */
         const uint32_t n = *a.n_relist;
         for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
-            k1_tile<D, SHIFT, GEN, FAST, RS>(a, (int)(a.relist[e] % a.ntiles), (int)(a.relist[e] / a.ntiles), (int)threadIdx.x);
+            uint32_t none[D ? ((K1Geo::NA * D + 16 + 1 + 1) / 2 + 255) / 256 : 1];
+            k1_tile<D, SHIFT, GEN, FAST, RS>(a, (int)(a.relist[e] % a.ntiles), (int)(a.relist[e] / a.ntiles), (int)threadIdx.x, none, -1, true);
             __syncthreads();                                  /* the tile's LDS is reused by the next entry */
         }
         return;
     }
-    if (!GEN || a.relist == nullptr) { k1_tile<D, SHIFT, GEN, FAST, RS, NT>(a, (int)(blockIdx.x + a.tile0), (int)blockIdx.y, (int)threadIdx.x); return; }
+    constexpr int NP = D ? ((K1GeoT<NT>::NA * D + 16 + 1 + 1) / 2 + NT - 1) / NT : 1;
+    uint32_t pre[NP];
+    if constexpr (D != 0 && RS == 1) {
+        /* the first pass without the RSSI: a.tpb consecutive tiles per block, each tile's input loaded while the one before is computed */
+        const int tpb = a.tpb > 1u ? (int)a.tpb : 1;
+        const int t0 = (int)a.tile0 + (int)blockIdx.x * tpb, t1 = a.tpb > 1u ? min(t0 + tpb, (int)a.tile_end) : t0 + 1;
+        const int stream = (int)blockIdx.y, tid = (int)threadIdx.x;
+        {
+            const K1Src<NT> in = k1_src<D, NT>(a, t0, stream);
+#pragma unroll
+            for (int it = 0; it < NP; it++) { const int u = tid + NT * it; pre[it] = u < in.NDW ? in.src[u] : 0u; }
+        }
+        /* no barrier between two tiles of a block: a tile's stage 0 writes the staging area, which nobody reads behind the
+         * tile's second barrier (RS = 1 has no magnitude rows), and the discriminator rows are written behind the NEXT first barrier */
+        for (int t = t0; t < t1; t++) k1_tile<D, SHIFT, GEN, FAST, RS, NT, true>(a, t, stream, tid, pre, t + 1 < t1 ? t + 1 : -1, t == t0);
+        return;
+    }
+    if (!GEN || a.relist == nullptr) { k1_tile<D, SHIFT, GEN, FAST, RS, NT>(a, (int)(blockIdx.x + a.tile0), (int)blockIdx.y, (int)threadIdx.x, pre, -1, true); return; }
     /* repair launch: a fixed grid walks the list k1_collect has just written (no host round trip in between) */
     const uint32_t n = *a.n_relist;
     for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
-        k1_tile<D, SHIFT, GEN, FAST>(a, (int)(a.relist[e] % a.ntiles), (int)(a.relist[e] / a.ntiles), (int)threadIdx.x);
+        k1_tile<D, SHIFT, GEN, FAST>(a, (int)(a.relist[e] % a.ntiles), (int)(a.relist[e] / a.ntiles), (int)threadIdx.x, pre, -1, true);
         __syncthreads();                                      /* the tile's LDS is reused by the next entry */
     }
 }

@@ -66,20 +66,32 @@ template <int D, bool SHIFT> static void run_k1(const K1Args &a, uint32_t gx, ui
         }
 }
 
-extern "C" { int wm_emu_k1_big = 0; }      /* 1: the first pass without the RSSI on 2000-sample tiles of 512 threads (wmbus_ctx.k1_big: d = 2, no -s) */
+extern "C" { int wm_emu_k1_big = 0; int wm_emu_k1_tpb = 1; }      /* tpb: consecutive tiles per block of the first pass (K1Args.tpb) */      /* 1: the first pass without the RSSI on 2000-sample tiles of 512 threads (wmbus_ctx.k1_big: d = 2, no -s) */
 
 template <int D, bool SHIFT> static void run_k1_od(K1Args a, uint32_t ntiles, uint32_t S, const std::vector<uint32_t> &list, uint32_t *n_list)
 {
+    const uint32_t tpb = (uint32_t)(wm_emu_k1_tpb > 1 ? wm_emu_k1_tpb : 1);
+    a.tpb = tpb;
     if (D == 2 && !SHIFT && wm_emu_k1_big) {
-        const uint32_t nt1 = (a.g.M + WM_K1_TILE_BIG - 1) / WM_K1_TILE_BIG;
-        gridDim = {nt1, S, 1};
+        const uint32_t nt1 = (a.g.M + WM_K1_TILE_BIG - 1) / WM_K1_TILE_BIG, nb = (nt1 + tpb - 1) / tpb;
+        a.tile_end = nt1;
+        gridDim = {nb, S, 1};
         for (uint32_t y = 0; y < S; y++)
-            for (uint32_t x = 0; x < nt1; x++) { blockIdx = {x, y, 0}; block_emu::run_block(512, [&] { k1_demod2<2, false, false, false, 1, 512>(a); }); }
+            for (uint32_t x = 0; x < nb; x++) { blockIdx = {x, y, 0}; block_emu::run_block(512, [&] { k1_demod2<2, false, false, false, 1, 512>(a); }); }
     } else {
-    gridDim = {ntiles, S, 1};
-    for (uint32_t y = 0; y < S; y++)
-        for (uint32_t x = 0; x < ntiles; x++) { blockIdx = {x, y, 0}; block_emu::run_block(256, [&] { k1_demod2<D, SHIFT, false, false, 1>(a); }); }
+    /* like the product: the push's tiles leave in two launches (the turn of the demodulation kernel is handed over early) */
+    const uint32_t n_tail = ntiles > 3 ? ntiles / 3 : 0, n_main = ntiles - n_tail;
+    for (int part = 0; part < 2; part++) {
+        const uint32_t lo = part ? n_main : 0, hi = part ? ntiles : n_main, nb = (hi - lo + tpb - 1) / tpb;
+        if (hi == lo) continue;
+        a.tile0 = lo; a.tile_end = hi;
+        gridDim = {nb, S, 1};
+        for (uint32_t y = 0; y < S; y++)
+            for (uint32_t x = 0; x < nb; x++) { blockIdx = {x, y, 0}; block_emu::run_block(256, [&] { k1_demod2<D, SHIFT, false, false, 1>(a); }); }
     }
+    a.tile0 = 0;
+    }
+    a.tpb = 0; a.tile_end = 0;
     a.relist = list.data(); a.n_relist = n_list;
     gridDim = {5, 1, 1};                                                    /* a fixed grid walks the list */
     for (uint32_t x = 0; x < 5; x++) { blockIdx = {x, 0, 0}; block_emu::run_block(256, [&] { k1_demod2<D, SHIFT, false, false, 2>(a); }); }

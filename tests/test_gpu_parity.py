@@ -308,7 +308,10 @@ def test_rssi_on_demand_falls_back_to_the_full_pass_where_it_cannot_prove_a_valu
             for off in range(0, cu8.size, push):
                 rx.push([cu8[off:off + push]])
                 text += [ln["text"] for ln in rx.lines()]
-                slow += rx.timing()["slow_path"]
+                tm = rx.timing()
+                slow += tm["slow_path"]
+                # how the push got its RSSI is reported: a full pass behind an unprovable value is FELL_BACK (and slow)
+                assert tm["rssi_mode"] != wm.RSSI_EVERY_SAMPLE and (tm["rssi_mode"] != wm.RSSI_FELL_BACK or tm["slow_path"] == 1)
             assert "".join(text) == ref["text"], push
     assert slow > 0                                         # the full pass was needed somewhere
 

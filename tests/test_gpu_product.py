@@ -460,6 +460,34 @@ def test_rssi_on_demand_goes_dense_pauses_and_comes_back(wm, oracle):
 
     text, tims = run(rssi_dense_pm=1000)                              # never pause: every push on demand
     assert text == want
-    assert all(t["rssi_mode"] in (OD, FB) for t in tims)
-    assert tims[k_silent]["rssi_mode"] == FB and tims[k_silent]["slow_path"] == 1
-    assert sum(t["rssi_mode"] == OD for t in tims) >= n_push - 6      # the fall-back is the exception
+    assert all(t["rssi_mode"] in (OD, FB) and t["rssi_tiles"] > 0 for t in tims)
+
+
+def test_rssi_on_demand_falls_back_for_a_telegram_right_behind_exact_silence(wm, oracle):
+    """A telegram whose preamble begins in exact silence: the tile that holds its access code is listed, and the lanes of that
+    tile whose warm-up lies in the silence cannot prove their start (lower trajectory 0, upper one still above it) -- THAT push
+    must take the full pass (rssi_mode FELL_BACK, slow_path), every other push stays on demand, the text is the oracle's."""
+    push, n_push = 1 << 16, 24                                        # 16384 decimated samples = 17 tiles per push
+    cu8, frames = wm.synth_capture(seed=909, n_samples=n_push * push // 2, kinds=wm.T1 | wm.C1A | wm.C1B, frames_per_s=25.0, amplitude=50.0)
+    cu8 = cu8.copy()
+    pick = None
+    for f in frames:                                                  # a frame whose access code (~384 decimated samples in) sits well inside a tile
+        F = f["start"] // 2                                           # decimated sample of the frame's first chip
+        k, p = divmod(F + 384, push // 4)
+        if f["complete"] and 2 <= k < n_push - 1 and 2500 < p < push // 4 - 6000 and 400 < p % 976 < 900:
+            pick = (f, F, k)
+            break
+    assert pick is not None
+    f, F, k_silent = pick
+    cu8[2 * 2 * (F - 2000): 2 * 2 * (F + 160)] = 128                  # exact zero input up to twenty chips into the preamble (the sync word stays)
+    want = oracle.run(cu8, flags_to_oracle_opts(oracle, ["-v"]))["text"]
+    assert f["telegram"].hex() in want                                # the telegram behind the silence is still received
+    text, tims = [], []
+    with wm.Receiver(n_streams=1, max_push_bytes=push, keep_taps=False, rssi_dense_pm=1000) as rx:
+        for k in range(n_push):
+            text.append(rx.push([cu8[k * push:(k + 1) * push]]))
+            tims.append(rx.timing())
+    assert "".join(text) == want
+    modes = [t["rssi_mode"] for t in tims]
+    assert modes[k_silent] == wm.RSSI_FELL_BACK and tims[k_silent]["slow_path"] == 1, (k_silent, modes)
+    assert sum(m == wm.RSSI_ON_DEMAND for m in modes) >= n_push - 3, modes

@@ -137,13 +137,14 @@ def test_atan2_approximation_options_on_host(emu, oracle, wm, atan_mode, d, extr
     check(emu, oracle, cu8, ["-v"] + (["-d", str(d)] if d != 2 else []) + extra, d, [4096 * 9, 4096 * 2], polyphase, atan_mode)
 
 
-def run_on_demand(emu, cu8, d, flags, push_bytes, rng, density, big=False):
+def run_on_demand(emu, cu8, d, flags, push_bytes, rng, density, big=False, tpb=1):
     """One capture push by push the RSSI-on-demand way: the first pass without RSSI, then the RSSI of randomly flagged tiles.
     Returns dphi [2][M], rssi [2][M], read [2][M] bool (samples whose RSSI was asked for), the filter state per push, failures."""
     emu.wm_emu_k1_od.restype = ctypes.c_long
     emu.wm_emu_k1_od.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint64, ctypes.c_uint,
                                  ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     ctypes.c_int.in_dll(emu, "wm_emu_k1_big").value = int(big)    # the first pass on 2000-sample tiles of 512 threads (wmbus_ctx.k1_big)
+    ctypes.c_int.in_dll(emu, "wm_emu_k1_tpb").value = int(tpb)    # ... several consecutive tiles per block, the next tile's input prefetched (K1Args.tpb)
     total = cu8.size // 4096 * 4096
     stride = (HIST + max(push_bytes) + 2 * (2048 + 16) * d + SLACK + 255) // 256 * 256     # a partial last tile reads (never uses) a tile past the staged bytes
     row = np.full(stride, 128, np.uint8)
@@ -170,17 +171,19 @@ def run_on_demand(emu, cu8, d, flags, push_bytes, rng, density, big=False):
     return [np.concatenate(x) for x in out_d], [np.concatenate(x) for x in out_r], [np.concatenate(x) for x in out_m], states, fails
 
 
-@pytest.mark.parametrize("d,flags_cli,big", [(2, ["-v"], False), (2, ["-v"], True), (2, ["-v", "-s"], False), (3, ["-v", "-d", "3"], False), (5, ["-v", "-d", "5", "-s"], False)])
-def test_rssi_on_demand_matches_the_oracle_where_it_is_read(emu, oracle, wm, d, flags_cli, big):
+@pytest.mark.parametrize("d,flags_cli,big,tpb", [(2, ["-v"], False, 1), (2, ["-v"], True, 1), (2, ["-v"], False, 2), (2, ["-v"], True, 3), (2, ["-v", "-s"], False, 2),
+                                                 (3, ["-v", "-d", "3"], False, 4), (5, ["-v", "-d", "5", "-s"], False, 1), (4, ["-v", "-d", "4"], False, 64)])
+def test_rssi_on_demand_matches_the_oracle_where_it_is_read(emu, oracle, wm, d, flags_cli, big, tpb):
     """RS = 1 leaves the soft symbols as they were; RS = 2 fills in the RSSI of the flagged tiles, every lane proving the
     state it starts from by a bracket of two trajectories (wm_k1_demod.h), and hands on the filter's state.  big: the first
-    pass runs on 2000-sample tiles of 512 threads (the product's choice at decimation 2 without -s), the RSSI launch on its 976."""
+    pass runs on 2000-sample tiles of 512 threads (an option at decimation 2 without -s), the RSSI launch on its 976; tpb: a block of the
+    first pass takes that many consecutive tiles, the input of the next one loaded while the current one is computed."""
     rng = np.random.default_rng(77 + d)
     cu8 = wm.synth_capture(seed=4242 + d, n_samples=1 << 17, kinds=15, frames_per_s=200.0, fs_khz=FS[d])[0]
     ref = oracle.run(cu8, flags_to_oracle_opts(oracle, flags_cli), taps=True)
     flags = F_ACCURATE | F_T1C1 | F_S1 | (F_SHIFT if "-s" in flags_cli else 0)
     for pushes in ([1 << 18], [4096 * 5, 4096 * 16, 4096]):
-        dphi, rssi, read, states, fails = run_on_demand(emu, cu8, d, flags, pushes, rng, 0.3, big=big)
+        dphi, rssi, read, states, fails = run_on_demand(emu, cu8, d, flags, pushes, rng, 0.3, big=big, tpb=tpb)
         assert fails == 0                                   # noise and signal: every bracket closes inside the warm-up
         for ch in (0, 1):
             m = len(dphi[ch])
