@@ -172,7 +172,7 @@ struct wmbus_ctx {
     WmPkt *h_pkts = nullptr; uint8_t *h_bytes = nullptr;
     void *dv_hdr = nullptr, *dv_words = nullptr, *dv_pkts = nullptr, *dv_bytes = nullptr;    /* their device views */
     uint32_t n_hdr = 0, n_words = 0, n_pkts = 0;
-    K1Args k1a{}; K2Args k2clk{}, k2rla{}; uint32_t ntiles = 0; bool fused = false;    /* this push's launch arguments (collect's slow path re-uses them) */
+    K1Args k1a{}; K2Args k2clk{}, k2rla{}; uint32_t ntiles = 0;    /* this push's launch arguments (collect's slow path re-uses them) */
     std::vector<HostDecoder> decs;                      /* [stream][chain][algo] */
     std::vector<wm_twin> twins;                         /* [stream][chain][2]: the last lines printed (cfg.dedup_twins) */
     std::unique_ptr<WorkerPool> pool;                   /* packet-decoder workers, created on first use */
@@ -448,7 +448,6 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
                (cfg->time2_enabled ? WM_F_T2A : 0);
     if (c->S < 64u) { c->ema_rounds = 2; c->fr_rounds = 5; }
     c->opt_rounds = !cfg->rounds_on_host;
-    if (cfg->fuse_framers && c->fr_rounds < 3) c->fr_rounds = 3;      /* the run-length framer's second list round rides in the third fused launch */
     /* the run-length framer gets as many list rounds as the clock kernel (round 3: one fewer -- enough for 1.6 MS/s captures,
      * "2300 re-runs, then 0", but configs[2] (-d 5 -s) leaves 750 lanes after the first round and fell to the host-driven
      * path on EVERY push: 64 ms per step instead of 25) */
@@ -715,22 +714,6 @@ static void fr_launch(wmbus_ctx *c, int algo, uint32_t cnt, hipStream_t st = nul
     else hipLaunchKernelGGL(k2_clock_list<false>, dim3(grid), dim3(B), 0, st, a);
 }
 
-/* the fused launch (cfg.fuse_framers): clock re-run list (scalar cnt_c) + run-length framer, all lanes (cnt_r == ~0) or its list */
-static void fr_launch_fused(wmbus_ctx *c, uint32_t cnt_c, uint32_t cnt_r)
-{
-    K2Args ca = c->k2clk, ra = c->k2rla;
-    ca.list = c->d_list; ca.n_ptr = c->d_scalars + cnt_c; ca.n_lanes = 0;
-    if (cnt_c == (uint32_t)SC_CLK) ca.bad = nullptr;          /* first list round: every listed segment on its own (fr_launch) */
-    const uint32_t lanes_r = 2u * ra.g.nseg[0] * ra.g.S, Br = 64 * WM_RLA_WPB;
-    const bool all = cnt_r == 0xFFFFFFFFu;
-    ra.list = all ? nullptr : c->d_list2; ra.n_lanes = lanes_r; ra.n_ptr = all ? nullptr : c->d_scalars + cnt_r;
-    if (!all && cnt_r == SC_RLA + 1u) ra.bad = nullptr;
-    const uint32_t lanes_c = 2u * ca.g.nseg[1] * ca.g.S;
-    const uint32_t cb = std::max(32u, (lanes_c / 64u) * 3u / 16u);           /* one clock wave per block here; blocks for 3/16 of the lanes */
-    const uint32_t rb = all ? (lanes_r + Br - 1) / Br : std::max(16u, (lanes_r / Br) * 3u / 16u);
-    hipLaunchKernelGGL(k2_clock_rla, dim3(cb + rb), dim3(Br), 0, c->stream, ca, ra, cb);
-}
-
 static void fr_carry(wmbus_ctx *c)
 {
     const uint32_t rows = 2u * c->S;
@@ -906,26 +889,15 @@ static int enqueue_front_impl(wmbus_ctx *c, size_t nbytes)
          * 4-5 ms and both LOSE: the job is bound by the ring of demodulation kernels, and more streams or fatter launches only
          * get in its way; DESIGN_HISTORY.md.) */
         const bool rla = c->flags & WM_F_RLA;
-        c->fused = c->cfg.fuse_framers && rla && !(c->flags & WM_F_DC) && c->opt_rounds;
         HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
         fr_launch(c, WMBUS_ALGO_T2A, 0xFFFFFFFFu);                 /* the clock kernel's first pass */
-        if (c->fused) {
-            /* round r carries the clock kernel's list r and the run-length framer's main pass (r = 0) or its list r */
-            for (unsigned r = 0; r < c->fr_rounds; r++) {
-                fr_verify(c, WMBUS_ALGO_T2A, SC_CLK + r);
-                if (r) fr_verify(c, WMBUS_ALGO_RLA, SC_RLA + r);
-                fr_launch_fused(c, SC_CLK + r, r ? SC_RLA + r : 0xFFFFFFFFu);
-            }
-            HIPCHK(c, hipEventRecord(c->ev[8], c->stream));
-        } else {
         for (unsigned r = 0; r < c->fr_rounds && c->opt_rounds; r++) { fr_verify(c, WMBUS_ALGO_T2A, SC_CLK + r); fr_launch(c, WMBUS_ALGO_T2A, SC_CLK + r); }
         HIPCHK(c, hipEventRecord(c->ev[8], c->stream));
         if (rla) {
             fr_launch(c, WMBUS_ALGO_RLA, 0xFFFFFFFFu);
             for (unsigned r = 1; r < c->rla_rounds && c->opt_rounds; r++) { fr_verify(c, WMBUS_ALGO_RLA, SC_RLA + r); fr_launch(c, WMBUS_ALGO_RLA, SC_RLA + r); }
         } else HIPCHK(c, hipMemsetAsync(c->d_counts[0], 0, (size_t)2 * c->S * c->nseg_cap[0] * sizeof(uint32_t), c->stream));
-        }
-        c->rla_fin = c->fused ? c->fr_rounds : c->rla_rounds;
+        c->rla_fin = c->rla_rounds;
         fr_verify(c, WMBUS_ALGO_T2A, SC_CLK + c->fr_rounds);
         if (rla) fr_verify(c, WMBUS_ALGO_RLA, SC_RLA + c->rla_fin);
         HIPCHK(c, hipEventRecord(c->ev[1], c->stream));

@@ -36,29 +36,6 @@
 #include "wm_k2_clock.h"
 #include "wm_k2_rla.h"
 
-/* One launch for two independent pieces of work (cfg.fuse_framers): the clock kernel's re-run lanes (few, long) and the
- * run-length framer (its main pass or its own re-run list).  Without the DC remover the slicer words are final after the clock
- * kernel's FIRST pass (sign of the soft symbol, no state), so the run-length framer need not wait for the clock re-runs, and
- * sharing a launch keeps both on the context's one stream (more streams than hardware queues serialise against each other).
- * Blocks [0, clk_blocks) walk the clock list, one wave each in the footprint of a run-length block (a block that needs a quarter
- * of a CU's LDS cannot be placed while the demodulation kernel refills the CU with its small blocks); the rest are run-length
- * blocks.  Round 2 built it, rounds 3-4 measured it neutral-to-negative while the ring of demodulation kernels bound the step;
- * round 5's shorter demodulation kernel makes a context's chain of launches the bound, which is what this shortens. */
-__global__ __launch_bounds__(64 * WM_RLA_WPB) void k2_clock_rla(K2Args clk, K2Args rla, uint32_t clk_blocks)
-{
-    wm_framer_prio();
-    __shared__ __attribute__((aligned(16))) union { ClkLds<1> c; RlaLds r; } lds;
-    if (blockIdx.x < clk_blocks) {
-        const uint32_t n = k2_lane_count(clk);
-        for (uint32_t b = blockIdx.x; (uint64_t)b * 64u < n; b += clk_blocks) clock_lanes<false, 1, false, 1>(clk, b, lds.c);
-    } else {
-        rla_lds_init(lds.r, threadIdx.x, 64 * WM_RLA_WPB);     /* the whole block is on this side */
-        __syncthreads();
-        const uint32_t n = k2_lane_count(rla), nb = gridDim.x - clk_blocks;
-        for (uint32_t b = blockIdx.x - clk_blocks; (uint64_t)b * (64u * WM_RLA_WPB) < n; b += nb) rla_lanes(rla, b, lds.r);
-    }
-}
-
 /* start[seg] must equal final[seg-1]; mismatching lanes are appended to `list`. */
 __global__ void k2_verify(WmPush g, uint32_t algo, const uint32_t *st_start, const uint32_t *st_final, uint32_t words,
                           uint32_t *list, uint32_t *n_list, uint32_t *bad)
