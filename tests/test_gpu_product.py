@@ -491,3 +491,29 @@ def test_rssi_on_demand_falls_back_for_a_telegram_right_behind_exact_silence(wm,
     modes = [t["rssi_mode"] for t in tims]
     assert modes[k_silent] == wm.RSSI_FELL_BACK and tims[k_silent]["slow_path"] == 1, (k_silent, modes)
     assert sum(m == wm.RSSI_ON_DEMAND for m in modes) >= n_push - 3, modes
+
+
+@pytest.mark.parametrize("tune", [dict(k1_tiles_per_block=3), dict(k1_tiles_per_block=1, k1_small_tile=True), dict(k1_tiles_per_block=4, k1_small_tile=True)],
+                         ids=["tpb3", "tpb1-small", "tpb4-small"])
+def test_tuning_fields_change_speed_not_output(wm, oracle, samples, tune):
+    """The launch-structure knobs of round 5 (k1_tiles_per_block / k1_small_tile: how the demodulation kernel's first pass cuts a
+    push into blocks, with the next tile's input prefetched) against the oracle: the bundled capture whole and in ragged pushes,
+    and 70 synthetic captures (one whole wave + a ragged one) with warm-ups short enough that every kind of re-run list is long
+    -- in two pushes, so that carried state crosses them."""
+    cu8 = samples["samples2"][: samples["samples2"].size // 4096 * 4096]
+    want = oracle.run(cu8, flags_to_oracle_opts(oracle, ["-v"]))["text"]
+    for push in (cu8.size, 4096 * 37):
+        with wm.Receiver(n_streams=1, max_push_bytes=push, keep_taps=False, **tune) as rx:
+            assert rx.run(cu8, push_bytes=push)[0] == want, push
+    n = 1 << 19
+    caps = [wm.synth_capture(seed=8800 + s, n_samples=n, kinds=15, frames_per_s=150.0, amplitude=40.0)[0] for s in range(70)]
+    wants = oracle.run_many(caps, flags_to_oracle_opts(oracle, ["-v"]))
+    with wm.Receiver(n_streams=70, max_push_bytes=n, keep_taps=False, seg_len=8192, rla_seg_len=2048, warmup_t1c1=2048, warmup_s1=4096, **tune) as rx:
+        text = [""] * 70
+        for off in (0, n):
+            rx.push([c[off:off + n] for c in caps])
+            for ln in rx.lines():
+                text[ln["stream"]] += ln["text"]
+            tm = rx.timing()
+            assert tm["clock_reruns"] > 0 and tm["rla_reruns"] > 0
+    assert text == wants
