@@ -215,6 +215,9 @@ def leg_c3_batch(wm, O, shard, S, n, device, steps, **tune):
         k1 = sum(alone) / len(alone)
         mean = {k: round(sum(t[k] for t in tims) / max(1, len(tims)), 3) for k in ("turn_wait_ms", "demod_ms", "clock_ms", "rla_ms", "gather_ms", "gpu_total_ms", "host_decode_ms",
                                                                                   "clock_reruns", "rla_reruns", "ema_retries", "slow_path")}
+        for key in ("clock_round", "rla_round"):
+            mean[key] = [round(sum(t[key][r] for t in tims) / max(1, len(tims)), 1) for r in range(4)]
+        mean["slow_pushes"] = sum(1 for t in tims if t["slow_path"])
         return {"stage_ms_mean_per_context_push": mean,"workload": f"{S} captures x {n} IQ samples at 4.0 MS/s, -d 5 -s, T1 + C1 at +325 kHz and S1 at -325 kHz, HBM-resident",
                 "value": round(S * n * steps / dt / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps,
                 "contexts_per_gpu": len(b.contexts), "kernel": "k1_demod2<5, true, false, false>", "k1_alone_ms": round(k1, 3),

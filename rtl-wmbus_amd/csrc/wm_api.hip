@@ -452,6 +452,10 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
      * "2300 re-runs, then 0", but configs[2] (-d 5 -s) leaves 750 lanes after the first round and fell to the host-driven
      * path on EVERY push: 64 ms per step instead of 25) */
     c->rla_rounds = std::min<unsigned>(c->fr_rounds + 1u, WM_MAX_ROUNDS + 1u);
+    /* ... and one more with -s: S1 telegrams (30-100 ms) lie in BOTH chains' bands there, a telegram is a chain of twenty to forty
+     * run-length segments that only a walk from its first one settles, and two list rounds left a remainder in every tenth push of
+     * configs[2] (round 5: rla_round = 10 994, 5 088, then the host-driven path; an empty round costs 0.2 ms) */
+    if (cfg->simultaneous) c->rla_rounds = std::min<unsigned>(c->rla_rounds + 1u, WM_MAX_ROUNDS + 1u);
     c->T = (uint32_t)WM_K1_TILE2;
     const uint32_t T = c->T;
     const uint64_t max_samples = cfg->max_push_bytes / 2;
