@@ -64,7 +64,7 @@ typedef struct wmbus_cfg {
     unsigned host_threads;      /* host decoder threads, 0 = auto                    */
     int keep_taps;              /* 1: wmbus_read_tap may be used (the debug views of the last push).  0: no views -- the context then
                                    computes the RSSI only for the samples a packet decoder reads (the default switches at
-                                   decimation 2 ... 5; DESIGN.md section 2 item 3a): same datagrams, fewer instructions */
+                                   decimation 2 ... 5; DESIGN.md section 2 item 4): same datagrams, fewer instructions */
     /* Low-pass in front of the decimator.  BOXCAR = the moving averages the reference's main()
      * runs (rtl_wmbus.c:1333-1344): what every reference binary computes, bit for bit.
      * POLYPHASE = lp_ppf_butter_1600kHz_160kHz_200kHz (rtl_wmbus.c:258-294 over ppf.h:46-59), which
@@ -88,7 +88,7 @@ typedef struct wmbus_cfg {
      * default switches (both chains, cargf arctangent, no -P): the discriminator uses a polynomial arctangent and the two
      * FIR low-passes fused multiply-adds, so soft symbols agree with the reference's to 2e-6 (absolute; they lie in
      * [-1, 1]) instead of bit for bit; RSSI, clock recovery and framers stay exact on those symbols.  A telegram whose
-     * decision hangs on the last bits of a soft symbol may decode differently (DESIGN.md section 12 counts them). */
+     * decision hangs on the last bits of a soft symbol may decode differently (DESIGN_HISTORY.md section 12 and DESIGN.md section 6 count them). */
     int tolerance_mode;
     /* Tuning and test knobs, 0 = the library's default.  (Rounds 1-4 read these from WMBUS_* environment variables inside the
      * push path; as configuration two contexts of one process can differ, and nothing in a push calls getenv.) */
@@ -144,7 +144,7 @@ typedef struct wmbus_timing {
 } wmbus_timing;
 
 /* wmbus_timing.rssi_mode.  EVERY_SAMPLE: in the demodulation kernel (contexts with debug views, option kernels, cfg.rssi_full).
- * ON_DEMAND: only where a packet decoder reads it (DESIGN.md section 2 item 3a).  PAUSED: an on-demand context whose bursts
+ * ON_DEMAND: only where a packet decoder reads it (DESIGN.md section 2 item 4).  PAUSED: an on-demand context whose bursts
  * cover most of its tiles takes the full pass for sixteen pushes.  FELL_BACK: a value read could not be proven, the push was
  * finished by the full pass (slow_path is set too). */
 enum { WMBUS_RSSI_EVERY_SAMPLE = 0, WMBUS_RSSI_ON_DEMAND = 1, WMBUS_RSSI_PAUSED = 2, WMBUS_RSSI_FELL_BACK = 3 };

@@ -137,7 +137,7 @@ unsigned wmbus_batch_plan(const wmbus_cfg *cfg, unsigned contexts, unsigned *cou
     const unsigned S = cfg->n_streams;
     /* Contexts of whole 64-capture waves where the batch allows it (the clock kernel's cooperative loads need that); by
      * default 8 of them, at most one per 64 captures: 8 x 128 for the 1024 captures of the headline configuration
-     * (4 / 6 / 10 / 12 / 16 contexts measured 96 / 111 / 141 / 120 / 117 against 144 Gsamples/s with 8).
+     * (4 / 6 / 10 / 12 / 16 contexts measured 96 / 111 / 141 / 120 / 117 against 144 Gsamples/s with 8, DESIGN_HISTORY.md section 8).
      * (tolerance mode: the demodulation kernel is a third shorter, the framers' share of a context's chain larger, and
      * twelve contexts cover it better than eight: 167 against 162 Gsamples/s) */
     unsigned nctx = contexts ? contexts : std::min(cfg->tolerance_mode ? 12u : 8u, std::max(1u, S / 64u));

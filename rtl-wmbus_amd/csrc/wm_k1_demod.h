@@ -182,7 +182,7 @@ __device__ __forceinline__ void k1_boxcars(const uint32_t *w, int d_rt, wm_s2 s8
  * a + 4, of a magnitude row at a + a/16 (the two chains' rows may alias when they carry the same
  * data).  Ends with the magnitude rows' barrier already passed by every thread. */
 /* FAST (wmbus_cfg.tolerance_mode, never the default): one fused multiply-add per tap instead of the reference's separately
- * rounded product and sum -- the soft symbol then differs from the reference's by rounding noise. */
+ * rounded product and sum -- the soft symbol then differs from the reference's by rounding noise (DESIGN_HISTORY.md section 12). */
 template <bool FAST = false>
 __device__ __forceinline__ void k1_fir_t(const K1Args &a, const float *yDrT, const int slot, const int stream, const int ts, const int tn)
 {
@@ -622,7 +622,7 @@ __global__ __launch_bounds__(NT, GEN ? 1 : RS == 2 ? 4 : 8) void k1_demod2(K1Arg
     /* One tile per block.  (A bounded grid whose blocks walk several tiles made the kernel itself 6 % faster -- fewer block
      * launches, per-thread addresses kept across tiles -- and the whole job 10 % slower: the framer kernels of the other
      * contexts get onto a CU when demodulation blocks retire, and blocks that live twice as long halve their chances; r03
-     * A/B in DESIGN.md section 10.) */
+     * A/B in DESIGN_HISTORY.md section 10; round 5 measured it again with the input prefetched: DESIGN.md section 6.) */
     if (RS == 2) {                                            /* the tiles k3_spans has listed, walked by a fixed grid */
         const uint32_t n = *a.n_relist;
         for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {

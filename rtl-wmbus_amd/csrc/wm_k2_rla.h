@@ -351,7 +351,7 @@ __device__ __forceinline__ void rla_lanes(const K2Args &a, const uint32_t block_
 }
 
 #ifndef WM_RLA_WAVES_PER_SIMD
-#define WM_RLA_WAVES_PER_SIMD 1        /* 8: at most 64 VGPRs (build-time experiment) */
+#define WM_RLA_WAVES_PER_SIMD 1        /* 8: at most 64 VGPRs (build-time experiment, DESIGN_HISTORY.md section 10) */
 #endif
 __global__ __launch_bounds__(64 * WM_RLA_WPB, WM_RLA_WAVES_PER_SIMD) void k2_rla(K2Args a)           /* main pass: one block per 64 * WM_RLA_WPB lanes */
 {

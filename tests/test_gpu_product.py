@@ -283,7 +283,7 @@ def test_tolerance_mode_soft_symbols_do_not_depend_on_the_push_size(wm):
 def test_tolerance_mode_over_the_synthetic_goldens(wm):
     """Tolerance mode on every synthetic golden of the reference binary (tests/golden/synthetic.json; the switch
     combinations that do not run the default switches' kernel simply stay exact): the weak-signal and the all-modes cases
-    are where a decision could hang on the last bits of a soft symbol.  The claim in DESIGN.md section 12 is "no line
+    are where a decision could hang on the last bits of a soft symbol.  The claim in DESIGN_HISTORY.md section 12 is "no line
     differs on these either"; a difference here is a finding about the mode, to be written down, not hidden."""
     from cases import SYNTH_CASES, flags_to_kwargs, synth_case_capture
     synth = json.load(open(os.path.join(GOLDEN, "synthetic.json")))

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Build a variant of the library for an in-box A/B:  tools/build_variant.sh <tag> [-DNAME=VALUE ...]
 # -> rtl-wmbus_amd/libwmbus_hip_<tag>.so (git-ignored; travels to the GPU box with the snapshot).
-# Use with tools/gpu_env.sh:  "WMBUS_HIP_LIB=$PWD/rtl-wmbus_amd/libwmbus_hip_<tag>.so -- --steps 10 --warmup 2"
-# Parked switches: -DWM_FUSED_WAVES_PER_SIMD=4  -DWM_FUSED_LEAN_CLOCK=1
-#                                         -DWM_CLK_WPB=2  -DWM_RLA_WPB=2
+# Use with tools/gpu_visit.sh:  tools/gpu_visit.sh TAG "libwmbus_hip_<tag>.so|" "-|"
+#
+#
 set -e
 tag=$1; shift
 here=$(cd "$(dirname "$0")/.." && pwd)/rtl-wmbus_amd

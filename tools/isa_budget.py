@@ -77,7 +77,7 @@ print("stage A per thread = 4 decimated samples x 2 chains: 8 discriminators (co
       "reduction, 11-term polynomial, quadrant fix-up: 71 instructions each in the exact kernel) + 8 magnitudes (exact square root: 13 each) + the packed-\n"
       "int16 boxcars.  Stage B is listed with all four wave roles; dynamically a wave runs 4 x 92 (exact) or 4 x 46 (FMA) instructions of the 46-tap FIR\n"
       "plus EITHER one chain's RSSI EMA (48 steps x 3 + 16 byte packs) OR half of the 11-tap FIR (2 x 4 x 22).  Measured per wave (SQ_INSTS_VALU /\n"
-      "SQ_WAVES, profiles/valu.json): see DESIGN.md section 8.\n"
+      "SQ_WAVES, profiles/valu.json): see DESIGN.md section 6.\n"
       "RS = 1 (no RSSI): three barriers, so the columns are stage 0, stage A and stage B; stage B holds the 11-tap filter twice (two of the four waves\n"
       "run it before the 46-tap one, two after): a wave executes 4 x 92 + 4 x 22 of it, a thread 85 + 634 + ~470 = ~1 190 in all.\n"
       "RS = 2 (the RSSI of a listed tile): the list loop's own barrier shifts the columns by one; its total is what counts (580 VALU static;\n"

@@ -2,7 +2,7 @@
 """What a lock-step wave pays in the run-length framer: edge trips per 64 samples for the unluckiest of 64 lanes, by step length.
 Runs the device source on the host (tests/emu/rla_emu.cpp, which counts a lane's trips per 64 samples) over 64 captures of the
 bench workload -- the 64 lanes of one wave -- and takes, per step of 64 / 128 / 256 / 512 samples, the largest count among them.
-No GPU.  DESIGN.md section 2.4 quotes the output."""
+No GPU.  DESIGN_HISTORY.md section 4 quotes the output."""
 import ctypes, importlib, os, subprocess, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
