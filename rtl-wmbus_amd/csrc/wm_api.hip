@@ -158,6 +158,7 @@ struct wmbus_ctx {
     uint32_t k1_tpb = 1;                                /* tiles per block of the first pass without the RSSI (cfg.k1_tiles_per_block) */
     uint32_t k1_tail_pm = 60;                           /* per mille of a push's tiles behind the early hand-over of the K1 turn (enqueue_front_impl) */
     uint32_t *d_rs_flags = nullptr, *d_rs_list = nullptr;   /* [ntiles_cap][S] chains read per (tile, capture); the tiles listed */
+    WmItemRec *d_plans = nullptr;                          /* [4 S + hits_cap] what k3_spans leaves k3_bursts about every item */
     uint32_t *d_ckpt = nullptr; uint32_t nck = 0;       /* clock kernel checkpoints [2][S][nseg_cap][nck][16] */
     uint32_t *d_bad = nullptr;                          /* [2][nseg_cap[0]][S] the run-length verifier's verdict per segment (K2Args.bad) */
     uint32_t *d_bad_clk = nullptr;                      /* [2][nseg_cap[1]][S] the clock verifier's */
@@ -215,7 +216,10 @@ enum { WM_MAX_DEVICES = 64 };                    /* per-device tables (K1 order,
  * A small batch is bound by its chain of dependent launches and by every host round trip in it, and its short segments
  * (wmbus_open) cascade further: it enqueues more rounds, so that the host-driven path (0.5 ms per round) stays the exception. */
 enum { WM_MAX_ROUNDS = 6 };
-enum { WM_K3_BLOCKS = 64, WM_RS_BLOCKS = 2048 };
+#ifndef WM_K3_BLOCKS
+#define WM_K3_BLOCKS 64           /* build-time A/B (tools/build_variant.sh): r02 256 -> 64 blocks + 6 %, 16 blocks - 9 % */
+#endif
+enum { WM_RS_BLOCKS = 2048 };
 enum { WM_K1_TPB_DEFAULT = 2 };                /* tiles per block of the demodulation kernel's first pass (RSSI on demand), see enqueue_front_impl */   /* bounded grids of the burst kernels and of the RSSI launch over the listed tiles (launch_k3) */                     /* counters per kind: rounds + 1 <= 8 (SC_* below) */
 enum { SC_ERR = 0, SC_NHITS = 1, SC_NHDR = 2, SC_NWORDS = 3, SC_NPKTS = 4, SC_NBYTES = 5, SC_SLOW = 6, SC_CHIPS = 8 /* [algo][chain] */,
        SC_RS_N = 12 /* tiles listed for the RSSI-on-demand launch */, SC_RS_FAIL = 13 /* a lane that is read could not prove its value */,
@@ -382,7 +386,7 @@ void wmbus_close(wmbus_ctx *c)
         std::lock_guard<std::mutex> lk(kc.m);
         if (kc.owner == c) { kc.last = nullptr; kc.owner = nullptr; }      /* nobody may wait on an event that is about to go */
     }
-    void *dev[] = {c->d_rs_flags, c->d_rs_list, c->d_bad, c->d_bad_clk, c->d_hist, c->d_list_ema, c->d_spill, c->d_chain, c->d_list2, c->d_first_bad, c->d_ckpt, c->d_in, c->d_dphi, c->d_rssi, c->d_bits, c->d_lut, c->d_ema_head, c->d_ema_tail, c->d_ema_carry,
+    void *dev[] = {c->d_plans, c->d_rs_flags, c->d_rs_list, c->d_bad, c->d_bad_clk, c->d_hist, c->d_list_ema, c->d_spill, c->d_chain, c->d_list2, c->d_first_bad, c->d_ckpt, c->d_in, c->d_dphi, c->d_rssi, c->d_bits, c->d_lut, c->d_ema_head, c->d_ema_tail, c->d_ema_carry,
                    c->d_chips[0], c->d_chips[1], c->d_counts[0], c->d_counts[1], c->d_st_start[0], c->d_st_start[1],
                    c->d_st_final[0], c->d_st_final[1], c->d_st_carry[0], c->d_st_carry[1], c->d_list, c->d_scalars,
                    c->d_hits, c->d_pending};
@@ -548,6 +552,7 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
     if (cfg->burst_caps[2]) c->pkts_cap = cfg->burst_caps[2];
     if (cfg->burst_caps[3]) c->bytes_cap = cfg->burst_caps[3];
     A(dalloc(&c->d_hits, (size_t)c->hits_cap));
+    if (c->rs_od) A(dalloc(&c->d_plans, (size_t)4 * c->S + c->hits_cap));
     A(dalloc(&c->d_pending, (size_t)4 * c->S));
     /* the verifiers' verdict per segment, for the chain walk of the re-run lanes (K2Args.bad).  Zeroed on the context's own stream: a
      * synchronous hipMemset runs on the NULL stream, whose hardware queue then takes part in the round-robin of streams onto
@@ -704,7 +709,10 @@ static void fr_launch(wmbus_ctx *c, int algo, uint32_t cnt, hipStream_t st = nul
      * framer resets inside the segment), so that state was right all along -- walking such runs serially made the round twice
      * as long on the bench workload (r04 A/B: 133 against 147 Gsamples/s).  What is STILL listed after that round is a true
      * cascade (a burst longer than a segment): from the second list round on a listed lane walks its chain (rla_lanes). */
-    if (!all && cnt == (algo == WMBUS_ALGO_RLA ? SC_RLA + 1u : (uint32_t)SC_CLK)) a.bad = nullptr;      /* the same for the clock kernel (clock_lanes) */
+    if (!all && algo == WMBUS_ALGO_RLA && cnt == SC_RLA + 1u) a.bad = nullptr;
+    /* the clock kernel's first list round: parallel too, but a lane whose end state came out new carries it into an UNLISTED
+     * successor (K2Args.walk_unlisted): the cascade of the second round, settled in the first */
+    if (!all && algo == WMBUS_ALGO_T2A && cnt == (uint32_t)SC_CLK) { if (c->cfg.k2_plain_rounds) a.bad = nullptr; else a.walk_unlisted = 1u; }
     /* list launches: blocks for 3/16 of the lanes (a re-run list is a few percent of them; the blocks walk whatever is more) */
     const uint32_t B = 64 * (algo == WMBUS_ALGO_RLA ? WM_RLA_WPB : WM_CLK_WPB), grid = all ? (lanes + B - 1) / B : std::max(16u, (lanes / B) * 3u / 16u);
     if (algo == WMBUS_ALGO_RLA) {
@@ -757,7 +765,9 @@ static int launch_k3(wmbus_ctx *c, bool again)
         k3.pkts = (WmPkt *)c->dv_pkts; k3.pkts_cap = c->pkts_cap; k3.bytes = (uint8_t *)c->dv_bytes; k3.bytes_cap = c->bytes_cap;
         k3.n_pkts = c->d_scalars + SC_NPKTS; k3.n_bytes = c->d_scalars + SC_NBYTES;
     }
+    k3.plans = nullptr;
     if (c->rs_this && !c->rs_full_now) {
+        k3.plans = c->d_plans;
         /* RSSI on demand: which tiles do the bursts touch (k3_spans), then their RSSI (an RS = 2 launch of the demodulation
          * kernel over the list, a fixed grid), then the bursts */
         HIPCHK(c, hipMemsetAsync(c->d_rs_flags, 0, (size_t)c->ntiles * c->S * sizeof(uint32_t), c->stream));

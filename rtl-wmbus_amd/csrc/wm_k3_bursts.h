@@ -20,6 +20,8 @@ struct K3Args {
     uint8_t *bytes; uint32_t bytes_cap;
     uint32_t *n_pkts, *n_bytes;
     uint32_t *err;
+    struct WmItemRec *plans;     /* [4 S + hits_cap] what k3_spans has found out about every item (RSSI on demand: it runs before k3_bursts
+                                    and needs the same facts); nullptr: k3_bursts finds out itself */
 };
 
 __device__ static const uint8_t D3OF6[64] = {
@@ -40,6 +42,10 @@ struct WmPlan {
     uint16_t L;              /* expected length with CRC bytes (the decoder's L) */
     uint16_t nbytes;         /* bytes the decoder stores, L-field included */
 };
+
+/* An item as k3_spans leaves it for k3_bursts: where its chips start in the push's chip stream, how many are left, how many a
+ * decoder takes (0: nothing to do -- an empty continuation slot, a stale hit) and the plan. */
+struct WmItemRec { uint32_t chip0, avail, n; WmPlan plan; };
 
 __device__ WmPlan burst_plan(uint32_t chain, uint32_t hb, uint32_t nb)
 {
@@ -194,13 +200,13 @@ __device__ __forceinline__ void k3_locate(const K3Item &it, uint32_t j, uint32_t
     sg = it.seg; kk = it.k + j;
     while (sg < it.nseg) { const uint32_t c = it.cnt[sg]; if (kk < c) break; kk -= c; sg++; }
 }
-/* false: nothing to do for this item (an empty continuation slot, a stale hit of a re-run segment).  By one wave. */
-__device__ __forceinline__ bool k3_item(const K3Args &a, const uint32_t item, const uint32_t ln, K3Item &it)
+/* Who the item is: framer, chain, capture, the segment and index of its first chip.  false: an empty continuation slot or an
+ * index beyond the hits.  `want` = chips a continuation still owes. */
+__device__ __forceinline__ bool k3_item_id(const K3Args &a, const uint32_t item, K3Item &it, uint32_t &want)
 {
     const WmPush &g = a.g;
     const uint32_t n_hits = min(*a.n_hits, a.hits_cap);
-    uint32_t want;
-    it.cont = 0;
+    it.cont = 0; want = 0;
     if (item < 4u * g.S) {                       /* continuation slots come first            */
         it.algo = item / (2u * g.S); it.ch = (item / g.S) & 1u; it.stream = item % g.S;
         want = a.pending[item];
@@ -211,12 +217,19 @@ __device__ __forceinline__ bool k3_item(const K3Args &a, const uint32_t item, co
         const uint2 h = a.hits[item - 4u * g.S];
         it.algo = h.x >> 31;
         lane_decode(g, it.algo, h.x & 0x7FFFFFFFu, it.ch, it.stream, it.seg);
-        it.k = h.y; want = 0;
+        it.k = h.y;
     }
     it.nseg = g.nseg[it.algo]; it.seg_len = g.seg_len[it.algo];
     it.row = (uint64_t)it.ch * g.S + it.stream;
     it.cnt = a.counts[it.algo] + it.row * g.nseg_cap[it.algo];
     it.sidx0 = it.row * g.nseg_cap[it.algo];
+    return true;
+}
+/* false: nothing to do for this item (an empty continuation slot, a stale hit of a re-run segment).  By one wave. */
+__device__ __forceinline__ bool k3_item(const K3Args &a, const uint32_t item, const uint32_t ln, K3Item &it)
+{
+    uint32_t want;
+    if (!k3_item_id(a, item, it, want)) return false;
     if (!it.cont) {                              /* stale record of a re-run segment?         */
         if (it.k >= it.cnt[it.seg] || !(k3_chip(a, it, it.seg, it.k) & 2u)) return false;
     }
@@ -242,12 +255,21 @@ __device__ __forceinline__ bool k3_item(const K3Args &a, const uint32_t item, co
     }
     return true;
 }
+/* the same from the record k3_spans has left (K3Args.plans) */
+__device__ __forceinline__ bool k3_item_recorded(const K3Args &a, const uint32_t item, K3Item &it)
+{
+    const WmItemRec r = a.plans[item];
+    uint32_t want;
+    if (r.n == 0u || !k3_item_id(a, item, it, want)) return false;
+    it.chip0 = r.chip0; it.avail = r.avail; it.n = r.n; it.plan = r.plan;
+    return true;
+}
 
 __device__ void burst_item(const K3Args &a, const uint32_t item, const uint32_t ln, unsigned long long *s_bits, uint8_t *s_bytes)
 {
     const WmPush &g = a.g;
     K3Item it;
-    if (!k3_item(a, item, ln, it)) return;
+    if (!(a.plans ? k3_item_recorded(a, item, it) : k3_item(a, item, ln, it))) return;
     const uint32_t algo = it.algo, ch = it.ch, stream = it.stream, cont = it.cont, seg_len = it.seg_len, chip0 = it.chip0, avail = it.avail, n = it.n;
     const uint64_t row = it.row;
     const WmPlan plan = it.plan;
@@ -409,7 +431,9 @@ __global__ __launch_bounds__(256) void k3_spans(K3Args a, uint32_t tile_len, uin
     const uint32_t n_items = 4u * g.S + min(*a.n_hits, a.hits_cap);
     for (uint32_t item = blockIdx.x * 4u + wv; item < n_items; item += gridDim.x * 4u) {
         K3Item it;
-        if (!k3_item(a, item, ln, it)) continue;
+        const bool todo = k3_item(a, item, ln, it);
+        if (a.plans && ln == 0) a.plans[item] = todo ? WmItemRec{it.chip0, it.avail, it.n, it.plan} : WmItemRec{};
+        if (!todo) continue;
         uint32_t pm = 0;
         if (ln < 2u) { uint32_t sg, kk; k3_locate(it, ln ? it.n - 1u : 0u, sg, kk); pm = sg * it.seg_len + WM_CHIP_POS(k3_chip(a, it, sg, kk)); }
         const uint32_t t0 = __shfl(pm, 0) / tile_len, t1 = min(__shfl(pm, 1) / tile_len, ntiles - 1u);

@@ -88,6 +88,9 @@ long wm_emu_k3(const uint64_t *geo, const uint32_t *chips0, const uint32_t *chip
         const uint32_t T = WM_K1_TILE2, nt = emu_span_tiles;
         std::vector<uint32_t> list(nt);
         uint32_t n_list = 0;
+        static std::vector<WmItemRec> plans;                 /* k3_spans leaves its findings for k3_bursts, as in the product */
+        plans.assign((size_t)4 * g.S + hdr_cap, WmItemRec{0xDEADu, 0xDEADu, 0xDEADu, WmPlan{}});
+        k3.plans = plans.data();
         std::fill(emu_span_flags, emu_span_flags + nt, 0u);
         for (uint32_t b = 0; b < gridDim.x; b++) {
             blockIdx = {b, 0, 0};

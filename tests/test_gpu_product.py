@@ -334,6 +334,8 @@ def test_exhausted_burst_storage_is_a_warning_and_never_hands_out_garbage(wm, or
     decoder, and the push succeeds with WMBUS_WARN_BURSTS_DROPPED: every line that still comes out is one of the oracle's
     (same text), none is invented, the stream goes on, and with the pressure gone (second receiver, default storage) the
     same bytes decode completely."""
+    if os.environ.get("WMBUS_TEST_BURSTS_TO_HOST") == "1" and caps.split(":")[1] == "1048576":
+        pytest.skip("every burst travels as chips in this campaign: packet / byte storage cannot run out")
     cu8 = wm.synth_capture(seed=4242, n_samples=1 << 20, kinds=15, frames_per_s=150.0)[0]
     want = oracle.run(cu8, flags_to_oracle_opts(oracle, ["-v"]))["text"].splitlines()
     code = (
