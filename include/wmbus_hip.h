@@ -103,7 +103,6 @@ typedef struct wmbus_cfg {
                                    WMBUS_WARN_BURSTS_DROPPED paths */
     unsigned k1_small_tile;     /* 1: the first pass of the demodulation kernel on 976-sample tiles even where the 2000-sample tile of
                                    512 threads is available (decimation 2, no -s, RSSI on demand); A/B */
-    unsigned k2_plain_rounds;   /* 1: the clock kernel's first re-run round as in round 4 (no lane goes on into an unlisted successor); A/B */
     unsigned k1_tiles_per_block;/* consecutive tiles a block of that first pass takes, each tile's input loaded while the one before
                                    is computed (0: the default; 1: one tile per block, no prefetch) */
 } wmbus_cfg;

@@ -709,10 +709,9 @@ static void fr_launch(wmbus_ctx *c, int algo, uint32_t cnt, hipStream_t st = nul
      * framer resets inside the segment), so that state was right all along -- walking such runs serially made the round twice
      * as long on the bench workload (r04 A/B: 133 against 147 Gsamples/s).  What is STILL listed after that round is a true
      * cascade (a burst longer than a segment): from the second list round on a listed lane walks its chain (rla_lanes). */
-    if (!all && algo == WMBUS_ALGO_RLA && cnt == SC_RLA + 1u) a.bad = nullptr;
-    /* the clock kernel's first list round: parallel too, but a lane whose end state came out new carries it into an UNLISTED
-     * successor (K2Args.walk_unlisted): the cascade of the second round, settled in the first */
-    if (!all && algo == WMBUS_ALGO_T2A && cnt == (uint32_t)SC_CLK) { if (c->cfg.k2_plain_rounds) a.bad = nullptr; else a.walk_unlisted = 1u; }
+    if (!all && cnt == (algo == WMBUS_ALGO_RLA ? SC_RLA + 1u : (uint32_t)SC_CLK)) a.bad = nullptr;      /* the same for the clock kernel (clock_lanes) */
+    /* (Round 5 tried a middle way for the clock kernel's first round: parallel, but a lane whose end state came out new carries it
+     * on into an UNLISTED successor.  The second round shrank from 7 to 4 lanes and the job lost 1.8 %: 170.0 against 173.1.) */
     /* list launches: blocks for 3/16 of the lanes (a re-run list is a few percent of them; the blocks walk whatever is more) */
     const uint32_t B = 64 * (algo == WMBUS_ALGO_RLA ? WM_RLA_WPB : WM_CLK_WPB), grid = all ? (lanes + B - 1) / B : std::max(16u, (lanes / B) * 3u / 16u);
     if (algo == WMBUS_ALGO_RLA) {

@@ -517,15 +517,13 @@ __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t bloc
     const uint64_t row = (uint64_t)ch * g.S + stream;
     const uint32_t *bad = a.bad + (uint64_t)ch * g.nseg_cap[1] * g.S + stream;       /* verdict of segment j at bad[j * S] */
     const WmClkState *stS = (const WmClkState *)a.st_start, *stF = (const WmClkState *)a.st_final;
-    if (!a.walk_unlisted && seg > 0u && bad[(uint64_t)(seg - 1u) * g.S]) return;            /* the head of my run covers me (first list round: everybody runs) */
+    if (seg > 0u && bad[(uint64_t)(seg - 1u) * g.S]) return;            /* the head of my run covers me */
     bool have_from = false;
     for (;;) {
         const int how = clock_segment<DC, W, LEAN, PASS>(a, lds, wv, ln, true, ch, stream, seg, have_from, from, fin);
         const uint64_t sidx = row * g.nseg_cap[1] + seg;
-        if (a.walk_unlisted && how != 0) return;            /* first list round: only a NEW end state is carried on */
         if (how == 1) fin = stF[sidx];                     /* left at a checkpoint: the recorded end state was exact */
         if (how == 2 || seg + 1u >= g.nseg[1]) return;
-        if (a.walk_unlisted && bad[(uint64_t)(seg + 1u) * g.S]) return;   /* the segment behind is listed: it has a lane of its own in this launch */
         const WmClkState next = stS[sidx + 1u];
         if (clk_state_same(fin, next)) return;             /* the next segment started from exactly this state */
         if (bad[(uint64_t)(seg + 1u) * g.S] && !bad[(uint64_t)seg * g.S]) return;      /* it is listed and has a lane of its own in this launch: next round */

@@ -30,11 +30,6 @@ struct K2Args {
     /* [2][nseg_cap][S]: k2_verify's verdict per segment (1: its start did not match its predecessor's end), for the chain
      * walk of the framer kernels' re-run lanes (clock_lanes, rla_lanes); nullptr: every listed segment on its own, as in round 3 */
     const uint32_t *bad;
-    /* clock kernel, FIRST list round (round 5): every listed segment is re-run on its own, in parallel, as before -- but a lane
-     * that ran to its segment's end (no checkpoint reproduced: its end state is new) goes on into the segment behind it when that
-     * one is NOT listed, for as long as the state it arrives with differs from the recorded start.  That is the cascade the
-     * second round used to exist for (1 366 lanes, then 7); a listed neighbour still has a lane of its own and is left alone. */
-    uint32_t walk_unlisted;
 };
 
 /* Issue priority of the latency-bound kernels behind K1 (framers, verifiers, burst kernels): a clock wave that shares its

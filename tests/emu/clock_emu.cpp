@@ -46,7 +46,6 @@ int wm_emu_descending = 1;
 int wm_emu_s1_span = 0;                   /* WmPush.s1_span of the next calls */
 uint32_t *wm_emu_seen_out = nullptr;      /* optional: receives the per-region "access-code chip seen" flags */
 int wm_emu_lean_reruns = 0;
-int wm_emu_walk_unlisted = 1;           /* K2Args.walk_unlisted in the first list round (round 5); 0: round 4's plain first round */
 int wm_emu_chains = 1;                    /* K2Args.bad: a listed lane walks its chain (round 4); 0: every listed segment on its own */
 
 /* One push of M decimated samples for S captures.  dphi: [2][S][Mcap] soft symbols; carry: [2][S]
@@ -113,11 +112,7 @@ long wm_emu_clock(const float *dphi, uint32_t S, uint32_t M, uint32_t Mcap, uint
         if (list.empty()) break;
         if (round > nseg + 1) return -1;
         reruns += (long)list.size();
-        /* the first list round re-runs every listed segment on its own and lets a new end state walk on into unlisted successors;
-         * later rounds walk chains (wm_api.hip fr_launch).  wm_emu_chains = 0: lone segments in every round (round 3) */
-        a.bad = wm_emu_chains ? bad.data() : nullptr;
-        a.walk_unlisted = (wm_emu_chains && round == 0 && wm_emu_walk_unlisted) ? 1u : 0u;
-        if (wm_emu_chains && round == 0 && !wm_emu_walk_unlisted) a.bad = nullptr;
+        a.bad = (wm_emu_chains && round >= 1) ? bad.data() : nullptr;   /* the first list round re-runs lone segments (wm_api.hip fr_launch) */
         launch(list.data(), (uint32_t)list.size());
     }
     WmClkState *c = (WmClkState *)carry;                                 /* k_carry */

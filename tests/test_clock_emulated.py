@@ -31,13 +31,12 @@ def emu():
     return L
 
 
-def run_emulated(emu, soft_rows, pushes, seg_len, warm, dc=False, descending=True, lean_reruns=False, s1_span=None, chains=True, walk_unlisted=True):
+def run_emulated(emu, soft_rows, pushes, seg_len, warm, dc=False, descending=True, lean_reruns=False, s1_span=None, chains=True):
     """soft_rows: [2][M] float32 FIR outputs of one capture; pushes: decimated samples per push."""
     ctypes.c_int.in_dll(emu, "wm_emu_descending").value = int(descending)   # see clock_emu.cpp: launch semantics
     ctypes.c_int.in_dll(emu, "wm_emu_lean_reruns").value = int(lean_reruns)  # per-sample block in re-run launches (WM_FUSED_LEAN_CLOCK)
     ctypes.c_int.in_dll(emu, "wm_emu_s1_span").value = int(s1_span or 0)     # WmPush.s1_span: S1 lanes cover two segments
     ctypes.c_int.in_dll(emu, "wm_emu_chains").value = int(chains)            # a listed lane walks its chain of listed segments (K2Args.bad)
-    ctypes.c_int.in_dll(emu, "wm_emu_walk_unlisted").value = int(walk_unlisted)   # first list round: a new end state walks on into unlisted successors (round 5)
     sb = emu.wm_emu_clock_state_bytes()
     carry = np.zeros(2 * sb, np.uint8)                     # a fresh context starts from the all-zero state
     chips_out, bits_out, m0, reruns, max_rounds = [[], []], [[], []], 0, 0, 0
@@ -89,7 +88,7 @@ def test_device_source_on_host_matches_oracle_bundled_capture(emu, oracle, sampl
 
 def test_device_source_on_host_matches_oracle_randomised(emu, oracle, wm):
     rng = np.random.default_rng(9 + int(os.environ.get("WMBUS_EMU_SEED", "0")))
-    multi, total_rounds, walked = {}, {}, 0
+    multi, walked = {False: 0, True: 0}, 0
     for k in range(int(os.environ.get("WMBUS_EMU_N", "8"))):               # more for a bug hunt
         cu8 = wm.synth_capture(seed=int(rng.integers(1, 1 << 30)), n_samples=1 << 18, kinds=int(rng.choice([15, 15, 8, 7])), frames_per_s=120.0,
                                amplitude=float(rng.choice([8.0, 25.0, 60.0])), noise_sigma=float(rng.choice([0.5, 3.0, 3.0, 10.0])))[0]
@@ -107,18 +106,16 @@ def test_device_source_on_host_matches_oracle_randomised(emu, oracle, wm):
         if os.environ.get("WMBUS_EMU_STRESS"):               # bug hunts: many checkpoints per segment, hopeless warm-ups
             seg_len = int(rng.choice([4096, 8192, 16384]))
             warm = (int(rng.choice([32, 64, 256])), int(rng.choice([32, 64, 256])))
-        for chains, walk in ((False, False), (True, False), (True, True)):   # round 3's rounds of lone segments; round 4's chain walk; round 5: + the first round walks on into unlisted successors
+        for chains in (False, True):                          # round 3's rounds of lone segments; round 4's chain walk
             chips, bits, reruns, rounds = run_emulated(emu, ref["dphi_fir"], pushes, seg_len, warm, dc=dc, descending=bool(k % 5), lean_reruns=bool(k % 2),
-                                                       s1_span=1 + (k // 2) % 2, chains=chains, walk_unlisted=walk)
-            multi[(chains, walk)] = multi.get((chains, walk), 0) + (rounds > 1)
-            total_rounds[(chains, walk)] = total_rounds.get((chains, walk), 0) + rounds
+                                                       s1_span=1 + (k // 2) % 2, chains=chains)
+            multi[chains] += rounds > 1
             walked += chains and reruns > 0
             for ch in (0, 1):
-                assert np.array_equal(bits[ch], ref["bit"][ch]), (k, "bits", ch, chains, walk)
-                assert np.array_equal(chips[ch], oracle_t2a_chips(ref, ch)), (k, "chips", ch, seg_len, warm, chains, walk)
-    assert multi[(False, False)] > 0                           # cascading re-run rounds (where the checkpoint bug lived) occurred
-    assert walked > 0 and multi[(True, False)] <= multi[(False, False)]     # the chain walk ran, and never needs more rounds than lone segments do
-    assert total_rounds[(True, True)] <= total_rounds[(True, False)]        # ... and carrying a new end state on in the first round never needs more
+                assert np.array_equal(bits[ch], ref["bit"][ch]), (k, "bits", ch, chains)
+                assert np.array_equal(chips[ch], oracle_t2a_chips(ref, ch)), (k, "chips", ch, seg_len, warm, chains)
+    assert multi[False] > 0                                    # cascading re-run rounds (where the checkpoint bug lived) occurred
+    assert walked > 0 and multi[True] <= multi[False]          # the chain walk ran, and never needs more rounds than lone segments do
 
 
 def test_cooperative_first_pass_of_a_whole_wave_on_the_block_emulator(emu, oracle, wm):
