@@ -177,6 +177,19 @@ __device__ __forceinline__ void k1_boxcars(const uint32_t *w, int d_rt, wm_s2 s8
     }
 }
 
+/* A 16-byte LDS read that stays ONE ds_read_b128: where a window's first or last vector is only partly used the compiler
+ * narrows the load to the used words and then re-pairs the scalars from the odd start -- the 46-tap window arrived as 24
+ * ds_read2_b32, each with its own address add (round 5, read off the ISA).  The empty asm makes all four words "used". */
+typedef float wm_k1v4 __attribute__((vector_size(16)));
+__device__ __forceinline__ wm_k1v4 k1_lds_v4(const float *p)
+{
+    wm_k1v4 v = *(const wm_k1v4 *)p;
+#ifdef __HIP_DEVICE_COMPILE__
+    asm("" : "+v"(v));
+#endif
+    return v;
+}
+
 /* Stages B1 (FIR) and B2 (RSSI EMA + hand-off certification) of a 976-sample tile; shared by the
  * moving-average and the polyphase front ends.  Rows: element a of a discriminator row at word
  * a + 4, of a magnitude row at a + a/16 (the two chains' rows may alias when they carry the same
@@ -192,8 +205,8 @@ __device__ __forceinline__ void k1_fir_t(const K1Args &a, const float *yDrT, con
     float w[16];                                              /* w[i] = element 4 slot + 36 + i */
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const float4 v = *(const float4 *)(yDrT + 4 * slot + 40 + 4 * k);
-        w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+        const wm_k1v4 v = k1_lds_v4(yDrT + 4 * slot + 40 + 4 * k);
+        w[4 * k] = v[0]; w[4 * k + 1] = v[1]; w[4 * k + 2] = v[2]; w[4 * k + 3] = v[3];
     }
     float acc[4];
 #pragma unroll
@@ -214,37 +227,37 @@ __device__ __forceinline__ void k1_fir_s(const K1Args &a, const float *yDrS, con
     if (m0l >= tn) return;
     /* y[n] = sum_k b[k] x[n - k], k ascending (fir.h:58-67), for the four outputs n = 4 slot + j; element i of the thread's
      * 52-sample window is x[4 slot - 48 + i], so tap k of output j reads element 48 + j - k.  The window passes through the
-     * registers in TWO halves, newest first: taps 0 .. 21 read elements 27 .. 51 (seven vectors), taps 22 .. 45 elements
-     * 3 .. 29 (eight vectors) -- 32 registers at a time instead of 52.  (Round 5: the registers are what a block's NEXT tile
+     * registers in TWO halves, newest first: taps 0 .. 23 read elements 25 .. 51, taps 24 .. 45 elements 3 .. 27 (seven
+     * vectors each) -- 28 registers at a time instead of 52.  (Round 5: the registers are what a block's NEXT tile
      * needs for its input words, which are in flight during this stage; with the whole window resident the kernel spilled.) */
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     {
         float w[28];                                          /* w[i] = element 24 + i */
 #pragma unroll
         for (int k = 6; k >= 0; k--) {
-            const float4 v = *(const float4 *)(yDrS + 4 * slot + 4 + 24 + 4 * k);
-            w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+            const wm_k1v4 v = k1_lds_v4(yDrS + 4 * slot + 4 + 24 + 4 * k);
+            w[4 * k] = v[0]; w[4 * k + 1] = v[1]; w[4 * k + 2] = v[2]; w[4 * k + 3] = v[3];
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             float s_ = acc[j];
 #pragma unroll
-            for (int k = 0; k < 22; k++) s_ = FAST ? __builtin_fmaf(FIR_S[k], w[24 + j - k], s_) : wm_add(s_, wm_mul(FIR_S[k], w[24 + j - k]));
+            for (int k = 0; k < 24; k++) s_ = FAST ? __builtin_fmaf(FIR_S[k], w[24 + j - k], s_) : wm_add(s_, wm_mul(FIR_S[k], w[24 + j - k]));
             acc[j] = s_;
         }
     }
     {
-        float w[32];                                          /* w[i] = element i */
+        float w[28];                                          /* w[i] = element i */
 #pragma unroll
-        for (int k = 7; k >= 0; k--) {
-            const float4 v = *(const float4 *)(yDrS + 4 * slot + 4 + 4 * k);
-            w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+        for (int k = 6; k >= 0; k--) {
+            const wm_k1v4 v = k1_lds_v4(yDrS + 4 * slot + 4 + 4 * k);
+            w[4 * k] = v[0]; w[4 * k + 1] = v[1]; w[4 * k + 2] = v[2]; w[4 * k + 3] = v[3];
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             float s_ = acc[j];
 #pragma unroll
-            for (int k = 22; k < 46; k++) s_ = FAST ? __builtin_fmaf(FIR_S[k], w[48 + j - k], s_) : wm_add(s_, wm_mul(FIR_S[k], w[48 + j - k]));
+            for (int k = 24; k < 46; k++) s_ = FAST ? __builtin_fmaf(FIR_S[k], w[48 + j - k], s_) : wm_add(s_, wm_mul(FIR_S[k], w[48 + j - k]));
             acc[j] = s_;
         }
     }
@@ -484,7 +497,13 @@ __device__ __forceinline__ void k1_tile(const K1Args &a, const int tile, const i
          * input loads and waited for with them (round 4 computed it in place: six dependent global loads in the first
          * wave of every block before its input loads went out) */
         uint32_t tabw = 0u;
-        if (RS != 2 && ps == 0 && first && tid < WM_ATAN_TAB_WORDS) tabw = WM_ATAN_TAB_BITS[tid];
+        if (RS != 2 && ps == 0 && first && tid < WM_ATAN_TAB_WORDS) {
+            int k = tid;
+#ifdef __HIP_DEVICE_COMPILE__
+            asm volatile("" : "+v"(k));                       /* the address is made HERE: hoisted in front of the tile loop it was a register pair spilled */
+#endif
+            tabw = WM_ATAN_TAB_BITS[k];
+        }
 #pragma unroll
         for (int it = 0; it < NP; it++) {
             const int u = tid + NT * (it + ps);
