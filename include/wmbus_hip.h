@@ -214,6 +214,11 @@ long wmbus_read_chips(wmbus_ctx *ctx, int chain, int algo, unsigned stream,
 int  wmbus_selftest_math(int device, const float *a, const float *b, float *o_sqrt, float *o_div,
                          float *o_atan2, float *o_disc, size_t n);
 
+/* Device self-test of the demodulation kernel's two low-pass filters (fir.h:48-72 with the coefficients of
+ * rtl_wmbus.c:369-391, lp_fir_butter_800kHz_100kHz_160kHz / _32kHz_36kHz) on one row: x[0 .. n + 48) holds 48 samples of history followed by the n inputs
+ * (n a multiple of 4, at most 976: one tile of the kernel); out[0 .. n) receives the 11-tap filter's outputs, out[n .. 2n) the 46-tap one's. */
+int  wmbus_selftest_fir(int device, const float *x, float *out, size_t n);
+
 /* Number of visible HIP devices (0 if none). */
 int  wmbus_device_count(void);
 

@@ -17,6 +17,9 @@
  *                       both chains.
  *   atan <1|2>          stdin = float pairs (imaginary, real); stdout = the reference's atan2_approximation /
  *                       atan2_approximation2 (atan2.h:14-74) of each pair, as raw floats
+ *   fir <0|1>           stdin = raw floats; stdout = the reference's own low-pass (0: lp_fir_butter_800kHz_100kHz_160kHz,
+ *                       1: lp_fir_butter_800kHz_32kHz_36kHz, rtl_wmbus.c:369-391 over fir.h:48-72) of the sequence, from a
+ *                       zeroed history, as raw floats -- for operands no capture produces (signed zeros, subnormals)
  *   chips <chain> <algo-tag>   stdin = (chip value, rssi) byte pairs -> reference packet decoder;
  *                       datagram lines appear on stdout exactly as the reference prints them.
  */
@@ -126,13 +129,24 @@ static int mode_atan(int which)
     return 0;
 }
 
+static int mode_fir(int which)
+{
+    float x;
+    while (fread(&x, sizeof x, 1, stdin) == 1) {
+        const float y = which == 0 ? lp_fir_butter_800kHz_100kHz_160kHz(x) : lp_fir_butter_800kHz_32kHz_36kHz(x);
+        fwrite(&y, sizeof y, 1, stdout);
+    }
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc >= 3 && !strcmp(argv[1], "fir")) return mode_fir(atoi(argv[2]));
     if (argc >= 3 && !strcmp(argv[1], "atan")) return mode_atan(atoi(argv[2]));
     if (argc >= 2 && !strcmp(argv[1], "tables")) return mode_tables();
     if (argc >= 3 && !strcmp(argv[1], "stages"))
         return mode_stages(argv[2], argc >= 4 && strchr(argv[3], 'a') != NULL, argc >= 4 && strchr(argv[3], 'p') != NULL);
     if (argc >= 4 && !strcmp(argv[1], "chips")) { opts_show_used_algorithm = 1; return mode_chips(atoi(argv[2]), argv[3]); }
-    fprintf(stderr, "usage: ref_probe tables | stages <prefix> [a][p] | atan <1|2> | chips <chain> <tag>\n");
+    fprintf(stderr, "usage: ref_probe tables | stages <prefix> [a][p] | atan <1|2> | fir <0|1> | chips <chain> <tag>\n");
     return 2;
 }

@@ -779,3 +779,14 @@ void wmo_free_text(char *t) { free(t); }
 void wmo_libm_atan2f(const float *y, const float *x, float *out, size_t n) { for (size_t i = 0; i < n; i++) out[i] = atan2f(y[i], x[i]); }
 void wmo_ieee_div(const float *a, const float *b, float *out, size_t n) { for (size_t i = 0; i < n; i++) out[i] = a[i] / b[i]; }
 void wmo_ieee_sqrt(const float *a, float *out, size_t n) { for (size_t i = 0; i < n; i++) out[i] = sqrtf(a[i]); }
+
+/* The two low-pass filters alone (rtl_wmbus.c:369-391 over fir.h:48-72), from a zeroed history: which = 0 the 11-tap filter
+ * of the T1/C1 chain, 1 the 46-tap one of the S1 chain.  For tests with operands no capture produces (signed zeros). */
+void wmo_fir(int which, const float *x, float *y, size_t n)
+{
+    chain_state c;
+    memset(&c, 0, sizeof c);
+    c.fir_b = which ? FIR_S1 : FIR_T1C1;
+    c.fir_len = which ? 46 : 11;
+    for (size_t i = 0; i < n; i++) y[i] = fir_step(&c, x[i]);
+}

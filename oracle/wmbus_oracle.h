@@ -48,6 +48,9 @@ typedef struct wmo_opts {
 /* The two approximations of atan2.h on arrays (for pinning against the reference's own functions). */
 void wmo_atan2_approx(int which, const float *im, const float *re, float *out, size_t n);
 
+/* the low-pass filters alone, from a zeroed history (which: 0 = 11 taps, T1/C1; 1 = 46 taps, S1) */
+void wmo_fir(int which, const float *x, float *y, size_t n);
+
 void wmo_default_opts(wmo_opts *o);
 
 enum { WMO_CHAIN_T1C1 = 0, WMO_CHAIN_S1 = 1 };

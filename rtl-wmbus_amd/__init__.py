@@ -95,7 +95,7 @@ EXPORTS = ["wmbus_batch_plan", "wmbus_batch_open", "wmbus_batch_close", "wmbus_b
            "wmbus_batch_device_input", "wmbus_batch_run",
            "wmbus_runtime_init", "wmbus_default_cfg", "wmbus_open", "wmbus_close", "wmbus_last_error", "wmbus_stage", "wmbus_device_input",
            "wmbus_process", "wmbus_collect", "wmbus_lines", "wmbus_lines_text", "wmbus_get_timing", "wmbus_read_tap",
-           "wmbus_read_chips", "wmbus_device_count", "wmbus_selftest_math", "wmbus_alloc_pinned", "wmbus_free_pinned"]
+           "wmbus_read_chips", "wmbus_device_count", "wmbus_selftest_math", "wmbus_selftest_fir", "wmbus_alloc_pinned", "wmbus_free_pinned"]
 
 _lib = None
 
@@ -126,6 +126,7 @@ def lib():
         L.wmbus_alloc_pinned.argtypes = [sz]; L.wmbus_alloc_pinned.restype = vp
         L.wmbus_free_pinned.argtypes = [vp]
         L.wmbus_selftest_math.argtypes = [ctypes.c_int] + [vp] * 6 + [sz]
+        L.wmbus_selftest_fir.argtypes = [ctypes.c_int, vp, vp, sz]
         L.wmbus_batch_open.argtypes = [ctypes.POINTER(Cfg), u, ctypes.POINTER(vp)]
         L.wmbus_batch_plan.argtypes = [ctypes.POINTER(Cfg), u, ctypes.POINTER(u), u]; L.wmbus_batch_plan.restype = u
         L.wmbus_batch_close.argtypes = [vp]
@@ -165,6 +166,18 @@ def selftest_math(a, b, device=0):
     if rc:
         raise WmbusError(f"selftest_math failed: {rc}")
     return dict(sqrt=outs[0], div=outs[1], atan2=outs[2], disc=outs[3])
+
+
+def selftest_fir(x, device=0):
+    """The demodulation kernel's 11-tap and 46-tap low-pass filters on the device: x = 48 samples of history + n inputs
+    (n a multiple of 4, <= 976); returns (y11[n], y46[n])."""
+    x = np.ascontiguousarray(x, np.float32)
+    n = x.size - 48
+    out = np.empty(2 * n, np.float32)
+    rc = lib().wmbus_selftest_fir(device, x.ctypes.data, out.ctypes.data, n)
+    if rc:
+        raise WmbusError(f"selftest_fir failed: {rc}")
+    return out[:n], out[n:]
 
 
 def _make_cfg(n_streams=1, max_push_bytes=4 << 20, decimation=2, simultaneous=False, accurate_atan=True,

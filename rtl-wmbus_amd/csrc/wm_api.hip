@@ -326,6 +326,21 @@ __global__ void k_selftest(const float *a, const float *b, float *o_sqrt, float 
     o_disc[i] = wm_discriminator_tab(a[i], b[i], b[(i + 1) % n], a[(i + 1) % n], tab);
 }
 
+/* The demodulation kernel's two low-pass filters (k1_fir_t / k1_fir_s, the very functions its stage B inlines) over one row of
+ * arbitrary floats: x[0 .. n + 48) with the 48 samples of history in front, n a multiple of 4 up to 976 (one tile of the kernel); out[0 .. n) the 11-tap
+ * filter, out[n .. 2n) the 46-tap one.  For the operands a capture cannot easily produce: signed zeros above all (a soft symbol
+ * must never be -0, the clock kernel takes the slicer's bit from its sign). */
+__global__ void __launch_bounds__(256) k_selftest_fir(const float *x, float *out, uint32_t n)
+{
+    __shared__ __attribute__((aligned(16))) float row[K1Geo::YD];
+    for (uint32_t w = threadIdx.x; w < (uint32_t)K1Geo::YD; w += blockDim.x) row[w] = w >= 4u && w - 4u < n + 48u ? x[w - 4u] : 0.0f;
+    __syncthreads();
+    K1Args a{};
+    a.g.S = 1; a.g.Mcap = n; a.dphi = out;
+    k1_fir_t<false>(a, row, (int)threadIdx.x, 0, 0, (int)n);
+    k1_fir_s<false>(a, row, (int)threadIdx.x, 0, 0, (int)n);
+}
+
 /* The demodulation kernels of one device's contexts run ONE AFTER THE OTHER (each fills the GPU on its own -- VALU
  * bound -- so two of them side by side only time-slice, while one of them beside the other contexts' latency- and
  * memory-bound framer kernels is complementary).  The order is kept on the GPU: a context's K1 waits for the event
@@ -1384,6 +1399,24 @@ int wmbus_selftest_math(int device, const float *a, const float *b, float *o_sqr
     int rc = hipDeviceSynchronize() == hipSuccess ? WMBUS_OK : WMBUS_EDEVICE;
     for (int k = 0; k < 4; k++) if (hipMemcpy(outs[k], d[2 + k], n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) rc = WMBUS_EDEVICE;
     for (auto &p : d) hipFree(p);
+    return rc;
+}
+
+int wmbus_selftest_fir(int device, const float *x, float *out, size_t n)
+{
+    if (wmbus_device_count() <= device || hipSetDevice(device) != hipSuccess) return WMBUS_ENODEVICE;
+    if (!x || !out || n == 0 || n > (size_t)K1Geo::T || (n & 3)) return WMBUS_EINVAL;
+    float *d_x = nullptr, *d_o = nullptr;
+    if (hipMalloc((void **)&d_x, (n + 48) * sizeof(float)) != hipSuccess || hipMalloc((void **)&d_o, 2 * n * sizeof(float)) != hipSuccess) {
+        hipFree(d_x); hipFree(d_o);
+        return WMBUS_ENOMEM;
+    }
+    int rc = hipMemcpy(d_x, x, (n + 48) * sizeof(float), hipMemcpyHostToDevice) == hipSuccess ? WMBUS_OK : WMBUS_EDEVICE;
+    if (rc == WMBUS_OK) {
+        hipLaunchKernelGGL(k_selftest_fir, dim3(1), dim3(256), 0, 0, d_x, d_o, (uint32_t)n);
+        if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out, d_o, 2 * n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) rc = WMBUS_EDEVICE;
+    }
+    hipFree(d_x); hipFree(d_o);
     return rc;
 }
 

@@ -177,6 +177,23 @@ __device__ __forceinline__ void k1_boxcars(const uint32_t *w, int d_rt, wm_s2 s8
     }
 }
 
+/* The first tap of a low-pass: the reference's sum starts from +0 (fir.h:56), so its first partial sum is 0 + b[0] x -- never
+ * -0 -- and neither is any soft symbol (+0 + -0 = +0; an exact cancellation is +0), which the clock kernel relies on when it
+ * takes the slicer's decision from the sign bit.  Written as an addition the compiler loses this: b[0] < 0, so 0 + b[0] x
+ * becomes 0 - |b[0]| x, and the backend folds "0 - y" into a negated operand of the next subtraction: -(|b[0]| x) - |b[1]| x',
+ * which is -0 where the reference has +0 when both samples are +0 (round 5, read off the ISA; reaching the filter's output
+ * would take a crafted input, -0 under every positive tap and +0 under every negative one).  fma(b[0], x, +0) is the same
+ * single rounding of the product with the +0 added, in one instruction like the multiplication it replaces. */
+template <bool FAST>
+__device__ __forceinline__ float k1_fir_first(const float b0, const float x)
+{
+#ifdef WM_FIR_FIRST_AS_ADD                                    /* the form before (A/B and the self-test's evidence: tools/build_variant.sh firadd -DWM_FIR_FIRST_AS_ADD) */
+    return FAST ? __builtin_fmaf(b0, x, 0.0f) : wm_add(0.0f, wm_mul(b0, x));
+#else
+    return FAST ? __builtin_fmaf(b0, x, 0.0f) : wm_fma_exact(b0, x, 0.0f);
+#endif
+}
+
 /* A 16-byte LDS read that stays ONE ds_read_b128: where a window's first or last vector is only partly used the compiler
  * narrows the load to the used words and then re-pairs the scalars from the odd start -- the 46-tap window arrived as 24
  * ds_read2_b32, each with its own address add (round 5, read off the ISA).  The empty asm makes all four words "used". */
@@ -211,9 +228,9 @@ __device__ __forceinline__ void k1_fir_t(const K1Args &a, const float *yDrT, con
     float acc[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        float s = 0.0f;
+        float s = k1_fir_first<FAST>(FIR_T[0], w[12 + j]);
 #pragma unroll
-        for (int k = 0; k < 11; k++) s = FAST ? __builtin_fmaf(FIR_T[k], w[12 + j - k], s) : wm_add(s, wm_mul(FIR_T[k], w[12 + j - k]));
+        for (int k = 1; k < 11; k++) s = FAST ? __builtin_fmaf(FIR_T[k], w[12 + j - k], s) : wm_add(s, wm_mul(FIR_T[k], w[12 + j - k]));
         acc[j] = s;
     }
     *(float4 *)(a.dphi + (uint64_t)stream * g.Mcap + (uint64_t)ts + m0l) = make_float4(acc[0], acc[1], acc[2], acc[3]);
@@ -230,7 +247,7 @@ __device__ __forceinline__ void k1_fir_s(const K1Args &a, const float *yDrS, con
      * registers in TWO halves, newest first: taps 0 .. 23 read elements 25 .. 51, taps 24 .. 45 elements 3 .. 27 (seven
      * vectors each) -- 28 registers at a time instead of 52.  (Round 5: the registers are what a block's NEXT tile
      * needs for its input words, which are in flight during this stage; with the whole window resident the kernel spilled.) */
-    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float acc[4];
     {
         float w[28];                                          /* w[i] = element 24 + i */
 #pragma unroll
@@ -240,9 +257,9 @@ __device__ __forceinline__ void k1_fir_s(const K1Args &a, const float *yDrS, con
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            float s_ = acc[j];
+            float s_ = k1_fir_first<FAST>(FIR_S[0], w[24 + j]);
 #pragma unroll
-            for (int k = 0; k < 24; k++) s_ = FAST ? __builtin_fmaf(FIR_S[k], w[24 + j - k], s_) : wm_add(s_, wm_mul(FIR_S[k], w[24 + j - k]));
+            for (int k = 1; k < 24; k++) s_ = FAST ? __builtin_fmaf(FIR_S[k], w[24 + j - k], s_) : wm_add(s_, wm_mul(FIR_S[k], w[24 + j - k]));
             acc[j] = s_;
         }
     }

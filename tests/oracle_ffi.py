@@ -178,3 +178,46 @@ def run_reference(cu8, argv):
 
 def have_reference():
     return os.path.exists(REF_BIN)
+
+
+# ---- the two low-pass filters alone (oracle: wmo_fir; reference: ref_probe fir) ---------------------------------------------
+FIR_NEG_TAPS = {0: [0, 1, 9, 10], 1: list(range(0, 11)) + list(range(35, 46))}     # taps with a negative coefficient (rtl_wmbus.c:369-391)
+FIR_LEN = {0: 11, 1: 46}
+
+
+def fir(which, x):
+    """The oracle's low-pass (0: 11 taps, T1/C1; 1: 46 taps, S1) of x, from a zeroed history."""
+    L = lib()
+    L.wmo_fir.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]; L.wmo_fir.restype = None
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.empty_like(x)
+    L.wmo_fir(which, x.ctypes.data, y.ctypes.data, x.size)
+    return y
+
+
+def fir_rows(seed, n=976):
+    """Rows of 48 + n floats for the low-pass tests: what a capture gives (angles in (-pi, pi]) and what it hardly ever does --
+    rows of signed zeros, among them the pattern that turns a sum started at -(b0 x) instead of 0 + b0 x into -0 at the
+    OUTPUT: +0 under every negative tap, -0 under every positive one, at several alignments -- zeros between sparse samples,
+    subnormals, huge values."""
+    rng = np.random.default_rng(seed)
+    N = 48 + n
+    pz, nz = np.float32(0.0), np.float32(-0.0)
+    rows = [rng.uniform(-np.pi, np.pi, N).astype(np.float32),
+            np.where(rng.integers(0, 2, N) == 1, nz, pz).astype(np.float32),
+            np.full(N, nz, np.float32), np.full(N, pz, np.float32)]
+    for which in (0, 1):
+        ln, neg = FIR_LEN[which], set(FIR_NEG_TAPS[which])
+        pat = np.array([pz if k in neg else nz for k in range(ln)], np.float32)[::-1]      # oldest first: tap k reads x[n - k]
+        row = np.where(rng.integers(0, 2, N) == 1, nz, pz).astype(np.float32)
+        for start in range(50 + which, N - ln, ln + 3):
+            row[start:start + ln] = pat
+        rows.append(row)
+        row = row.copy(); row[rng.integers(0, N, 12)] = rng.standard_normal(12).astype(np.float32)
+        rows.append(row)
+    sparse = np.zeros(N, np.float32); idx = rng.integers(0, N, N // 8); sparse[idx] = rng.uniform(-3, 3, idx.size).astype(np.float32)
+    sparse[rng.integers(0, N, N // 8)] = nz
+    rows.append(sparse)
+    rows.append((rng.standard_normal(N) * 1e-39).astype(np.float32))                        # subnormal products
+    rows.append((rng.standard_normal(N).astype(np.float32) * np.float32(10.0) ** rng.integers(-30, 30, N).astype(np.float32)).astype(np.float32))
+    return rows

@@ -114,6 +114,21 @@ def test_device_arithmetic_is_ieee_and_glibc_exact(wm, oracle, libm_is_glibc_235
     assert np.array_equal(r["atan2"].view(np.uint32), host2(L.wmo_libm_atan2f, yy, xx).view(np.uint32))
 
 
+def test_device_low_pass_filters_signed_zeros_included(wm, oracle):
+    """The demodulation kernel's two low-pass filters (the functions its stage B inlines, run by wmbus_selftest_fir) against the
+    oracle's FIR on rows a capture hardly ever produces -- signed zeros above all: the reference's sum starts from +0
+    (fir.h:56), so a soft symbol is never -0, and the clock kernel takes the slicer's bit (`>= 0`, rtl_wmbus.c:1059) from the
+    sign bit.  (Round 5: the compiler had turned 0 + b0 x, b0 < 0, into a negated operand of the next subtraction --
+    -0 where the reference has +0 under the pattern of tests/oracle_ffi.py fir_rows; the first tap is an fma with +0 now.)"""
+    for seed in (1, 2, 3):
+        for x in oracle.fir_rows(seed):
+            y11, y46 = wm.selftest_fir(x)
+            for which, got in ((0, y11), (1, y46)):
+                want = oracle.fir(which, x)[48:]
+                assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (seed, which)
+                assert not np.any(got.view(np.uint32) == 0x80000000)
+
+
 @pytest.mark.parametrize("name,flags", BUNDLED_CASES, ids=[f"{n[14:22]}:{' '.join(f)}" for n, f in BUNDLED_CASES])
 def test_bundled_captures_match_reference_golden(wm, name, flags):
     cu8 = np.fromfile(os.path.join(SAMPLES, name), np.uint8)

@@ -97,3 +97,17 @@ def test_atan2_approximations_equal_the_references_own_functions(which):
     im, re = np.ascontiguousarray(pairs[:, 0]), np.ascontiguousarray(pairs[:, 1])
     L.wmo_atan2_approx(which, im.ctypes.data, re.ctypes.data, got.ctypes.data, len(pairs))
     assert len(want) == len(got) and np.array_equal(want.view(np.uint32), got.view(np.uint32))
+
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_low_pass_filters_equal_the_references_own_functions_signed_zeros_included(which):
+    """rtl_wmbus.c:369-391 over fir.h:48-72: the oracle's FIR against the reference's own functions on rows a capture hardly ever
+    produces.  The sum starts from +0, so an output is never -0 -- the property the clock kernel's slicer (sign bit instead of
+    `>= 0`, rtl_wmbus.c:1059) rests on and the device self-test checks on the same rows (test_gpu_parity.py)."""
+    for seed in (1, 2):
+        for x in O.fir_rows(seed):
+            p = subprocess.run([O.REF_PROBE, "fir", str(which)], input=x.tobytes(), stdout=subprocess.PIPE, check=True)
+            want = np.frombuffer(p.stdout, np.float32)
+            got = O.fir(which, x)
+            assert np.array_equal(want.view(np.uint32), got.view(np.uint32))
+            assert not np.any(got.view(np.uint32) == 0x80000000), "a soft symbol is never -0"
