@@ -19,7 +19,8 @@ done
 # roofline of the bench line is computed from (instruction counts) and what the waves spend their time on
 i=0
 for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
-           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC" ; do
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL" ; do
   i=$((i+1))
   timeout 600 rocprofv3 --pmc $grp --kernel-trace --stats -d $R/gpurun_out/prof/pmc_sq$i -o pmc --output-format csv -- python $R/bench.py --steps 1 --warmup 0 --contexts 1 --quick > $R/gpurun_out/prof/pmc_sq$i.log 2>&1
   echo "SQ group $i rc=$?"
@@ -29,7 +30,7 @@ import csv,os,collections,json
 R=os.environ['GRAFT_REPO_ROOT']+'/gpurun_out/prof'
 out={}
 sq=collections.defaultdict(lambda: collections.defaultdict(list)); durs=collections.defaultdict(list)
-for i in (1,2):
+for i in (1,2,3):
     p=f'{R}/pmc_sq{i}/pmc_counter_collection.csv'
     if not os.path.exists(p): continue
     seen=set()
