@@ -20,8 +20,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 wm = importlib.import_module("rtl-wmbus_amd")
 
-# dynamic VALU instructions per wave and stage, from the ISA (tools/isa_budget.py; stage B: 4 x 92 + 4 x 22 + addressing)
-INSTR = {256: (30, 586, 470), 512: (34, 586, 470)}
+# dynamic VALU instructions per wave and stage, from the ISA (tools/isa_budget.py; stage B: 4 x 92 + 4 x 22 + addressing; 470 before the whole-vector window loads)
+INSTR = {256: (30, 586, 446), 512: (34, 586, 446)}
 N = 1 << 22
 
 
