@@ -62,7 +62,7 @@ WM_HD float wm_fma_exact(float a, float b, float c) { return wm_add(wm_mul(a, b)
  * emits for `/` and sqrtf under -fhip-fp32-correctly-rounded-divide-sqrt, without its range
  * scaling (v_div_scale / v_div_fmas scaling, the 2^32 pre-scale of tiny sqrt arguments) and
  * special-case fix-up (v_div_fixup, the class test), which can only act outside that domain.
- * 11 -> 8 and ~18 -> 9 instructions.  The discriminator divides integers below 2^24 (and range
+ * 11 -> 6 and ~18 -> 9 instructions.  The discriminator divides integers below 2^24 (and range
  * reduced values in [2^-24, 2^24]); the RSSI takes the root of an integer below 2^24.  A zero
  * DIVISOR gives NaN here instead of +-Inf: wm_atan2f_tab overrides x == 0 anyway.
  * tests/test_gpu_parity.py checks both on the device against the host's IEEE results:
@@ -70,13 +70,17 @@ WM_HD float wm_fma_exact(float a, float b, float c) { return wm_add(wm_mul(a, b)
 #if defined(__HIP_DEVICE_COMPILE__)
 WM_HD float wm_div_dom(float a, float b)
 {
+    /* Markstein: with y = RN(1/b) and q a faithful a/b, ONE correction q + (a - b q) y rounds to RN(a/b).  gfx950's v_rcp_f32 is
+     * good to 1 ulp, and one Newton step from it IS the correctly rounded reciprocal for every one of the 2^23 significands
+     * (tools/recip_check.hip, exhaustive on the device; the quotient itself against `/` on 8 x 10^8 operand pairs) -- so the
+     * second correction step the compiler's expansion carries (it has to cope with scaled and subnormal operands) is not
+     * needed on this domain: 6 instructions instead of 8 (round 5).  The sign of a zero quotient is not the IEEE one for
+     * a = -0 (+0 comes out): wm_atan2f_tab uses |q| only. */
     float y = __builtin_amdgcn_rcpf(b);                      /* 1 ulp */
     const float e = __builtin_fmaf(-b, y, 1.0f);
     y = __builtin_fmaf(e, y, y);
-    float q = __fmul_rn(a, y);
-    float r = __builtin_fmaf(-b, q, a);
-    q = __builtin_fmaf(r, y, q);
-    r = __builtin_fmaf(-b, q, a);
+    const float q = __fmul_rn(a, y);
+    const float r = __builtin_fmaf(-b, q, a);
     return __builtin_fmaf(r, y, q);
 }
 WM_HD float wm_sqrt_dom(float x)
