@@ -93,7 +93,11 @@ __device__ __forceinline__ bool clk_state_same(const WmClkState &a, const WmClkS
  * Bits: the slicer output (soft >= 0, rtl_wmbus.c:1059) is the inverted sign bit -- a soft symbol
  * is never -0 (the FIR accumulates from +0, and +0 + -0 = +0; the DC remover's x - x_old is never
  * -0 either) -- shifted into a word with one v_alignbit; clock levels via WM_LEVEL_CARRY. */
-template <bool DC>
+/* WARM (round 5): a warm-up block whose chips nobody looks at (it ends more than WM_CLK_SR_WINDOW samples before the segment) --
+ * the recurrences of all three sections run as ever, but what only FEEDS THE OUTPUT is left out: the last section's feed-forward
+ * half and the level (6 instructions), the slicer bit (1): 20 instead of 27 per sample.  s.clk is not touched; the full blocks
+ * behind it (at least WM_CLK_SR_WINDOW / 32 + 1 of them) set it. */
+template <bool DC, bool WARM = false>
 __device__ __forceinline__ void clk_block32(WmClkState &s, const IirCoef &c, const float *xrow, uint32_t &bitw, uint32_t &smask)
 {
     /* xrow: this lane's 32 soft symbols in LDS; four are fetched every fourth tick, so the block in
@@ -118,7 +122,7 @@ __device__ __forceinline__ void clk_block32(WmClkState &s, const IirCoef &c, con
             const int n0 = t - P;
             if (n0 >= 0 && n0 < 32) {
                 const float sf = DC ? soft : xt;
-                sgn = __builtin_amdgcn_alignbit(sgn, wm_f2u(sf), 31);      /* (sgn << 1) | signbit */
+                if (!WARM) sgn = __builtin_amdgcn_alignbit(sgn, wm_f2u(sf), 31);      /* (sgn << 1) | signbit */
                 in[0] = wm_mul(sf, sf);
             }
         }
@@ -127,7 +131,7 @@ __device__ __forceinline__ void clk_block32(WmClkState &s, const IirCoef &c, con
             const int n = t - P - k;
             if (n >= 0 && n < 32) {
                 m1[k] = wm_mul(c.a1[k], h1[k]); m2[k] = wm_mul(c.a2[k], h2[k]);
-                p1[k] = wm_mul(c.b1[k], h1[k]); p2[k] = wm_mul(c.b2[k], h2[k]);
+                if (!(WARM && k == 2)) { p1[k] = wm_mul(c.b1[k], h1[k]); p2[k] = wm_mul(c.b2[k], h2[k]); }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -143,10 +147,10 @@ __device__ __forceinline__ void clk_block32(WmClkState &s, const IirCoef &c, con
         __builtin_amdgcn_sched_barrier(0);
         /* level 4, 5 */
 #pragma unroll
-        for (int k = 0; k < 3; k++) { const int n = t - P - k; if (n >= 0 && n < 32) u[k] = wm_add(h0[k], p1[k]); }
+        for (int k = 0; k < 3; k++) { const int n = t - P - k; if (n >= 0 && n < 32 && !(WARM && k == 2)) u[k] = wm_add(h0[k], p1[k]); }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < 3; k++) { const int n = t - P - k; if (n >= 0 && n < 32) o[k] = wm_add(u[k], p2[k]); }
+        for (int k = 0; k < 3; k++) { const int n = t - P - k; if (n >= 0 && n < 32 && !(WARM && k == 2)) o[k] = wm_add(u[k], p2[k]); }
         /* hand over: section k's output is section k+1's input at the next tick */
 #pragma unroll
         for (int k = 2; k >= 0; k--) {
@@ -154,13 +158,14 @@ __device__ __forceinline__ void clk_block32(WmClkState &s, const IirCoef &c, con
             if (n >= 0 && n < 32) {
                 h2[k] = h1[k]; h1[k] = h0[k];
                 if (k < 2) in[k + 1] = o[k];
-                else low = wm_shift_in_level_low(low, wm_f2u(o[2]));
+                else if (!WARM) low = wm_shift_in_level_low(low, wm_f2u(o[2]));
             }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
     s.h[0] = h1[0]; s.h[1] = h2[0]; s.h[2] = h1[1]; s.h[3] = h2[1]; s.h[4] = h1[2]; s.h[5] = h2[2];
     s.dc_x = dcx; s.dc_y = dcy;
+    if (WARM) { bitw = 0u; smask = 0u; return; }
     bitw = ~__builtin_bitreverse32(sgn);
     /* clock lock (rtl_wmbus.c:1092-1111): take the bit at n iff the levels at n-3..n are L,H,H,H */
     /* WmClkState.clk keeps the last three levels with the NEWEST in bit 0; here time runs upwards */
@@ -292,6 +297,9 @@ __device__ __forceinline__ int clock_segment(const K2Args &a, ClkLds<W> &lds, co
 #ifndef WM_CLK_SR_WINDOW
 #define WM_CLK_SR_WINDOW 1024     /* 0: shift-register upkeep over the whole warm-up (the r03 form; A/B) */
 #endif
+#ifndef WM_CLK_WARM_SHORT
+#define WM_CLK_WARM_SHORT 1        /* 0: warm-up blocks compute their (unread) outputs too (A/B) */
+#endif
 #ifndef WM_CLK_PREFETCH
 #define WM_CLK_PREFETCH 2          /* blocks of loads in flight per lane; 1 = build-time experiment (32 VGPRs fewer) */
 #endif
@@ -321,11 +329,14 @@ __device__ __forceinline__ int clock_segment(const K2Args &a, ClkLds<W> &lds, co
     /* ---- phase 1: warm-up blocks [m, mb): soft symbols only; no store is issued in this loop, so
      * waiting for a block in flight never waits for anything else (gfx950's vmcnt counts loads
      * and stores in one in-order queue) --------------------------------------------------------- */
+    constexpr bool warm_short = WM_CLK_WARM_SHORT != 0 && WM_CLK_SR_WINDOW != 0;
     auto warm_block = [&](wm_f4 (&gx)[8]) WM_LAMBDA_INLINE {
         put_x(gx);
         fetch_x(gx, min(m + AHEAD, m_last));
         uint32_t bitw, smask;
-        if (LEAN) clk_block32_lean<DC>(s, c, xrow, bitw, smask); else clk_block32<DC>(s, c, xrow, bitw, smask);
+        if (LEAN) clk_block32_lean<DC>(s, c, xrow, bitw, smask);
+        else if (warm_short && mb - m > (uint32_t)WM_CLK_SR_WINDOW + 32u) clk_block32<DC, true>(s, c, xrow, bitw, smask);
+        else clk_block32<DC>(s, c, xrow, bitw, smask);
         /* shift-register upkeep: at most 8 chips per block, oldest first; the wave stops as soon as none of its lanes
          * has a chip left (T1/C1 lanes meet 4 per block, S1 lanes 1.3: half the trips of the fixed eight).  The register
          * is a function of the last 16 / 24 chips only, so the upkeep starts WM_CLK_SR_WINDOW samples before the segment
