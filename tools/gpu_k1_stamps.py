@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 wm = importlib.import_module("rtl-wmbus_amd")
 
 # dynamic VALU instructions per wave and stage, from the ISA (tools/isa_budget.py; stage B: 4 x 92 + 4 x 22 + addressing; 470 before the whole-vector window loads)
-INSTR = {256: (30, 586, 446), 512: (34, 586, 446)}
+INSTR = {256: (30, 554, 446), 512: (34, 554, 446)}
 N = 1 << 22
 
 
