@@ -52,23 +52,29 @@ void batch_worker(wmbus_batch *b, unsigned i, const wmbus_batch_io *io, BatchTot
     auto source = [&](int k) -> size_t {                    /* bytes of the next push (0: the input has ended), staged if host-sourced */
         if (b->stop.load()) return 0;
         if (!io->fill) { if (passes_left == 0) return 0; passes_left--; return io->resident_bytes; }
-        if (!io->self_staged && !b->slab[k][i]) {
+        (void)k;
+        /* ONE page-locked slab per context (round 5; two until then): the copies of a push leave the slab long before the next
+         * push is read into it -- they were queued an iteration ago and the demodulation kernel behind them has been enqueued
+         * since -- so the refill only has to make sure (one event, normally signalled already), and the staging the driver has
+         * to pin, at about 5 GB/s and inside the decode time, is files x push bytes instead of twice that. */
+        if (!io->self_staged && !b->slab[0][i]) {
             /* Page-locked staging is allocated HERE, by the context's own thread when it first needs the slab: the driver
              * pins one allocation at a time (16 GB for 1024 files of 8 MiB pushes: 2.4-3 s), so a batch that pinned
              * everything before its first push spent longer setting up than decoding; now the first contexts decode while
              * the others' slabs are still being pinned, and a context's second slab is pinned while its first push runs. */
             hipSetDevice(b->cfg.device);
-            if (hipHostMalloc((void **)&b->slab[k][i], (size_t)S * pitch) != hipSuccess) {
-                b->slab[k][i] = nullptr;
+            if (hipHostMalloc((void **)&b->slab[0][i], (size_t)S * pitch) != hipSuccess) {
+                b->slab[0][i] = nullptr;
                 batch_fail(b, WMBUS_ENOMEM, "batch: cannot allocate %zu bytes of page-locked staging", (size_t)S * pitch);
                 return 0;
             }
         }
-        const size_t n = io->fill(io->user, s0, S, io->self_staged ? nullptr : b->slab[k][i], pitch, pitch);
+        if (!io->self_staged && hipEventSynchronize(c->ev_staged) != hipSuccess) { batch_fail(b, WMBUS_EDEVICE, "batch: context %u: waiting for the staging copies failed", i); return 0; }
+        const size_t n = io->fill(io->user, s0, S, io->self_staged ? nullptr : b->slab[0][i], pitch, pitch);
         if (n == 0) return 0;
         if (n > pitch || n % WMBUS_BLOCK_BYTES) { batch_fail(b, WMBUS_EINVAL, "batch: the source returned %zu bytes (multiple of 4096, at most %zu)", n, pitch); return 0; }
         for (unsigned s = 0; s < S && !io->self_staged; s++)
-            if (wmbus_stage(c, s, b->slab[k][i] + (size_t)s * pitch, n)) { batch_fail(b, WMBUS_EDEVICE, "batch: context %u: %s", i, c->err); return 0; }
+            if (wmbus_stage(c, s, b->slab[0][i] + (size_t)s * pitch, n)) { batch_fail(b, WMBUS_EDEVICE, "batch: context %u: %s", i, c->err); return 0; }
         return n;
     };
     size_t n_cur = source(cur);

@@ -51,7 +51,7 @@ static void print_usage(const char *prog)
     fprintf(stdout, "\t-s receive S1 and T1/C1 datagrams simultaneously. rtl_sdr _MUST_ be set to 868.625MHz (-f 868.625M)\n");
     fprintf(stdout, "\t-p [T,S] to disable processing T1/C1 or S1 mode\n");
     fprintf(stdout, "\t-f exit if flow of incoming data stops\n");
-    fprintf(stdout, "\t-B bytes per GPU push (multiple of 4096; default 1048576 for a live stream, 2097152 per file in batch mode)\n");
+    fprintf(stdout, "\t-B bytes per GPU push (multiple of 4096; default 1048576 for a live stream; per file in batch mode 2097152, 1048576 from 384 files per GPU on)\n");
     fprintf(stdout, "\t-L ms a live stream's bytes wait at most this long for their push to fill (default 50; 0: only full pushes)\n");
     fprintf(stdout, "\t-S batch mode: print samples, seconds and Msamples/s to stderr\n");
     fprintf(stdout, "\t-G HIP device ordinal (default 0); batch mode: 'all' or a list '0,2,5' shards the files, file i on device list[i mod n]\n");
@@ -369,9 +369,14 @@ int main(int argc, char **argv)
         /* batch mode: 2 MiB per file and push (-B overrides).  The staging is page-locked -- 2 x files x push bytes, pinned by
          * the driver one allocation at a time at about 6 GB/s -- and a job whose files are a few pushes long spends longer
          * pinning than decoding: 1024 files of 64 MiB took 3.9-4.3 s end to end with 8 MiB pushes (16 GB of staging),
-         * 2.5-2.7 s with 2 MiB (4 GB), 2.9-3.1 s with 4 MiB; r03, which pinned everything before its first push: 6.6-7.4 s */
-        if (cfg.max_push_bytes == 0) cfg.max_push_bytes = 2u << 20;
+         * 2.5-2.7 s with 2 MiB (4 GB), 2.9-3.1 s with 4 MiB; r03, which pinned everything before its first push: 6.6-7.4 s.
+         * Round 5 (parallel readers; ONE slab per context, wm_batch.h: the staging is files x push bytes), Gsamples/s decode:
+         * 1024 files 20.5-21.3 with 1 MiB, 17-18 with 512-768 KiB, 14.2-15.2 with 2 MiB, 11.5-13.9 with 4 MiB; 512 files 17.5-18.6
+         * with 1 MiB, 15.4-15.9 with 2 MiB; 256 files 15.0-15.5 with 1.5-2 MiB, 11.9 with 1 MiB, 14.4-15.7 with 4 MiB
+         * (profiles/r05_cli_push_bytes.txt): a context wants 64-128 MiB per push -- less starves the GPU, more makes the
+         * pipeline's first and last push, and the pinning, long.  So: 1 MiB per file and push from 384 files per device on, else 2 MiB */
         if (n_devs == 0) { devs[0] = cfg.device; n_devs = 1; }
+        if (cfg.max_push_bytes == 0) cfg.max_push_bytes = (argc - optind + n_devs - 1) / n_devs >= 384 ? 1u << 20 : 2u << 20;
         finish(run_sharded(cfg, argc - optind, argv + optind, devs, n_devs, map_only, stats));
     }
     if (cfg.max_push_bytes == 0) cfg.max_push_bytes = 1u << 20;
