@@ -15,7 +15,7 @@ struct wmbus_batch {
     char err[256] = {0};
     std::vector<wmbus_ctx *> ctx;
     std::vector<unsigned> first, count;                 /* stream range of every context */
-    std::vector<uint8_t *> slab[2];                     /* per context: two page-locked staging slabs (host-sourced runs), allocated on first use */
+    std::vector<uint8_t *> slab;                        /* per context: its page-locked staging slab (host-sourced runs), allocated on first use */
     std::mutex out_lock, err_lock;
     std::atomic<bool> stop{false};
     int rc = 0;
@@ -57,24 +57,24 @@ void batch_worker(wmbus_batch *b, unsigned i, const wmbus_batch_io *io, BatchTot
          * push is read into it -- they were queued an iteration ago and the demodulation kernel behind them has been enqueued
          * since -- so the refill only has to make sure (one event, normally signalled already), and the staging the driver has
          * to pin, at about 5 GB/s and inside the decode time, is files x push bytes instead of twice that. */
-        if (!io->self_staged && !b->slab[0][i]) {
+        if (!io->self_staged && !b->slab[i]) {
             /* Page-locked staging is allocated HERE, by the context's own thread when it first needs the slab: the driver
              * pins one allocation at a time (16 GB for 1024 files of 8 MiB pushes: 2.4-3 s), so a batch that pinned
              * everything before its first push spent longer setting up than decoding; now the first contexts decode while
-             * the others' slabs are still being pinned, and a context's second slab is pinned while its first push runs. */
+             * the others' slabs are still being pinned. */
             hipSetDevice(b->cfg.device);
-            if (hipHostMalloc((void **)&b->slab[0][i], (size_t)S * pitch) != hipSuccess) {
-                b->slab[0][i] = nullptr;
+            if (hipHostMalloc((void **)&b->slab[i], (size_t)S * pitch) != hipSuccess) {
+                b->slab[i] = nullptr;
                 batch_fail(b, WMBUS_ENOMEM, "batch: cannot allocate %zu bytes of page-locked staging", (size_t)S * pitch);
                 return 0;
             }
         }
         if (!io->self_staged && hipEventSynchronize(c->ev_staged) != hipSuccess) { batch_fail(b, WMBUS_EDEVICE, "batch: context %u: waiting for the staging copies failed", i); return 0; }
-        const size_t n = io->fill(io->user, s0, S, io->self_staged ? nullptr : b->slab[0][i], pitch, pitch);
+        const size_t n = io->fill(io->user, s0, S, io->self_staged ? nullptr : b->slab[i], pitch, pitch);
         if (n == 0) return 0;
         if (n > pitch || n % WMBUS_BLOCK_BYTES) { batch_fail(b, WMBUS_EINVAL, "batch: the source returned %zu bytes (multiple of 4096, at most %zu)", n, pitch); return 0; }
         for (unsigned s = 0; s < S && !io->self_staged; s++)
-            if (wmbus_stage(c, s, b->slab[0][i] + (size_t)s * pitch, n)) { batch_fail(b, WMBUS_EDEVICE, "batch: context %u: %s", i, c->err); return 0; }
+            if (wmbus_stage(c, s, b->slab[i] + (size_t)s * pitch, n)) { batch_fail(b, WMBUS_EDEVICE, "batch: context %u: %s", i, c->err); return 0; }
         return n;
     };
     size_t n_cur = source(cur);
@@ -132,7 +132,7 @@ void wmbus_batch_close(wmbus_batch *b)
 {
     if (!b) return;
     for (auto *c : b->ctx) wmbus_close(c);
-    for (auto &v : b->slab) for (auto *p : v) if (p) hipHostFree(p);
+    for (auto *p : b->slab) if (p) hipHostFree(p);
     delete b;
 }
 
@@ -187,7 +187,7 @@ int wmbus_batch_open(const wmbus_cfg *cfg, unsigned contexts, wmbus_batch **out)
         b->ctx.push_back(c); b->first.push_back(at); b->count.push_back(n);
         at += n;
     }
-    b->slab[0].assign(nctx, nullptr); b->slab[1].assign(nctx, nullptr);
+    b->slab.assign(nctx, nullptr);
     b->opened = true;
     return WMBUS_OK;
 }

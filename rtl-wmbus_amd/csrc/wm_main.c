@@ -366,7 +366,7 @@ int main(int argc, char **argv)
     }
 
     if (optind < argc) {
-        /* batch mode: 2 MiB per file and push (-B overrides).  The staging is page-locked -- 2 x files x push bytes, pinned by
+        /* batch mode: 2 MiB per file and push (-B overrides).  The staging is page-locked -- files x push bytes (twice that until round 5), pinned by
          * the driver one allocation at a time at about 6 GB/s -- and a job whose files are a few pushes long spends longer
          * pinning than decoding: 1024 files of 64 MiB took 3.9-4.3 s end to end with 8 MiB pushes (16 GB of staging),
          * 2.5-2.7 s with 2 MiB (4 GB), 2.9-3.1 s with 4 MiB; r03, which pinned everything before its first push: 6.6-7.4 s.
