@@ -60,6 +60,22 @@ static inline void step_fma(St &s, const Coef &c, float x)
     }
 }
 
+/* the first nsec sections only (the others keep their zero state): a STAGGERED warm-up switches section 1 on A samples and
+ * section 2 A + B samples behind section 0 -- a later section's input is only true once the sections before it have settled */
+static inline void step_sections(St &s, const Coef &c, float x, int nsec)
+{
+    float v = x * x;
+    for (int k = 0; k < nsec; k++) {
+        const float h1 = s.h[2 * k], h2 = s.h[2 * k + 1];
+        const float m1 = c.a1[k] * h1, m2 = c.a2[k] * h2, p1 = c.b1[k] * h1, p2 = c.b2[k] * h2;
+        const float t = m1 + m2;
+        const float h0 = v - t;
+        const float u = h0 + p1;
+        v = u + p2;
+        s.h[2 * k + 1] = h1; s.h[2 * k] = h0;
+    }
+}
+
 static inline bool same(const St &a, const St &b) { return std::memcmp(a.h, b.h, sizeof a.h) == 0 && a.clk == b.clk; }
 
 extern "C" {
@@ -86,7 +102,12 @@ int clk_warm_study(const float *x, uint32_t M, int ch, uint32_t seg, uint32_t W,
         if (mb <= W) continue;
         St q{};
         uint32_t m = mb - W;
-        const uint32_t m_ex = E >= W ? m : mb - E;
+        const uint32_t m_ex = E >= (1u << 30) ? m : E >= W ? m : mb - E;
+        if (E >= (1u << 30)) {                                   /* staggered: E = 2^30 | A << 15 | B (A, B in units of 1 sample, < 32768) */
+            const uint32_t A = (E >> 15) & 0x7FFFu, B = E & 0x7FFFu;
+            for (; m < mb - W + A; m++) step_sections(q, c, x[m], 1);
+            for (; m < mb - W + A + B; m++) step_sections(q, c, x[m], 2);
+        } else
         for (; m < m_ex; m++) step_fma(q, c, x[m]);
         for (; m < mb; m++) { const bool hi = step_exact(q, c, x[m]); q.clk = ((q.clk << 1) | (hi ? 1u : 0u)) & 7u; }
         uint32_t i = 0;

@@ -41,6 +41,20 @@ def main():
     print("# leave[i]: hand-offs certified at the boundary (i = 0) / re-run meets the speculative pass at checkpoint i / not within the segment (last)")
     schemes = {0: [(12288, 12288), (12288, 8192), (12288, 6144), (12288, 4096), (12288, 2048), (16384, 4096), (16384, 8192), (8192, 8192), (16384, 16384)],
                1: [(24576, 24576), (24576, 16384), (24576, 12288), (24576, 8192), (24576, 4096), (32768, 8192), (32768, 16384), (28672, 12288), (32768, 32768), (16384, 16384)]}
+    stag = {0: [(12288, 2048, 2048), (12288, 4096, 2048), (12288, 4096, 4096), (12288, 2048, 6144), (16384, 4096, 4096)],
+            1: [(24576, 4096, 4096), (24576, 8192, 4096), (24576, 8192, 8192), (24576, 4096, 12288), (32768, 8192, 8192)]}
+    if "--stagger" in sys.argv:
+        print("# STAGGERED warm-ups: section 1 starts A samples, section 2 A + B samples behind section 0 (all exact); ops: 5 / 13 / 20 per sample in the three phases, 27 in the segment")
+        for ch in (0, 1):
+            for W, A, B in stag[ch]:
+                leave = np.zeros(nl, np.uint32)
+                tot = 0
+                for r in rows:
+                    tot += L.clk_warm_study(r[ch].ctypes.data, r[ch].size, ch, seg, W, (1 << 30) | (A << 15) | B, ck, leave.ctypes.data, nl)
+                cost = (A * 5 + B * 13 + (W - A - B) * 20 + seg * 27) / (W * 20.0 + seg * 27.0)
+                print(f"chain {ch} W {W:6d} section 1 at +{A:5d}, section 2 at +{A + B:5d}: boundaries {tot:5d} failed {100.0 * (tot - leave[0]) / tot:6.2f} %  "
+                      f"first-pass instructions x{cost:5.3f}  leave {' '.join(str(v) for v in leave)}", flush=True)
+        return
     for ch in (0, 1):
         for W, E in schemes[ch]:
             leave = np.zeros(nl, np.uint32)
