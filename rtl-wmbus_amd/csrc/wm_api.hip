@@ -640,6 +640,19 @@ void *wmbus_alloc_pinned(size_t nbytes)
 
 void wmbus_free_pinned(void *p) { if (p) hipHostFree(p); }
 
+/* Every stream's bytes of the next push in ONE copy (the batch's host-sourced path: a context's streams lie `pitch` apart in
+ * its page-locked slab and in_stride apart in HBM -- a pitched copy; 128 copies of 1-2 MiB per context-push were 1024
+ * copy commands per step of the batch CLI).  Same rules as wmbus_stage. */
+static int wm_stage_all(wmbus_ctx *c, const uint8_t *slab, size_t pitch, size_t nbytes)
+{
+    if (!c || !slab) return WMBUS_EINVAL;
+    if (nbytes > c->cfg.max_push_bytes || nbytes % WMBUS_BLOCK_BYTES || pitch < nbytes) return fail(c, WMBUS_EINVAL, "stage: nbytes must be a multiple of 4096 and <= max_push_bytes");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (c->in_flight && c->n_win == 1) return fail(c, WMBUS_EINVAL, "stage: a push is in flight and the context has one input window (cfg.input_windows = 2 overlaps them)");
+    HIPCHK(c, hipMemcpy2DAsync(wmbus_device_input(c, 0), c->in_stride, slab, pitch, nbytes, c->S, hipMemcpyHostToDevice, c->copy_stream));
+    return WMBUS_OK;
+}
+
 void *wmbus_device_input(wmbus_ctx *c, unsigned stream)
 {
     if (!c || stream >= c->S) return nullptr;

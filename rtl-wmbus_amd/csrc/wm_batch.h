@@ -73,8 +73,14 @@ void batch_worker(wmbus_batch *b, unsigned i, const wmbus_batch_io *io, BatchTot
         const size_t n = io->fill(io->user, s0, S, io->self_staged ? nullptr : b->slab[i], pitch, pitch);
         if (n == 0) return 0;
         if (n > pitch || n % WMBUS_BLOCK_BYTES) { batch_fail(b, WMBUS_EINVAL, "batch: the source returned %zu bytes (multiple of 4096, at most %zu)", n, pitch); return 0; }
-        for (unsigned s = 0; s < S && !io->self_staged; s++)
-            if (wmbus_stage(c, s, b->slab[i] + (size_t)s * pitch, n)) { batch_fail(b, WMBUS_EDEVICE, "batch: context %u: %s", i, c->err); return 0; }
+        if (!io->self_staged) {
+#ifndef WM_STAGE_PER_STREAM
+            if (wm_stage_all(c, b->slab[i], pitch, n)) { batch_fail(b, WMBUS_EDEVICE, "batch: context %u: %s", i, c->err); return 0; }
+#else                                                       /* one copy per stream (until round 5; A/B) */
+            for (unsigned s = 0; s < S; s++)
+                if (wmbus_stage(c, s, b->slab[i] + (size_t)s * pitch, n)) { batch_fail(b, WMBUS_EDEVICE, "batch: context %u: %s", i, c->err); return 0; }
+#endif
+        }
         return n;
     };
     size_t n_cur = source(cur);

@@ -51,4 +51,4 @@ except Exception as e:
 json.dump(out, open("gpurun_out/cli_rate.json", "w"), indent=1)
 print(json.dumps(out))
 PY
-rm -rf $D
+[ -n "$KEEP_FILES" ] || rm -rf $D
