@@ -46,7 +46,7 @@ class Cfg(ctypes.Structure):
                 ("input_windows", ctypes.c_uint), ("tolerance_mode", ctypes.c_int),
                 # tuning and test knobs (0 = default), wmbus_hip.h
                 ("rounds_on_host", ctypes.c_uint), ("rssi_full", ctypes.c_uint), ("rssi_dense_pm", ctypes.c_uint), ("bursts_to_host", ctypes.c_uint),
-                ("burst_caps", ctypes.c_uint * 4), ("k1_small_tile", ctypes.c_uint), ("k1_tiles_per_block", ctypes.c_uint)]
+                ("burst_caps", ctypes.c_uint * 4), ("k1_small_tile", ctypes.c_uint), ("k1_tiles_per_block", ctypes.c_uint), ("clock_waves", ctypes.c_uint)]
 
 
 class Line(ctypes.Structure):
@@ -184,7 +184,7 @@ def _make_cfg(n_streams=1, max_push_bytes=4 << 20, decimation=2, simultaneous=Fa
               remove_dc=False, t1c1=True, s1=True, rla=True, time2=True, show_algorithm=True, device=0,
               seg_len=0, rla_seg_len=0, warmup_t1c1=0, warmup_s1=0, rla_lookback=0, host_threads=0, fixed_timestamp=True,
               prefilter=0, atan_mode=0, keep_taps=True, spill_words=0, input_windows=1, dedup_twins=False, only_crc_ok=False, tolerance_mode=0,
-              rounds_on_host=False, rssi_full=False, rssi_dense_pm=0, bursts_to_host=False, burst_caps=None, k1_small_tile=False, k1_tiles_per_block=0):
+              rounds_on_host=False, rssi_full=False, rssi_dense_pm=0, bursts_to_host=False, burst_caps=None, k1_small_tile=False, k1_tiles_per_block=0, clock_waves=0):
     c = Cfg()
     lib().wmbus_default_cfg(ctypes.byref(c))
     # test campaigns (tests/README.md): the whole GPU suite once with every hand-off failure finished by the host-driven path,
@@ -201,6 +201,7 @@ def _make_cfg(n_streams=1, max_push_bytes=4 << 20, decimation=2, simultaneous=Fa
     c.dedup_twins, c.only_crc_ok, c.tolerance_mode = int(dedup_twins), int(only_crc_ok), int(tolerance_mode)
     c.rounds_on_host, c.rssi_full, c.rssi_dense_pm, c.bursts_to_host, c.k1_small_tile = int(rounds_on_host), int(rssi_full), int(rssi_dense_pm), int(bursts_to_host), int(k1_small_tile)
     c.k1_tiles_per_block = int(k1_tiles_per_block)
+    c.clock_waves = int(clock_waves)
     for i, v in enumerate(burst_caps or ()):
         c.burst_caps[i] = int(v)
     return c

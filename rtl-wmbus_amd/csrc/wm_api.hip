@@ -156,6 +156,7 @@ struct wmbus_ctx {
     unsigned rs_pause = 0;                              /* pushes left before on demand is tried again */
     bool k1_big = false;                                /* the first pass without the RSSI runs on 2000-sample tiles of 512 threads (decimation 2, no -s) */
     uint32_t k1_tpb = 1;                                /* tiles per block of the first pass without the RSSI (cfg.k1_tiles_per_block) */
+    bool clk_sys = true;                                /* clock recovery in its systolic form (cfg.clock_waves, wm_k2_clock_sys.h) */
     uint32_t k1_tail_pm = 60;                           /* per mille of a push's tiles behind the early hand-over of the K1 turn (enqueue_front_impl) */
     uint32_t *d_rs_flags = nullptr, *d_rs_list = nullptr;   /* [ntiles_cap][S] chains read per (tile, capture); the tiles listed */
     WmItemRec *d_plans = nullptr;                          /* [4 S + hits_cap] what k3_spans leaves k3_bursts about every item */
@@ -523,6 +524,7 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
         c->k1_big = c->rs_od && c->d == 2 && !(c->flags & WM_F_SHIFT) && !cfg->k1_small_tile;
         c->k1_tail_pm = cfg->tolerance_mode ? 0u : 60u;
         c->k1_tpb = cfg->k1_tiles_per_block ? std::min(cfg->k1_tiles_per_block, 64u) : WM_K1_TPB_DEFAULT;
+        c->clk_sys = cfg->clock_waves != 1u;
         if (c->rs_od) { A(dalloc(&c->d_rs_flags, (size_t)c->ntiles_cap * c->S)); A(dalloc(&c->d_rs_list, (size_t)c->ntiles_cap * c->S)); }
     }
     const size_t stw[2] = {sizeof(WmRlaState), sizeof(WmClkState)};
@@ -741,6 +743,19 @@ static void fr_launch(wmbus_ctx *c, int algo, uint32_t cnt, hipStream_t st = nul
     /* (Round 5 tried a middle way for the clock kernel's first round: parallel, but a lane whose end state came out new carries it
      * on into an UNLISTED successor.  The second round shrank from 7 to 4 lanes and the job lost 1.8 %: 170.0 against 173.1.) */
     /* list launches: blocks for 3/16 of the lanes (a re-run list is a few percent of them; the blocks walk whatever is more) */
+    if (algo == WMBUS_ALGO_T2A && c->clk_sys) {
+        /* the systolic form: a block of four waves per 64 lanes (wm_k2_clock_sys.h); list launches as below: blocks for 3/16 of the lanes */
+        const uint32_t grid = all ? (lanes + 63u) / 64u : std::max(64u, (lanes / 64u) * 3u / 16u);
+        if (all) {
+            const bool dc = c->flags & WM_F_DC, coop = a.g.S % 64u == 0u;        /* whole waves of captures load cooperatively */
+            if (dc && coop) hipLaunchKernelGGL((k2_clock_sys<true, true>), dim3(grid), dim3(256), sizeof(ClkSysLds), st, a);
+            else if (dc) hipLaunchKernelGGL((k2_clock_sys<true, false>), dim3(grid), dim3(256), sizeof(ClkSysLds), st, a);
+            else if (coop) hipLaunchKernelGGL((k2_clock_sys<false, true>), dim3(grid), dim3(256), sizeof(ClkSysLds), st, a);
+            else hipLaunchKernelGGL((k2_clock_sys<false, false>), dim3(grid), dim3(256), sizeof(ClkSysLds), st, a);
+        } else if (c->flags & WM_F_DC) hipLaunchKernelGGL(k2_clock_sys_list<true>, dim3(grid), dim3(256), sizeof(ClkSysLds), st, a);
+        else hipLaunchKernelGGL(k2_clock_sys_list<false>, dim3(grid), dim3(256), sizeof(ClkSysLds), st, a);
+        return;
+    }
     const uint32_t B = 64 * (algo == WMBUS_ALGO_RLA ? WM_RLA_WPB : WM_CLK_WPB), grid = all ? (lanes + B - 1) / B : std::max(16u, (lanes / B) * 3u / 16u);
     if (algo == WMBUS_ALGO_RLA) {
         if (all) hipLaunchKernelGGL(k2_rla, dim3(grid), dim3(B), 0, st, a);

@@ -34,6 +34,7 @@
 #include "wm_k1_demod.h"
 #include "wm_k2_common.h"
 #include "wm_k2_clock.h"
+#include "wm_k2_clock_sys.h"
 #include "wm_k2_rla.h"
 
 /* start[seg] must equal final[seg-1]; mismatching lanes are appended to `list`. */

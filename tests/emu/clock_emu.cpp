@@ -39,8 +39,12 @@ using std::min;
 #include "wm_exact.h"
 #include "wm_k2_common.h"
 #include "wm_k2_clock.h"
+#include "wm_k2_clock_sys.h"
 
 extern "C" {
+
+int wm_emu_sys = 0;                       /* 1: the systolic form (wm_k2_clock_sys.h): every 64 lanes a block of four waves on the block emulator */
+void *wm_emu_states_out = nullptr;        /* optional: receives st_start then st_final ([2][S][nseg] WmClkState each) after the last round */
 
 int wm_emu_descending = 1;
 int wm_emu_s1_span = 0;                   /* WmPush.s1_span of the next calls */
@@ -71,9 +75,23 @@ long wm_emu_clock(const float *dphi, uint32_t S, uint32_t M, uint32_t Mcap, uint
     a.algo = 1; a.err = &err; a.sync_seen = seen.data(); a.ckpt = ckpt.data(); a.nck = nck;
     a.bad = wm_emu_chains ? bad.data() : nullptr;
     static ClkLds<1> lds;
+    static ClkSysLds sys_lds;
     const bool dc = flags & WM_F_DC;
     auto launch = [&](const uint32_t *lst, uint32_t n) {
         a.list = lst; a.n_lanes = n;
+        if (wm_emu_sys) {
+            /* four coroutines per lane; the chunks of a launch in descending or ascending order (see below) */
+            const uint32_t groups = (n + 63u) / 64u;
+            for (uint32_t i = 0; i < groups; i++) {
+                const uint32_t b = wm_emu_descending ? groups - 1 - i : i;
+                block_emu::run_block(256, [&] {
+                    if (lst) { if (dc) clock_sys_group<true, 1, false>(a, b, sys_lds); else clock_sys_group<false, 1, false>(a, b, sys_lds); }
+                    else if (S % 64u == 0u) { if (dc) clock_sys_group<true, 0, true>(a, b, sys_lds); else clock_sys_group<false, 0, true>(a, b, sys_lds); }
+                    else { if (dc) clock_sys_group<true, 0, false>(a, b, sys_lds); else clock_sys_group<false, 0, false>(a, b, sys_lds); }
+                });
+            }
+            return;
+        }
         /* On the GPU all lanes of a launch start together: a re-run lane usually reads its predecessor's
          * end state BEFORE that predecessor's own re-run (same launch) has replaced it -- which is what
          * makes cascading rounds.  Lanes in descending order reproduce that; ascending order is the
@@ -118,6 +136,10 @@ long wm_emu_clock(const float *dphi, uint32_t S, uint32_t M, uint32_t Mcap, uint
     WmClkState *c = (WmClkState *)carry;                                 /* k_carry */
     for (uint32_t r = 0; r < rows; r++) c[r] = st_final[(size_t)r * nseg + nseg - 1];
     if (wm_emu_seen_out) std::memcpy(wm_emu_seen_out, seen.data(), seen.size() * sizeof(uint32_t));
+    if (wm_emu_states_out) {
+        std::memcpy(wm_emu_states_out, st_start.data(), st_start.size() * sizeof(WmClkState));
+        std::memcpy((char *)wm_emu_states_out + st_start.size() * sizeof(WmClkState), st_final.data(), st_final.size() * sizeof(WmClkState));
+    }
     if (err_out) *err_out = err;
     if (rounds_out) *rounds_out = round;
     return reruns;
