@@ -105,9 +105,9 @@ typedef struct wmbus_cfg {
                                    512 threads is available (decimation 2, no -s, RSSI on demand); A/B */
     unsigned k1_tiles_per_block;/* consecutive tiles a block of that first pass takes, each tile's input loaded while the one before
                                    is computed (0: the default; 1: one tile per block, no prefetch) */
-    unsigned clock_waves;       /* how a clock-recovery lane's filter cascade (iir.h:49-77 behind rtl_wmbus.c:1089-1111) is laid onto
-                                   waves: 4 = systolic, the sections on the four waves of a block (round 6; 0: the default), 1 = the
-                                   whole cascade in one wave (rounds 1-5).  Same records in memory, same datagrams; A/B */
+    unsigned clock_waves;       /* how a clock-recovery lane group's filter cascade (iir.h:49-77 behind rtl_wmbus.c:1089-1111) is laid onto
+                                   waves: 4 = systolic, the sections on the four waves of a block (round 6; 0: the default); 1 = one wave,
+                                   software-pipelined across the sections (rounds 1-5).  Same records in memory, same datagrams; A/B */
 } wmbus_cfg;
 
 enum { WMBUS_PREFILTER_BOXCAR = 0, WMBUS_PREFILTER_POLYPHASE = 1 };

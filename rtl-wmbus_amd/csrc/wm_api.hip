@@ -156,7 +156,7 @@ struct wmbus_ctx {
     unsigned rs_pause = 0;                              /* pushes left before on demand is tried again */
     bool k1_big = false;                                /* the first pass without the RSSI runs on 2000-sample tiles of 512 threads (decimation 2, no -s) */
     uint32_t k1_tpb = 1;                                /* tiles per block of the first pass without the RSSI (cfg.k1_tiles_per_block) */
-    bool clk_sys = true;                                /* clock recovery in its systolic form (cfg.clock_waves, wm_k2_clock_sys.h) */
+    unsigned clk_form = 4;                              /* cfg.clock_waves: 4 systolic (wm_k2_clock_sys.h), 1 rounds 1-5's one wave per lane group (wm_k2_clock.h) */
     uint32_t k1_tail_pm = 60;                           /* per mille of a push's tiles behind the early hand-over of the K1 turn (enqueue_front_impl) */
     uint32_t *d_rs_flags = nullptr, *d_rs_list = nullptr;   /* [ntiles_cap][S] chains read per (tile, capture); the tiles listed */
     WmItemRec *d_plans = nullptr;                          /* [4 S + hits_cap] what k3_spans leaves k3_bursts about every item */
@@ -447,8 +447,16 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
     {
         uint32_t k = 1;
         while (k < 8u && c->S * k < 64u) k *= 2u;          /* 1 for >= 64 captures ... 8 for fewer than 16 */
-        c->C[1] = cfg->seg_len ? cfg->seg_len : 32768u / std::min(k, 4u);      /* one capture, r04: 9.3 / 8.8 / 7.7 ms per configs[1] push with 4096 / 8192 / 16384,
-                                                                                  9.5 / 9.0 / 10.5 for configs[2]: 8192 */
+        c->clk_form = cfg->clock_waves == 1u ? 1u : 4u;
+        if (c->clk_form != 4u)
+            c->C[1] = 32768u / std::min(k, 4u);            /* one capture, r04: 9.3 / 8.8 / 7.7 ms per configs[1] push with 4096 / 8192 / 16384, 9.5 / 9.0 / 10.5 for configs[2]: 8192 */
+        else
+            /* the systolic form walks a segment in 0.4 of the time (round 6, one capture of configs[1]: 5.6 / 4.9 / 4.25 / 5.8 ms per push with
+             * 8192 / 16384 / 32768 / 65536, against 7.6 with the one-wave form's 8192): 32768 whatever the batch size -- and 65536 where the
+             * demodulation kernel is the heavier side (exact arithmetic, 1.6 MS/s, no -s: the warm-ups of 12288 / 24576 samples are a quarter
+             * less work per sample; bench workload 181-187 against 174-181 Gsamples/s, tolerance mode 199 against 202, configs[2] 161 against 171) */
+            c->C[1] = c->S >= 64u && !cfg->tolerance_mode && cfg->decimation == 2u && !cfg->simultaneous ? 65536u : 32768u;
+        if (cfg->seg_len) c->C[1] = cfg->seg_len;
         /* run-length segments: 4096 (r04 A/B on the bench workload: 151.0 / 151.1 against 148.9 / 150.6 with round 3's 8192 and
          * 136.3 / 134.1 with 2048); 2048 with -s, where S1 telegrams -- 30-100 ms, several segments long -- are expected in both
          * chains and every segment inside one is re-run in a chain walk whose length is the telegram's whatever the segment
@@ -524,7 +532,7 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
         c->k1_big = c->rs_od && c->d == 2 && !(c->flags & WM_F_SHIFT) && !cfg->k1_small_tile;
         c->k1_tail_pm = cfg->tolerance_mode ? 0u : 60u;
         c->k1_tpb = cfg->k1_tiles_per_block ? std::min(cfg->k1_tiles_per_block, 64u) : WM_K1_TPB_DEFAULT;
-        c->clk_sys = cfg->clock_waves != 1u;
+        c->clk_form = cfg->clock_waves == 1u ? 1u : 4u;
         if (c->rs_od) { A(dalloc(&c->d_rs_flags, (size_t)c->ntiles_cap * c->S)); A(dalloc(&c->d_rs_list, (size_t)c->ntiles_cap * c->S)); }
     }
     const size_t stw[2] = {sizeof(WmRlaState), sizeof(WmClkState)};
@@ -743,7 +751,14 @@ static void fr_launch(wmbus_ctx *c, int algo, uint32_t cnt, hipStream_t st = nul
     /* (Round 5 tried a middle way for the clock kernel's first round: parallel, but a lane whose end state came out new carries it
      * on into an UNLISTED successor.  The second round shrank from 7 to 4 lanes and the job lost 1.8 %: 170.0 against 173.1.) */
     /* list launches: blocks for 3/16 of the lanes (a re-run list is a few percent of them; the blocks walk whatever is more) */
-    if (algo == WMBUS_ALGO_T2A && c->clk_sys) {
+#ifdef WM_DBG_SKIP_CLOCK                                      /* timing experiment only (tools/build_variant.sh): from the fourth push on no clock-recovery launch at all --
+                                                             * what the clock kernels' place on the GPU costs the rest of the job.  The output is wrong. */
+    if (algo == WMBUS_ALGO_T2A && c->push_seq > 3) return;
+#endif
+#ifdef WM_DBG_SKIP_RLA
+    if (algo == WMBUS_ALGO_RLA && c->push_seq > 3) return;
+#endif
+    if (algo == WMBUS_ALGO_T2A && c->clk_form == 4u) {
         /* the systolic form: a block of four waves per 64 lanes (wm_k2_clock_sys.h); list launches as below: blocks for 3/16 of the lanes */
         const uint32_t grid = all ? (lanes + 63u) / 64u : std::max(64u, (lanes / 64u) * 3u / 16u);
         if (all) {

@@ -188,26 +188,6 @@ __device__ __forceinline__ void clk_block32(WmClkState &s, const IirCoef &c, con
  * WM_CLK_XROW).  Lane-private 16-byte loads of the same data touch 64 lines per instruction and
  * re-fetch each line from L2 several times.  Re-run launches and odd stream counts take the
  * lane-private path. */
-/* The same block, one sample after the other (clk_step): a 36-deep dependent chain per sample instead
- * of three interleaved ones, but a fraction of the registers.  Candidate for the few re-run lanes of the
- * fused launch (k2_clock_rla), whose register need is also what its thousand run-length waves are
- * charged; selected with WM_FUSED_LEAN_CLOCK (off: not measured yet).  Host-emulated against the oracle. */
-template <bool DC>
-__device__ __forceinline__ void clk_block32_lean(WmClkState &s, const IirCoef &c, const float *xrow, uint32_t &bitw, uint32_t &smask)
-{
-    uint32_t bw = 0, sm = 0, hist = s.clk;
-#pragma unroll 1
-    for (uint32_t k = 0; k < 32u; k++) {
-        float soft;
-        const uint32_t high = clk_step(s, c, DC, xrow[k], soft);
-        hist = ((hist << 1) | high) & 0xFu;
-        bw |= (uint32_t)(soft >= 0.0f) << k;
-        sm |= (uint32_t)(hist == 7u) << k;
-    }
-    s.clk = hist & 7u;
-    bitw = bw; smask = sm;
-}
-
 template <int W> struct ClkLds {         /* per block: W independent waves */
     float x[W][64 * WM_CLK_XROW];
     uint32_t chip[W][64 * WM_CLK_CROW];
@@ -226,7 +206,7 @@ template <int W> struct ClkLds {         /* per block: W independent waves */
  * st_final), 1 when a re-run left early at a checkpoint it reproduced (the end state in st_final was exact already), 2 when
  * there was nothing to do.  `from` (with have_from): the exact state a re-run starts from when the caller has it at hand (else: the
  * predecessor's record / the carried state).  By value, not by pointer: a pointer that may name the caller's `fin` kept both in scratch. */
-template <bool DC, int W, bool LEAN, int PASS>
+template <bool DC, int W, int PASS>
 __device__ __forceinline__ int clock_segment(const K2Args &a, ClkLds<W> &lds, const uint32_t wv, const uint32_t ln, const bool rerun,
                                              const uint32_t ch, const uint32_t stream, const uint32_t seg, const bool have_from, const WmClkState &from, WmClkState &fin)
 {
@@ -334,8 +314,7 @@ __device__ __forceinline__ int clock_segment(const K2Args &a, ClkLds<W> &lds, co
         put_x(gx);
         fetch_x(gx, min(m + AHEAD, m_last));
         uint32_t bitw, smask;
-        if (LEAN) clk_block32_lean<DC>(s, c, xrow, bitw, smask);
-        else if (warm_short && mb - m > (uint32_t)WM_CLK_SR_WINDOW + 32u) clk_block32<DC, true>(s, c, xrow, bitw, smask);
+        if (warm_short && mb - m > (uint32_t)WM_CLK_SR_WINDOW + 32u) clk_block32<DC, true>(s, c, xrow, bitw, smask);
         else clk_block32<DC>(s, c, xrow, bitw, smask);
         /* shift-register upkeep: at most 8 chips per block, oldest first; the wave stops as soon as none of its lanes
          * has a chip left (T1/C1 lanes meet 4 per block, S1 lanes 1.3: half the trips of the fixed eight).  The register
@@ -389,7 +368,7 @@ __device__ __forceinline__ int clock_segment(const K2Args &a, ClkLds<W> &lds, co
         put_x(gx);
         fetch_x(gx, min(m + AHEAD, m_last));
         uint32_t bitw, smask;
-        if (LEAN) clk_block32_lean<DC>(s, c, xrow, bitw, smask); else clk_block32<DC>(s, c, xrow, bitw, smask);
+        clk_block32<DC>(s, c, xrow, bitw, smask);
         uint32_t cnt = 0;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
@@ -509,11 +488,11 @@ __device__ __forceinline__ int clock_segment(const K2Args &a, ClkLds<W> &lds, co
  * its own in this launch (listed behind an unlisted one), which the next round sorts out.  (Walking chains already in the
  * first list round made it 2.8 ms longer on the bench workload: neighbours that are both listed usually both leave at an
  * early checkpoint, and serialising them doubles the longest lane.) */
-template <bool DC, int W, bool LEAN = false, int PASS = 2>
+template <bool DC, int W, int PASS = 2>
 __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t block, ClkLds<W> &lds)
 {
     const uint32_t ln = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    if (wv >= (uint32_t)W) return;           /* W < waves of the block: the fused launch (see k2_clock_rla) */
+    if (wv >= (uint32_t)W) return;
     uint32_t lane = (block * W + wv) * 64 + ln;
     const bool rerun = PASS == 2 ? a.list != nullptr : PASS == 1;
     const WmPush &g = a.g;
@@ -524,14 +503,14 @@ __device__ __forceinline__ void clock_lanes(const K2Args &a, const uint32_t bloc
     if (!(g.flags & (ch ? WM_F_S1 : WM_F_T1C1))) return;
     WmClkState fin, from{};
     const bool chains = rerun && a.bad != nullptr && !(ch == 1u && g.s1_span == 2u);
-    if (!chains) { clock_segment<DC, W, LEAN, PASS>(a, lds, wv, ln, rerun, ch, stream, seg, false, from, fin); return; }
+    if (!chains) { clock_segment<DC, W, PASS>(a, lds, wv, ln, rerun, ch, stream, seg, false, from, fin); return; }
     const uint64_t row = (uint64_t)ch * g.S + stream;
     const uint32_t *bad = a.bad + (uint64_t)ch * g.nseg_cap[1] * g.S + stream;       /* verdict of segment j at bad[j * S] */
     const WmClkState *stS = (const WmClkState *)a.st_start, *stF = (const WmClkState *)a.st_final;
     if (seg > 0u && bad[(uint64_t)(seg - 1u) * g.S]) return;            /* the head of my run covers me */
     bool have_from = false;
     for (;;) {
-        const int how = clock_segment<DC, W, LEAN, PASS>(a, lds, wv, ln, true, ch, stream, seg, have_from, from, fin);
+        const int how = clock_segment<DC, W, PASS>(a, lds, wv, ln, true, ch, stream, seg, have_from, from, fin);
         const uint64_t sidx = row * g.nseg_cap[1] + seg;
         if (how == 1) fin = stF[sidx];                     /* left at a checkpoint: the recorded end state was exact */
         if (how == 2 || seg + 1u >= g.nseg[1]) return;
@@ -548,7 +527,7 @@ __global__ __launch_bounds__(64 * WM_CLK_WPB) void k2_clock(K2Args a)           
 {
     wm_framer_prio();
     __shared__ __attribute__((aligned(16))) ClkLds<WM_CLK_WPB> lds;
-    clock_lanes<DC, WM_CLK_WPB, false, 0>(a, blockIdx.x, lds);
+    clock_lanes<DC, WM_CLK_WPB, 0>(a, blockIdx.x, lds);
 }
 
 template <bool DC>
@@ -557,7 +536,7 @@ __global__ __launch_bounds__(64 * WM_CLK_WPB) void k2_clock_list(K2Args a)      
     wm_framer_prio();
     __shared__ __attribute__((aligned(16))) ClkLds<WM_CLK_WPB> lds;
     const uint32_t n = k2_lane_count(a);
-    for (uint32_t b = blockIdx.x; (uint64_t)b * (64u * WM_CLK_WPB) < n; b += gridDim.x) clock_lanes<DC, WM_CLK_WPB, false, 1>(a, b, lds);
+    for (uint32_t b = blockIdx.x; (uint64_t)b * (64u * WM_CLK_WPB) < n; b += gridDim.x) clock_lanes<DC, WM_CLK_WPB, 1>(a, b, lds);
 }
 
 #endif /* WM_K2_CLOCK_H */

@@ -219,7 +219,10 @@ __device__ __forceinline__ void clock_sys_group(const K2Args &a, const uint32_t 
              * first half's arithmetic, second half into registers -- the row is free --, the next block takes its place and the one
              * after the next is asked for, then the second half's arithmetic hides both */
             wm_f4 xa[4], xb[4];
-            if (has) {
+#ifndef WM_SYS_R0_TAIL
+#define WM_SYS_R0_TAIL 0        /* 1 (A/B): both halves and the staging behind barrier A, staging last */
+#endif
+            if (has && !WM_SYS_R0_TAIL) {
 #pragma unroll
                 for (int q = 0; q < 4; q++) xa[q] = *(const wm_f4 *)(xrow + 4 * q);
             }
@@ -229,12 +232,18 @@ __device__ __forceinline__ void clock_sys_group(const K2Args &a, const uint32_t 
                 const uint32_t m = G.m0 + 32u * b;
                 const bool last = b + 1u == G.nb, warm = sys_warm_short(G, m);
                 uint32_t sgn = 0;
+                if (WM_SYS_R0_TAIL) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) xa[q] = *(const wm_f4 *)(xrow + 4 * q);
+                }
                 if (warm) sys_r0_half16<DC, true, 0>(h1, h2, dcx, dcy, c, xa, hop_out, sgn); else sys_r0_half16<DC, false, 0>(h1, h2, dcx, dcy, c, xa, hop_out, sgn);
+                if (WM_SYS_R0_TAIL) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int q = 0; q < 4; q++) xb[q] = *(const wm_f4 *)(xrow + 16 + 4 * q);
                 WM_SYS_MARK(1);
-                if (!last) { stage(mine); fetch(mine, m + 96u); }
+                if (!last && !WM_SYS_R0_TAIL) { stage(mine); fetch(mine, m + 96u); }
                 if (warm) sys_r0_half16<DC, true, 1>(h1, h2, dcx, dcy, c, xb, hop_out, sgn); else sys_r0_half16<DC, false, 1>(h1, h2, dcx, dcy, c, xb, hop_out, sgn);
+                if (!last && WM_SYS_R0_TAIL) { __builtin_amdgcn_sched_barrier(0); stage(mine); fetch(mine, m + 96u); }
                 lds.bitw[b & 3u][ln] = warm ? 0u : ~__builtin_bitreverse32(sgn);
                 if (last || sys_snap0(G, m, nck)) {
                     uint32_t (*sn)[64] = lds.snap[last ? 1 : 0];
@@ -331,19 +340,31 @@ __device__ __forceinline__ void clock_sys_group(const K2Args &a, const uint32_t 
             n_fl = 0; pend = 0; saw_sync = 0;
             if (G.m0 == G.mb) stS[G.sidx] = s;
         };
-        auto flush8 = [&]() WM_LAMBDA_INLINE {                /* chips leave in whole, 32-byte aligned groups of 8 (clock_segment); n_fl is a multiple of 8 */
+        /* Chips leave in whole, 32-byte aligned groups of 8 (clock_segment); n_fl is a multiple of 8.  A group that fills up in the middle of
+         * a segment is only READ here (fl_w); its two stores are issued at the top of the lane's next block (put_group), when the words have
+         * long arrived -- read-then-store on the spot was a full LDS round trip in every block of a T1/C1 wave, whose 64 lanes between
+         * them fill a group nearly every block. */
+        uint32_t fl_w[8], fl_at = 0xFFFFFFFFu;
+        auto put_group = [&]() WM_LAMBDA_INLINE {
+            if (fl_at != 0xFFFFFFFFu) {
+                *(uint4 *)(out + fl_at) = make_uint4(fl_w[0], fl_w[1], fl_w[2], fl_w[3]);
+                *(uint4 *)(out + fl_at + 4) = make_uint4(fl_w[4], fl_w[5], fl_w[6], fl_w[7]);
+                fl_at = 0xFFFFFFFFu;
+            }
+        };
+        auto take_group = [&]() WM_LAMBDA_INLINE {
             const uint32_t *h = my_chip + (n_fl & 8u);
-            uint32_t w[8];
 #pragma unroll
-            for (int i = 0; i < 8; i++) w[i] = h[i];
-            *(uint4 *)(out + n_fl) = make_uint4(w[0], w[1], w[2], w[3]);
-            *(uint4 *)(out + n_fl + 4) = make_uint4(w[4], w[5], w[6], w[7]);
+            for (int i = 0; i < 8; i++) fl_w[i] = h[i];
+            fl_at = n_fl;
             n_fl += 8u; pend = pend > 8u ? pend - 8u : 0u;
         };
+        auto flush8 = [&]() WM_LAMBDA_INLINE { put_group(); take_group(); put_group(); };
         /* the end of a segment (its last whole block done, or none to do): ragged tail, end record, count -- clock_segment's epilogue */
         auto end_segment = [&]() WM_LAMBDA_INLINE {
             uint32_t n_out = n_fl + pend;
             const uint32_t cap_t2 = g.cap[1];
+            put_group();
             if (pend) flush8();                              /* last group; slots beyond n_out are never read */
             if (G.me_full < G.me) {
                 const float *x = a.dphi + G.row * g.Mcap;
@@ -408,7 +429,8 @@ __device__ __forceinline__ void clock_sys_group(const K2Args &a, const uint32_t 
             const uint32_t b = step - b0 - 3u;
             const bool has0 = active && b < G.nb;
             wm_f4 in[8];
-            if (has0) sys_hop_read(hop_in, in);
+            uint32_t bitw = 0;                               /* the block's slicer word comes with its input: nothing in the block waits for LDS */
+            if (has0) { sys_hop_read(hop_in, in); bitw = lds.bitw[b & 3u][ln]; }
             uint32_t cw = sys_control<PASS>(lds, step, ln, valid, b0, G.nb);
             if (COOP) cw = wm_uniform(cw);
             cmd = WM_SYS_NONE;
@@ -430,7 +452,6 @@ __device__ __forceinline__ void clock_sys_group(const K2Args &a, const uint32_t 
                     else {
                         uint32_t smask;
                         sys_r3_block32(g1, g2, s.clk, c, in, smask);
-                        const uint32_t bitw = lds.bitw[b & 3u][ln];
                         if (WM_CLK_SR_WINDOW && G.mb - m > (uint32_t)WM_CLK_SR_WINDOW) smask = 0u;
 #pragma unroll
                         for (int i = 0; i < 8; i++) {
@@ -447,8 +468,8 @@ __device__ __forceinline__ void clock_sys_group(const K2Args &a, const uint32_t 
                     /* ---- block of the segment proper: chips into the staging row, whole groups to memory ---- */
                     uint32_t smask;
                     sys_r3_block32(g1, g2, s.clk, c, in, smask);
-                    const uint32_t bitw = lds.bitw[b & 3u][ln];
                     uint32_t cnt = 0;
+                    put_group();                             /* the group that filled up a block ago */
 #pragma unroll
                     for (int i = 0; i < 8; i++) {
                         const bool hs = smask != 0u;
@@ -464,7 +485,7 @@ __device__ __forceinline__ void clock_sys_group(const K2Args &a, const uint32_t 
                         cnt += hs;
                     }
                     pend += t2a ? cnt : 0u;
-                    if (pend >= 8u) flush8();
+                    if (pend >= 8u) take_group();
                     if (last) { gather(1); end_segment(); cmd = after_segment(false); active = false; }
                     else if (sys_snap0(G, m, nck)) {
                         /* ---- interior checkpoint j: recorded by the first pass, met again by a re-run (clock_segment) ---- */
@@ -482,6 +503,7 @@ __device__ __forceinline__ void clock_sys_group(const K2Args &a, const uint32_t 
                             if (same && n1 <= n0) {
                                 /* back on the speculative pass's trajectory: everything it produced from here on is exact already.  My chips
                                  * replace its first n0; if they are fewer, its tail moves down. */
+                                put_group();
                                 for (uint32_t i = 0; i < pend; i++) out[n_fl + i] = ring(n_fl + i);
                                 if (n1 < n0) {
                                     const uint32_t total0 = a.counts[G.sidx];

@@ -49,7 +49,6 @@ void *wm_emu_states_out = nullptr;        /* optional: receives st_start then st
 int wm_emu_descending = 1;
 int wm_emu_s1_span = 0;                   /* WmPush.s1_span of the next calls */
 uint32_t *wm_emu_seen_out = nullptr;      /* optional: receives the per-region "access-code chip seen" flags */
-int wm_emu_lean_reruns = 0;
 int wm_emu_chains = 1;                    /* K2Args.bad: a listed lane walks its chain (round 4); 0: every listed segment on its own */
 
 /* One push of M decimated samples for S captures.  dphi: [2][S][Mcap] soft symbols; carry: [2][S]
@@ -79,7 +78,7 @@ long wm_emu_clock(const float *dphi, uint32_t S, uint32_t M, uint32_t Mcap, uint
     const bool dc = flags & WM_F_DC;
     auto launch = [&](const uint32_t *lst, uint32_t n) {
         a.list = lst; a.n_lanes = n;
-        if (wm_emu_sys) {
+        if (wm_emu_sys == 1) {
             /* four coroutines per lane; the chunks of a launch in descending or ascending order (see below) */
             const uint32_t groups = (n + 63u) / 64u;
             for (uint32_t i = 0; i < groups; i++) {
@@ -107,10 +106,7 @@ long wm_emu_clock(const float *dphi, uint32_t S, uint32_t M, uint32_t Mcap, uint
         for (uint32_t i = 0; i < n; i++) {
             const uint32_t l = wm_emu_descending ? n - 1 - i : i;
             threadIdx.x = l & 63u;
-            /* re-run launches may use the lean per-sample block (candidate for the fused launch) */
-            const bool lean = wm_emu_lean_reruns && lst != nullptr;
-            if (dc) { if (lean) clock_lanes<true, 1, true>(a, l >> 6, lds); else clock_lanes<true, 1>(a, l >> 6, lds); }
-            else { if (lean) clock_lanes<false, 1, true>(a, l >> 6, lds); else clock_lanes<false, 1>(a, l >> 6, lds); }
+            if (dc) clock_lanes<true, 1>(a, l >> 6, lds); else clock_lanes<false, 1>(a, l >> 6, lds);
         }
     };
     launch(nullptr, lanes);

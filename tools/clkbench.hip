@@ -113,9 +113,11 @@ template <int PRIO> __global__ __launch_bounds__(256) void k_sys(const float *x,
             }
             wm_sys_barrier(); mark(cb);
             if (b < nblk) {
-                uint32_t bitw;
-                sys_r0_block32<false, false>(h1, h2, dcx, dcy, c, in, lds.hop[0] + 4u * ln, bitw);
-                lds.bitw[b & 3u][ln] = bitw;
+                uint32_t sgn = 0;
+                const wm_f4 (&lo)[4] = *(const wm_f4 (*)[4])&in[0], (&hi)[4] = *(const wm_f4 (*)[4])&in[4];
+                sys_r0_half16<false, false, 0>(h1, h2, dcx, dcy, c, lo, lds.hop[0] + 4u * ln, sgn);
+                sys_r0_half16<false, false, 1>(h1, h2, dcx, dcy, c, hi, lds.hop[0] + 4u * ln, sgn);
+                lds.bitw[b & 3u][ln] = ~__builtin_bitreverse32(sgn);
             }
             mark(cw); wm_sys_barrier(); mark(cb); b++;
         };

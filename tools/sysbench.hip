@@ -65,7 +65,7 @@ int main(int argc, char **argv)
         CK(hipMemcpy(counts.data(), d_counts, counts.size() * 4, hipMemcpyDeviceToHost));
         uint64_t total = 0; for (uint32_t v : counts) total += v;
         const uint32_t blocks_t1 = (seg_len + 12288) / 32, blocks_s1 = (seg_len + 24576) / 32;
-        printf("%s: %.3f ms for %u lanes (segments of %u): %.3f us per block of the longest lane (%u blocks; T1/C1 lanes: %u); %llu chips\n", form ? "systolic" : "one wave",
+        printf("%s: %.3f ms for %u lanes (segments of %u): %.3f us per block of the longest lane (%u blocks; T1/C1 lanes: %u); %llu chips\n", form == 0 ? "one wave" : "systolic",
                ms, lanes, seg_len, ms * 1e3 / blocks_s1, blocks_s1, blocks_t1, (unsigned long long)total);
         if (form == 0) chips_one = counts;
         else if (chips_one != counts) printf("  !! the two forms' chip counts differ\n");
