@@ -168,6 +168,35 @@ def leg_single_stream(wm, O, name, n, kw, okw, synth_kw, reps=7):
             "reruns": {k: tim[k] for k in ("clock_reruns", "rla_reruns", "ema_retries", "slow_path")}}
 
 
+def leg_live_latency(wm, O, device, sizes=(1 << 16, 1 << 18, 1 << 20, 1 << 22), reps=9):
+    """configs[1] seen from the live path (/root/reference/README.md:64-73, rtl_wmbus.c:1298-1308): ONE 1.6 MS/s
+    stream, default switches, pushed in pieces of 2^16 ... 2^22 IQ samples -- wall clock per push (process + collect) and the
+    stages' HIP-event times, median over the pushes of a 2^23-sample capture fed `reps` pieces at a time; the whole text of every
+    run against the oracle fed the same pieces' worth of input."""
+    n_total = 1 << 23
+    cu8 = wm.synth_capture(n_samples=n_total, seed=0xC2C2, kinds=wm.T1 | wm.C1A | wm.C1B, frames_per_s=20.0)[0]
+    rows = {}
+    for n in sizes:
+        pushes = min(reps + 1, n_total // n)
+        want = O.run(cu8[: 2 * n * pushes], O.make_opts())["text"]
+        with wm.Receiver(n_streams=1, max_push_bytes=2 * n, keep_taps=False, device=device) as rx:
+            got, ms, tims = "", [], []
+            for k in range(pushes):
+                t = time.perf_counter()
+                rx.stage(0, cu8[2 * n * k: 2 * n * (k + 1)])     # from pageable host memory: what a live reader hands over
+                rx.process(2 * n)
+                got += rx.collect()
+                if k:                                         # the first push also loads code objects and sizes pools
+                    ms.append((time.perf_counter() - t) * 1e3)
+                    tims.append(rx.timing())
+        med = lambda v: round(sorted(v)[len(v) // 2], 3)
+        rows[str(n)] = {"ms_per_push": med(ms), "x_real_time": round(n / 1.6e6 / (med(ms) * 1e-3), 1), "parity_ok": got == want,
+                        "clock_ms": med([t["clock_ms"] for t in tims]), "rla_ms": med([t["rla_ms"] for t in tims]),
+                        "burst_ms": med([t["gather_ms"] for t in tims]), "demod_ms": med([t["demod_ms"] for t in tims]),
+                        "host_decode_ms": med([t["host_decode_ms"] for t in tims])}
+    return {"workload": "configs[1] live path: one 1.6 MS/s stream, default switches, input staged from host memory per push", "by_samples_per_push": rows}
+
+
 def leg_c3_batch(wm, O, shard, S, n, device, steps, **tune):
     """configs[2] at batch size (informational): S captures at 4.0 MS/s through `-d 5 -s` (both chains fed from the +-325 kHz
     translation), resident in HBM.  Rate, the demodulation kernel alone, 16 captures' first pass against the oracle."""
@@ -605,6 +634,7 @@ def main():
             ("c3_single_stream", lambda: leg_single_stream(wm, O, "configs[2]: one 4.0 MS/s capture, -d 5 -s, S1 + T1 + C1 concurrently, HBM-resident", n,
                                                            dict(device=local, decimation=5, simultaneous=True), dict(decimation=5, simultaneous=1),
                                                            dict(seed=0xC3C3, fs_khz=4000, kinds=15, frames_per_s=50.0, t1c1_center_khz=325.0, s1_center_khz=-325.0))),
+            ("live_latency", lambda: leg_live_latency(wm, O, local)),
             ("c3_batch", lambda: leg_c3_batch(wm, O, shard, S, n, local, max(3, a.steps // 4))),
             ("cli", lambda: leg_cli(wm)),
             ("cli_1024", lambda: leg_cli(wm, n_files=1024)),
@@ -658,7 +688,7 @@ def main():
         }
         if tol is not None:
             out["tolerance_mode_leg"] = tol
-        for key in ("c2_single_stream", "c3_single_stream", "c3_batch", "cli", "cli_1024"):
+        for key in ("c2_single_stream", "c3_single_stream", "live_latency", "c3_batch", "cli", "cli_1024"):
             if key in legs:
                 out[key] = legs[key]
         if "cli" not in legs:                                  # not measured in this run: say where the number comes from
@@ -718,6 +748,10 @@ def main():
             if key in legs:
                 sm[short] = legs[key].get("value")
                 sm[short + "_ok"] = legs[key].get("parity_ok", legs[key].get("error", "")[:60] if legs[key].get("error") else None)
+        if "live_latency" in legs and "by_samples_per_push" in legs["live_latency"]:
+            ll = legs["live_latency"]["by_samples_per_push"]
+            sm["c2_ms"] = {k: v["ms_per_push"] for k, v in ll.items()}          # ms per push of 2^16 ... 2^22 samples of one live stream
+            sm["c2_ms_ok"] = all(v["parity_ok"] for v in ll.values())
         if "c3_batch" in legs:
             cb3 = legs["c3_batch"]
             sm["c3_batch"] = cb3.get("value")

@@ -216,15 +216,18 @@ enum { WM_MAX_DEVICES = 64 };                    /* per-device tables (K1 order,
  * workload: clock re-runs 1400, then < 10, then 0; run-length 2300, then 0; a third costs every push 0.2 ms of empty launches).
  * A small batch is bound by its chain of dependent launches and by every host round trip in it, and its short segments
  * (wmbus_open) cascade further: it enqueues more rounds, so that the host-driven path (0.5 ms per round) stays the exception. */
-enum { WM_MAX_ROUNDS = 6 };
+enum { WM_MAX_ROUNDS = 6 };                      /* counters per kind of round: rounds + 1 <= 8 slots of the SC_* layout below (the run-length framer's
+                                                    index runs to rla_rounds <= WM_MAX_ROUNDS + 1) */
+/* bounded grids of the burst kernels and of the RSSI launch over the listed tiles (launch_k3) */
 #ifndef WM_K3_BLOCKS
 #define WM_K3_BLOCKS 64           /* build-time A/B (tools/build_variant.sh): r02 256 -> 64 blocks + 6 %, 16 blocks - 9 % */
 #endif
 enum { WM_RS_BLOCKS = 2048 };
-enum { WM_K1_TPB_DEFAULT = 2 };                /* tiles per block of the demodulation kernel's first pass (RSSI on demand), see enqueue_front_impl */   /* bounded grids of the burst kernels and of the RSSI launch over the listed tiles (launch_k3) */                     /* counters per kind: rounds + 1 <= 8 (SC_* below) */
+enum { WM_K1_TPB_DEFAULT = 2 };                /* tiles per block of the demodulation kernel's first pass (RSSI on demand), see enqueue_front_impl */
 enum { SC_ERR = 0, SC_NHITS = 1, SC_NHDR = 2, SC_NWORDS = 3, SC_NPKTS = 4, SC_NBYTES = 5, SC_SLOW = 6, SC_CHIPS = 8 /* [algo][chain] */,
        SC_RS_N = 12 /* tiles listed for the RSSI-on-demand launch */, SC_RS_FAIL = 13 /* a lane that is read could not prove its value */,
        SC_EMA = 16 /* [ema_rounds + 1] */, SC_CLK = 24 /* [fr_rounds + 1] */, SC_RLA = 32 /* [rla_rounds + 1] */, SC_COUNT = 40 };
+static_assert(WM_MAX_ROUNDS + 2 <= 8 && SC_RLA + WM_MAX_ROUNDS + 2 <= SC_COUNT, "every kind of round keeps its counters inside its eight SC_* slots");
 
 /* 4096 bytes per capture from src + row * sstride + soff to dst + row * dstride (256 threads x 16 bytes).  The input
  * history: the last 4096 staged bytes of a push are put aside (d_hist) when the push is enqueued and placed in front of
@@ -1423,7 +1426,8 @@ long wmbus_read_chips(wmbus_ctx *c, int chain, int algo, unsigned stream, uint32
     /* a context without debug views computes the RSSI only in the tiles a packet decoder reads (RSSI on demand): elsewhere its rows hold
      * nothing, so this view shows 0 there instead of what an earlier push left */
     hipLaunchKernelGGL(k4_flatten, dim3(1), dim3(1), 0, c->stream, c->last, (uint32_t)algo, c->d_chips[algo], c->d_counts[algo],
-                       c->rs_od ? (const uint8_t *)nullptr : c->d_rssi, c->cap[algo], (uint32_t)chain, stream, d_dst, d_pos, (uint32_t)max_elems, d_n);
+                       /* no RSSI row where the last push computed it on demand only (a paused or fallen-back push ran the full pass: the row is valid) */
+                       c->rs_this && !c->rs_full_now ? (const uint8_t *)nullptr : c->d_rssi, c->cap[algo], (uint32_t)chain, stream, d_dst, d_pos, (uint32_t)max_elems, d_n);
     uint32_t n = 0;
     hipStreamSynchronize(c->stream);
     hipMemcpy(&n, d_n, 4, hipMemcpyDeviceToHost);

@@ -75,7 +75,7 @@ void batch_worker(wmbus_batch *b, unsigned i, const wmbus_batch_io *io, BatchTot
         if (n > pitch || n % WMBUS_BLOCK_BYTES) { batch_fail(b, WMBUS_EINVAL, "batch: the source returned %zu bytes (multiple of 4096, at most %zu)", n, pitch); return 0; }
         if (!io->self_staged) {
 #ifndef WM_STAGE_PER_STREAM
-            if (wm_stage_all(c, b->slab[i], pitch, n)) { batch_fail(b, WMBUS_EDEVICE, "batch: context %u: %s", i, c->err); return 0; }
+            { const int src = wm_stage_all(c, b->slab[i], pitch, n); if (src) { batch_fail(b, src, "batch: context %u: %s", i, c->err); return 0; } }      /* the code as it came (an argument error is not a device error) */
 #else                                                       /* one copy per stream (until round 5; A/B) */
             for (unsigned s = 0; s < S; s++)
                 if (wmbus_stage(c, s, b->slab[i] + (size_t)s * pitch, n)) { batch_fail(b, WMBUS_EDEVICE, "batch: context %u: %s", i, c->err); return 0; }
@@ -176,22 +176,30 @@ int wmbus_batch_open(const wmbus_cfg *cfg, unsigned contexts, wmbus_batch **out)
     const unsigned nctx = wmbus_batch_plan(cfg, contexts, plan.data(), S);
     unsigned hw = std::thread::hardware_concurrency();
     if (hw == 0) hw = 16;
+    /* the contexts are opened side by side (round 6: one after the other it was 0.06 s each -- allocations, page-locked result areas,
+     * initial fills --, 0.3 s of a 320-file batch that decodes in 0.23 s) */
+    std::vector<wmbus_ctx *> opened(nctx, nullptr);
+    std::vector<int> rcs(nctx, 0);
+    std::vector<std::thread> openers;
+    for (unsigned i = 0; i < nctx; i++)
+        openers.emplace_back([&, i] {
+            wmbus_cfg cc = *cfg;
+            cc.n_streams = plan[i];
+            /* host decoder threads: the contexts decode at different times, so the box is shared 2 x oversubscribed */
+            if (cc.host_threads == 0) cc.host_threads = std::max(2u, std::min(16u, 2u * hw / std::max(1u, nctx)));
+            rcs[i] = wmbus_open(&cc, &opened[i]);
+        });
+    for (auto &t : openers) t.join();
+    for (unsigned i = 0; i < nctx; i++)
+        if (rcs[i]) {
+            batch_fail(b, rcs[i], "batch: context %u of %u (%u captures): %s", i, nctx, plan[i], opened[i] ? opened[i]->err : "out of memory");
+            for (wmbus_ctx *c : opened) wmbus_close(c);
+            return rcs[i];
+        }
     unsigned at = 0;
     for (unsigned i = 0; i < nctx; i++) {
-        const unsigned n = plan[i];
-        wmbus_cfg cc = *cfg;
-        cc.n_streams = n;
-        /* host decoder threads: the contexts decode at different times, so the box is shared 2 x oversubscribed */
-        if (cc.host_threads == 0) cc.host_threads = std::max(2u, std::min(16u, 2u * hw / std::max(1u, nctx)));
-        wmbus_ctx *c = nullptr;
-        const int rc = wmbus_open(&cc, &c);
-        if (rc) {
-            batch_fail(b, rc, "batch: context %u of %u (%u captures): %s", i, nctx, n, c ? c->err : "out of memory");
-            wmbus_close(c);
-            return rc;
-        }
-        b->ctx.push_back(c); b->first.push_back(at); b->count.push_back(n);
-        at += n;
+        b->ctx.push_back(opened[i]); b->first.push_back(at); b->count.push_back(plan[i]);
+        at += plan[i];
     }
     b->slab.assign(nctx, nullptr);
     b->opened = true;

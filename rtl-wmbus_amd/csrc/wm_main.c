@@ -51,6 +51,7 @@ static void print_usage(const char *prog)
     fprintf(stdout, "\t-s receive S1 and T1/C1 datagrams simultaneously. rtl_sdr _MUST_ be set to 868.625MHz (-f 868.625M)\n");
     fprintf(stdout, "\t-p [T,S] to disable processing T1/C1 or S1 mode\n");
     fprintf(stdout, "\t-f exit if flow of incoming data stops\n");
+    fprintf(stdout, "\t   (this back end decimates by 1 ... 16: -d 17 and beyond, which the reference accepts, are refused)\n");
     fprintf(stdout, "\t-B bytes per GPU push (multiple of 4096; default 1048576 for a live stream; per file in batch mode 2097152, 1048576 from 384 files per GPU on)\n");
     fprintf(stdout, "\t-L ms a live stream's bytes wait at most this long for their push to fill (default 50; 0: only full pushes)\n");
     fprintf(stdout, "\t-S batch mode: print samples, seconds and Msamples/s to stderr\n");
@@ -118,7 +119,7 @@ static void report_warnings(unsigned warnings, unsigned *told)
  * The files of a group are read by several threads side by side: one thread copies page-cache bytes into the page-locked slab
  * at 5-6 GB/s, a context's push of 128 x 2 MiB then takes 43 ms to read against 12 ms on the GPU, and the whole program ran
  * at the readers' 4-8 x 6 GB/s instead of the link's 50 (round 4: 12.9 Gsamples/s over 256 files, 16-17 over 1024). */
-struct fill_part { struct batch_job *j; unsigned first, k0, k1; uint8_t *slab; size_t pitch, cap; size_t *got; };
+struct fill_part { struct batch_job *j; unsigned first, k0, k1; uint8_t *slab; size_t pitch, cap; size_t *got; struct fill_part *next; unsigned *left; };
 
 static void *fill_part_run(void *p)
 {
@@ -133,6 +134,42 @@ static void *fill_part_run(void *p)
     return NULL;
 }
 
+/* The readers are a pool that lives as long as the process (up to 15 threads were created and joined in EVERY fill
+ * call, thousands of times per batch, inside the out-of-GPU critical path).  A fill call -- several may run at once, one per context --
+ * queues its parts, works on the queue itself and waits for its own parts' count to reach zero. */
+static struct { pthread_mutex_t m; pthread_cond_t work, done; struct fill_part *head; unsigned threads; } pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, NULL, 0};
+
+static struct fill_part *pool_take(void) { struct fill_part *q = pool.head; if (q) pool.head = q->next; return q; }      /* pool.m held */
+static void pool_finish(struct fill_part *q)                                                                               /* pool.m held */
+{
+    if (--*q->left == 0) pthread_cond_broadcast(&pool.done);
+}
+static void *pool_worker(void *unused)
+{
+    (void)unused;
+    pthread_mutex_lock(&pool.m);
+    for (;;) {
+        struct fill_part *q = pool_take();
+        if (!q) { pthread_cond_wait(&pool.work, &pool.m); continue; }
+        pthread_mutex_unlock(&pool.m);
+        fill_part_run(q);
+        pthread_mutex_lock(&pool.m);
+        pool_finish(q);
+    }
+    return NULL;
+}
+static void pool_grow(unsigned want)       /* detached workers, started on first use; fewer than asked for is fine (the caller works too) */
+{
+    pthread_mutex_lock(&pool.m);
+    while (pool.threads < want && pool.threads < 64u) {
+        pthread_t th;
+        if (pthread_create(&th, NULL, pool_worker, NULL)) break;
+        pthread_detach(th);
+        pool.threads++;
+    }
+    pthread_mutex_unlock(&pool.m);
+}
+
 static size_t batch_fill_padded(void *user, unsigned first, unsigned n, uint8_t *slab, size_t pitch, size_t cap)
 {
     struct batch_job *j = user;
@@ -143,13 +180,26 @@ static size_t batch_fill_padded(void *user, unsigned first, unsigned n, uint8_t 
     if (T > 16u) T = 16u;
     if (n < 2u * T) T = 1u;
     struct fill_part part[16];
-    pthread_t th[16];
-    unsigned started = 0;
-    for (unsigned t = 0; t < T; t++) part[t] = (struct fill_part){j, first, (unsigned)((uint64_t)n * t / T), (unsigned)((uint64_t)n * (t + 1) / T), slab, pitch, cap, got};
-    for (unsigned t = 1; t < T; t++) { if (pthread_create(&th[t], NULL, fill_part_run, &part[t])) break; started = t; }
+    unsigned left = T;
+    for (unsigned t = 0; t < T; t++) part[t] = (struct fill_part){j, first, (unsigned)((uint64_t)n * t / T), (unsigned)((uint64_t)n * (t + 1) / T), slab, pitch, cap, got, NULL, &left};
+    if (T > 1u) {
+        pool_grow(8u * (T - 1u));                            /* readers for the contexts that fill at the same time */
+        pthread_mutex_lock(&pool.m);
+        for (unsigned t = T - 1u; t >= 1u; t--) { part[t].next = pool.head; pool.head = &part[t]; }
+        pthread_cond_broadcast(&pool.work);
+        pthread_mutex_unlock(&pool.m);
+    }
     fill_part_run(&part[0]);
-    for (unsigned t = 1; t <= started; t++) pthread_join(th[t], NULL);
-    for (unsigned t = started + 1; t < T; t++) fill_part_run(&part[t]);      /* a thread that could not be started: its share here */
+    pthread_mutex_lock(&pool.m);
+    pool_finish(&part[0]);
+    for (;;) {                                               /* my own parts nobody has taken yet: here; those in other hands: wait */
+        struct fill_part *q = NULL, **pp = &pool.head;
+        for (; *pp; pp = &(*pp)->next) if ((*pp)->left == &left) { q = *pp; *pp = q->next; break; }
+        if (q) { pthread_mutex_unlock(&pool.m); fill_part_run(q); pthread_mutex_lock(&pool.m); pool_finish(q); continue; }
+        if (left == 0) break;
+        pthread_cond_wait(&pool.done, &pool.m);
+    }
+    pthread_mutex_unlock(&pool.m);
     for (unsigned k = 0; k < n; k++) if (got[k] > most) most = got[k];
     for (unsigned k = 0; k < n; k++) if (got[k] < most) memset(slab + (size_t)k * pitch + got[k], 128, most - got[k]);
     free(got);

@@ -33,8 +33,10 @@ int wm_reader_run(const wm_reader_cfg *cfg, wm_reader_push_fn push, void *user)
 #define PUSH_WHOLE_BLOCKS() do { \
         const size_t k_ = have / WM_BLOCK * WM_BLOCK; \
         if (k_) { \
+            const long long t0_ = now_ms(); \
             if (push(user, buf, k_)) { rc = WM_READER_PUSH_FAILED; goto out; } \
             memmove(buf, buf + k_, have - k_); have -= k_; t_first = now_ms(); \
+            t_data += t_first - t0_;          /* -f measures how long the INPUT has been quiet: time inside push() (GPU push, line printing) does not count */ \
         } } while (0)
 
     for (;;) {

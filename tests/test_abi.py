@@ -70,7 +70,7 @@ def test_cli_usage_and_exit_codes(wm):
     import subprocess
     # unknown option (the reference's getopt string has no 'h'): usage on stdout, exit 1
     p = subprocess.run([wm.CLI_PATH, "-h"], capture_output=True, text=True, stdin=subprocess.DEVNULL)
-    assert p.returncode == 1 and "Usage" in p.stdout and "-p [T,S]" in p.stdout
+    assert p.returncode == 1 and "Usage" in p.stdout and "-p [T,S]" in p.stdout and "1 ... 16" in p.stdout       # the one argv difference is in the usage text
     p = subprocess.run([wm.CLI_PATH, "-V"], capture_output=True, text=True, stdin=subprocess.DEVNULL)
     assert p.returncode == 0 and p.stdout.startswith("rtl_wmbus:") and len(p.stdout.splitlines()) == 2      # version, commit (rtl_wmbus.c:886-890)
     p = subprocess.run([wm.CLI_PATH, "-d", "17"], capture_output=True, text=True, stdin=subprocess.DEVNULL)

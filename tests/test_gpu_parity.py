@@ -39,6 +39,47 @@ def compare_chips(rx, ref, stream=0, chains=(0, 1), algos=(0, 1)):
             assert np.array_equal(pos, oc["sample"])
 
 
+def test_device_divide_on_the_adversarial_operands(wm):
+    """wm_div_dom (wm_exact.h) makes ONE Markstein correction q + (a - b q) y from q = RN(a y), y = RN(1/b) -- exact if q is a faithful
+    quotient, and the analytic bound for q is about 1.5 ulp where the quotient's significand is close to 2 and y was rounded UP by
+    nearly half an ulp.  So those operands are tested by construction, not by sampling: for EVERY significand of b the
+    dividends just below 2 b and just above b, and for the 30 000 significands whose reciprocal rounds worst, 64 dividends a side
+    more plus the quotients next to a rounding boundary -- against the host's IEEE division (numpy float32 `/`)."""
+    def check(a, b, what):
+        a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+        r = wm.selftest_math(a, b)
+        want = (a / b).astype(np.float32)
+        bad = np.flatnonzero(r["div"].view(np.uint32) != want.view(np.uint32))
+        assert bad.size == 0, (what, bad.size, a[bad[:4]], b[bad[:4]], r["div"][bad[:4]], want[bad[:4]])
+
+    worst = []
+    for slab in range(2):                                     # all 2^23 significands: b = (2^23 + k), an integer below 2^24 like the kernels' operands
+        k = np.arange(slab << 22, (slab + 1) << 22, dtype=np.int64)
+        b = (k + (1 << 23)).astype(np.float32)
+        two_b = (2 * (k + (1 << 23))).astype(np.float32)
+        for steps in (1, 2, 3):
+            below = (two_b.view(np.uint32) - np.uint32(steps)).view(np.float32)      # quotient = 2 - a few ulps
+            check(below, b, f"just below 2b, slab {slab}")
+            above = (b.view(np.uint32) + np.uint32(steps)).view(np.float32)          # quotient = 1 + a few ulps
+            check(above, b, f"just above b, slab {slab}")
+        y64 = 1.0 / b.astype(np.float64)
+        y32 = y64.astype(np.float32)
+        err = (y32.astype(np.float64) - y64) / np.spacing(y32).astype(np.float64)     # in ulps of y: +0.5 = rounded up by half an ulp
+        idx = np.argsort(-np.abs(err))[:15000]
+        worst.append(b[idx])
+    b = np.concatenate(worst)
+    rng = np.random.default_rng(5)
+    for steps in range(1, 65):
+        check(((2 * b).view(np.uint32) - np.uint32(steps)).view(np.float32), b, f"worst reciprocals, 2b - {steps} ulp")
+        check((b.view(np.uint32) + np.uint32(steps)).view(np.float32), b, f"worst reciprocals, b + {steps} ulp")
+    for _ in range(16):                                       # quotients next to a rounding boundary: a = RN(b (q + half an ulp of q)) for q near 2
+        q = (np.float32(2.0).view(np.uint32) - rng.integers(1, 1 << 12, b.size).astype(np.uint32)).view(np.float32)
+        a = (b.astype(np.float64) * (q.astype(np.float64) + 0.5 * np.spacing(q).astype(np.float64))).astype(np.float32)
+        check(a, b, "next to a rounding boundary")
+        check((a.view(np.uint32) + np.uint32(1)).view(np.float32), b, "next to a rounding boundary + 1")
+        check((a.view(np.uint32) - np.uint32(1)).view(np.float32), b, "next to a rounding boundary - 1")
+
+
 def test_device_arithmetic_is_ieee_and_glibc_exact(wm, oracle, libm_is_glibc_235):
     """The kernels' scalar arithmetic (wm_exact.h) on the device against this host's IEEE / glibc:
       * square root: EXHAUSTIVE over the RSSI operand domain, every integer in [0, 2^24) (the
