@@ -973,17 +973,34 @@ static int enqueue_front_impl(wmbus_ctx *c, size_t nbytes)
         const bool rla = c->flags & WM_F_RLA;
         HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
         fr_launch(c, WMBUS_ALGO_T2A, 0xFFFFFFFFu);                 /* the clock kernel's first pass */
-        for (unsigned r = 0; r < c->fr_rounds && c->opt_rounds; r++) { fr_verify(c, WMBUS_ALGO_T2A, SC_CLK + r); fr_launch(c, WMBUS_ALGO_T2A, SC_CLK + r); }
+        /* (a push of one segment per row has no hand-off inside it: its only lane starts from the carried state -- no rounds to enqueue;
+         * a live stream's 2^16-sample pushes are such) */
+        for (unsigned r = 0; r < c->fr_rounds && c->opt_rounds && g.nseg[1] > 1u; r++) { fr_verify(c, WMBUS_ALGO_T2A, SC_CLK + r); fr_launch(c, WMBUS_ALGO_T2A, SC_CLK + r); }
         HIPCHK(c, hipEventRecord(c->ev[8], c->stream));
         if (rla) {
             fr_launch(c, WMBUS_ALGO_RLA, 0xFFFFFFFFu);
-            for (unsigned r = 1; r < c->rla_rounds && c->opt_rounds; r++) { fr_verify(c, WMBUS_ALGO_RLA, SC_RLA + r); fr_launch(c, WMBUS_ALGO_RLA, SC_RLA + r); }
+            for (unsigned r = 1; r < c->rla_rounds && c->opt_rounds && g.nseg[0] > 1u; r++) { fr_verify(c, WMBUS_ALGO_RLA, SC_RLA + r); fr_launch(c, WMBUS_ALGO_RLA, SC_RLA + r); }
         } else HIPCHK(c, hipMemsetAsync(c->d_counts[0], 0, (size_t)2 * c->S * c->nseg_cap[0] * sizeof(uint32_t), c->stream));
         c->rla_fin = c->rla_rounds;
-        fr_verify(c, WMBUS_ALGO_T2A, SC_CLK + c->fr_rounds);
-        if (rla) fr_verify(c, WMBUS_ALGO_RLA, SC_RLA + c->rla_fin);
-        HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-        fr_carry(c);
+        if (rla) {
+            /* the last verification of either framer and both carries in one launch (k2_finish) */
+            K2Finish f{};
+            const K2Args *ka2[2] = {&c->k2rla, &c->k2clk};
+            for (int al = 0; al < 2; al++) {
+                f.st_start[al] = (const uint32_t *)ka2[al]->st_start; f.st_final[al] = (const uint32_t *)ka2[al]->st_final;
+                f.words[al] = (uint32_t)((al ? sizeof(WmClkState) : sizeof(WmRlaState)) / 4);
+                f.carry[al] = (uint32_t *)st_carry(c, al, true); f.verify[al] = 1u; f.do_carry[al] = 1u;
+            }
+            f.list[0] = c->d_list2; f.list[1] = c->d_list; f.n_list[0] = c->d_scalars + SC_RLA + c->rla_fin; f.n_list[1] = c->d_scalars + SC_CLK + c->fr_rounds;
+            f.bad[0] = c->rla_chains ? c->d_bad : nullptr; f.bad[1] = c->d_bad_clk;
+            const uint32_t most = std::max(2u * g.S, 2u * std::max(g.nseg[0], g.nseg[1]) * g.S);
+            hipLaunchKernelGGL(k2_finish, dim3((most + 255u) / 256u), dim3(256), 0, c->stream, g, f);
+            HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+        } else {
+            fr_verify(c, WMBUS_ALGO_T2A, SC_CLK + c->fr_rounds);
+            HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+            fr_carry(c);
+        }
         c->committed = true;
     }
     /* the next push sees the last 4096 staged bytes in front of it */

@@ -38,11 +38,9 @@
 #include "wm_k2_rla.h"
 
 /* start[seg] must equal final[seg-1]; mismatching lanes are appended to `list`. */
-__global__ void k2_verify(WmPush g, uint32_t algo, const uint32_t *st_start, const uint32_t *st_final, uint32_t words,
-                          uint32_t *list, uint32_t *n_list, uint32_t *bad)
+__device__ __forceinline__ void k2_verify_lane(const WmPush &g, uint32_t algo, uint32_t lane, const uint32_t *st_start, const uint32_t *st_final, uint32_t words,
+                                               uint32_t *list, uint32_t *n_list, uint32_t *bad)
 {
-    wm_framer_prio();
-    const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
     if (lane >= 2u * g.nseg[algo] * g.S) return;
     uint32_t ch, stream, seg;
     lane_decode(g, algo, lane, ch, stream, seg);
@@ -55,6 +53,33 @@ __global__ void k2_verify(WmPush g, uint32_t algo, const uint32_t *st_start, con
      * was 200 000 scattered 4-byte stores per verification: read-modify-write traffic worth 2 ms of every step) */
     if (bad) bad[((uint64_t)ch * g.nseg_cap[algo] + seg) * g.S + stream] = same ? 0u : 1u;
     if (!same) list[atomicAdd(n_list, 1u)] = lane;
+}
+
+__global__ void k2_verify(WmPush g, uint32_t algo, const uint32_t *st_start, const uint32_t *st_final, uint32_t words,
+                          uint32_t *list, uint32_t *n_list, uint32_t *bad)
+{
+    wm_framer_prio();
+    k2_verify_lane(g, algo, blockIdx.x * blockDim.x + threadIdx.x, st_start, st_final, words, list, n_list, bad);
+}
+
+/* The end of a push's framer stage in ONE launch (round 6: it was four): the last verification of either framer and the two
+ * carries -- the end state of every row's last segment becomes the next push's start state.  (If a verification still lists
+ * segments, wmbus_collect finishes them with the host in the loop and carries again.) */
+struct K2Finish {
+    const uint32_t *st_start[2], *st_final[2];           /* [framer] */
+    uint32_t *list[2], *n_list[2], *bad[2], *carry[2];
+    uint32_t words[2], verify[2], do_carry[2];
+};
+__global__ void k2_finish(WmPush g, K2Finish f)
+{
+    wm_framer_prio();
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint32_t algo = 0; algo < 2u; algo++) {
+        if (f.verify[algo]) k2_verify_lane(g, algo, t, f.st_start[algo], f.st_final[algo], f.words[algo], f.list[algo], f.n_list[algo], f.bad[algo]);
+        if (f.do_carry[algo] && t < 2u * g.S)
+            for (uint32_t k = 0; k < f.words[algo]; k++)
+                f.carry[algo][(uint64_t)t * f.words[algo] + k] = f.st_final[algo][((uint64_t)t * g.nseg_cap[algo] + g.nseg[algo] - 1u) * f.words[algo] + k];
+    }
 }
 
 #include "wm_k3_bursts.h"
