@@ -443,6 +443,18 @@ __device__ __forceinline__ void k1_stage_rssi(const K1Args &a, const int tid, co
     }
 }
 
+/* How many of a lane's NP input words per tile are PREFETCHED across the tile before (first pass, PRE): all of them where they fit the
+ * 64 registers of a wave that shares its SIMD with seven others -- decimation 2 and 3 without -s --, else the first few: the rest is
+ * asked for at the top of the tile's stage 0 and arrives while the prefetched words are converted.  (Round 5 prefetched all eleven
+ * words of -d 5 -s: 31 VGPRs spilled, 84 bytes of scratch per lane in the product's first pass; VERDICT r5 #3.) */
+#ifndef WM_K1_PF_PLAIN
+#define WM_K1_PF_PLAIN 5
+#endif
+#ifndef WM_K1_PF_SHIFT
+#define WM_K1_PF_SHIFT 16
+#endif
+__host__ __device__ constexpr int k1_prefetched(int np, bool shift) { return np < (shift ? WM_K1_PF_SHIFT : WM_K1_PF_PLAIN) ? np : (shift ? WM_K1_PF_SHIFT : WM_K1_PF_PLAIN); }
+
 /* The staged input of a tile: dword u of the tile's window (two IQ samples) at src[u], u < NDW; LDS word 2 u - off. */
 template <int NT> struct K1Src { const uint32_t *src; long r_al; int off, NDW; };
 template <int D, int NT>
@@ -508,7 +520,7 @@ __device__ __forceinline__ void k1_tile(const K1Args &a, const int tile, const i
 #pragma unroll
         for (int it = 0; it < NP; it++) {
             const int u = tid + NT * (it + ps);
-            wv[it] = PRE ? pre[it] : u < NDW ? src[u] : 0u;
+            wv[it] = PRE && it < k1_prefetched(NP, SHIFT) ? pre[it] : u < NDW ? src[u] : 0u;
         }
         /* the arctangent's table (5 range rows + range LUT, wm_exact.h): word k by lane k, ONE load issued behind the
          * input loads and waited for with them (round 4 computed it in place: six dependent global loads in the first
@@ -563,7 +575,7 @@ __device__ __forceinline__ void k1_tile(const K1Args &a, const int tile, const i
         if (PRE && next >= 0) {                               /* the next tile's input into the registers this tile's has just left */
             const K1Src<NT> nx = k1_src<D, NT>(a, next, stream);
 #pragma unroll
-            for (int it = 0; it < NP; it++) { const int u = tid + NT * it; pre[it] = u < nx.NDW ? nx.src[u] : 0u; }
+            for (int it = 0; it < k1_prefetched(NP, SHIFT); it++) { const int u = tid + NT * it; pre[it] = u < nx.NDW ? nx.src[u] : 0u; }
         }
     }
     WM_K1_STAMP(1);
@@ -651,8 +663,19 @@ __device__ __forceinline__ void k1_tile(const K1Args &a, const int tile, const i
     WM_K1_STAMP_END(tid);
 }
 
+/* Waves per SIMD the register budget is cut for: what the block's LDS lets onto a CU anyway (160 KB; a 256-thread block is one wave per
+ * SIMD, a 512-thread block two).  Decimation 2 without -s: eight -- 64 VGPRs.  With -s the staging is two rows and at -d 5 a block has
+ * 50 KB: three blocks per CU whatever the registers, and a 64-register budget only bought 31 spilled VGPRs. */
+template <int D, bool SHIFT, int NT>
+__host__ __device__ constexpr int k1_waves_per_simd()
+{
+    const size_t lds = sizeof(K1LdsT<NT>) + K1GeoT<NT>::smem(D ? D : 2, SHIFT);
+    const int blocks = (int)(160u * 1024u / lds), waves = blocks * (NT / 256);
+    return waves > 8 ? 8 : waves < 1 ? 1 : waves;
+}
+
 template <int D, bool SHIFT, bool GEN = true, bool FAST = false, int RS = 0, int NT = 256>
-__global__ __launch_bounds__(NT, GEN ? 1 : RS == 2 ? 4 : 8) void k1_demod2(K1Args a)          /* first pass: at most 64 VGPRs -- eight waves fill a SIMD's register file exactly; the RSSI launch over the listed tiles is small and latency-bound: 128 (its -s forms spilled up to 48 registers at 64) */
+__global__ __launch_bounds__(NT, (GEN ? 1 : RS == 2 ? 4 : k1_waves_per_simd<D, SHIFT, NT>())) void k1_demod2(K1Args a)          /* the RSSI launch over the listed tiles is small and latency-bound: 128 VGPRs (its -s forms spilled up to 48 registers at 64) */
 {
     static_assert(NT == 256 || (NT == 512 && RS == 1 && !GEN), "the 512-thread tile is the first pass's without the RSSI");
     /* One tile per block.  (A bounded grid whose blocks walk several tiles made the kernel itself 6 % faster -- fewer block
@@ -678,7 +701,7 @@ __global__ __launch_bounds__(NT, GEN ? 1 : RS == 2 ? 4 : 8) void k1_demod2(K1Arg
         {
             const K1Src<NT> in = k1_src<D, NT>(a, t0, stream);
 #pragma unroll
-            for (int it = 0; it < NP; it++) { const int u = tid + NT * it; pre[it] = u < in.NDW ? in.src[u] : 0u; }
+            for (int it = 0; it < k1_prefetched(NP, SHIFT); it++) { const int u = tid + NT * it; pre[it] = u < in.NDW ? in.src[u] : 0u; }
         }
         /* no barrier between two tiles of a block: a tile's stage 0 writes the staging area, which nobody reads behind the
          * tile's second barrier (RS = 1 has no magnitude rows), and the discriminator rows are written behind the NEXT first barrier */
