@@ -222,6 +222,11 @@ int  wmbus_selftest_math(int device, const float *a, const float *b, float *o_sq
  * (n a multiple of 4, at most 976: one tile of the kernel); out[0 .. n) receives the 11-tap filter's outputs, out[n .. 2n) the 46-tap one's. */
 int  wmbus_selftest_fir(int device, const float *x, float *out, size_t n);
 
+/* Measurement aid: the host half of wmbus_collect (sort, strip / format, merge: wm_decoder.c, replacing the decoders' fprintf at
+ * t1_c1_packet_decoder.h:671-699 / s1_packet_decoder.h:248-269) over the records of the context's last push again, `reps` times, without
+ * any GPU work.  Returns the lines of one repetition; *seconds receives the wall clock of all of them. */
+long wmbus_debug_replay_decode(wmbus_ctx *ctx, unsigned reps, double *seconds);
+
 /* Number of visible HIP devices (0 if none). */
 int  wmbus_device_count(void);
 

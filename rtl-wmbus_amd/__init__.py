@@ -95,7 +95,8 @@ EXPORTS = ["wmbus_batch_plan", "wmbus_batch_open", "wmbus_batch_close", "wmbus_b
            "wmbus_batch_device_input", "wmbus_batch_run",
            "wmbus_runtime_init", "wmbus_default_cfg", "wmbus_open", "wmbus_close", "wmbus_last_error", "wmbus_stage", "wmbus_device_input",
            "wmbus_process", "wmbus_collect", "wmbus_lines", "wmbus_lines_text", "wmbus_get_timing", "wmbus_read_tap",
-           "wmbus_read_chips", "wmbus_device_count", "wmbus_selftest_math", "wmbus_selftest_fir", "wmbus_alloc_pinned", "wmbus_free_pinned"]
+           "wmbus_read_chips", "wmbus_device_count", "wmbus_selftest_math", "wmbus_selftest_fir", "wmbus_alloc_pinned", "wmbus_free_pinned",
+           "wmbus_debug_replay_decode"]
 
 _lib = None
 
@@ -127,6 +128,7 @@ def lib():
         L.wmbus_free_pinned.argtypes = [vp]
         L.wmbus_selftest_math.argtypes = [ctypes.c_int] + [vp] * 6 + [sz]
         L.wmbus_selftest_fir.argtypes = [ctypes.c_int, vp, vp, sz]
+        L.wmbus_debug_replay_decode.argtypes = [vp, u, ctypes.POINTER(ctypes.c_double)]; L.wmbus_debug_replay_decode.restype = ctypes.c_long
         L.wmbus_batch_open.argtypes = [ctypes.POINTER(Cfg), u, ctypes.POINTER(vp)]
         L.wmbus_batch_plan.argtypes = [ctypes.POINTER(Cfg), u, ctypes.POINTER(u), u]; L.wmbus_batch_plan.restype = u
         L.wmbus_batch_close.argtypes = [vp]

@@ -32,9 +32,13 @@
 
 namespace {
 
+/* one formatted line of a push: where its text lies in its part's buffer (round 6: a std::string per line was a heap allocation per
+ * line -- with eight ranks' contexts decoding at once on one host, 64 x 4 threads in malloc, the decode of a context-push took
+ * 18 ms instead of 2.8: tools/host_replay.py) */
 struct LineRec {
-    uint64_t sample; uint32_t stream; uint8_t chain, algo, crc_ok; uint32_t seq; std::string text;
+    uint64_t sample; uint32_t stream; uint8_t chain, algo, crc_ok; uint32_t seq; uint32_t part, off, len;
 };
+struct LinePart { std::vector<LineRec> recs; std::string text; };
 
 /* Persistent host worker pool of a context (packet decoders): run(n, f) executes f(0..n-1) on the
  * workers and the caller; threads are created once, not per push. */
@@ -1161,8 +1165,14 @@ static void line_timestamp(const wmbus_ctx *c, uint64_t sample, const char *ts_f
 }
 
 static void decode_stream_range(wmbus_ctx *c, const std::vector<Entry> &order, size_t lo, size_t hi,
-                                std::vector<LineRec> &out, const char *ts_fixed)
+                                LinePart &part, uint32_t part_no, const char *ts_fixed)
 {
+    std::vector<LineRec> &out = part.recs;
+    auto keep = [&](LineRec &r, const char *line, size_t n) {
+        r.part = part_no; r.off = (uint32_t)part.text.size(); r.len = (uint32_t)n;
+        part.text.append(line, n);
+        out.push_back(r);
+    };
     char line[1024], ts[64];
     uint8_t pkt[WM_PKT_MAXBYTES + 4];
     uint32_t seq = 0;
@@ -1192,8 +1202,8 @@ static void decode_stream_range(wmbus_ctx *c, const std::vector<Entry> &order, s
                 const size_t n = wm_packet_format(p.chain ? WM_MODE_S1 : WM_MODE_T1C1, (p.flags & WM_PKTF_C1) != 0, (p.flags & WM_PKTF_FRAME_B) != 0,
                                                   (p.flags & WM_PKTF_ERR3OF6) != 0, ok, p.L, pkt, p.pkt_rssi, p.rssi_now, tag, ts, line, sizeof line);
                 LineRec r; r.sample = p.sample; r.stream = p.stream; r.chain = p.chain; r.algo = p.algo;
-                r.crc_ok = (uint8_t)ok; r.seq = seq++; r.text.assign(line, n);
-                out.push_back(std::move(r));
+                r.crc_ok = (uint8_t)ok; r.seq = seq++;
+                keep(r, line, n);
                 continue;
             }
             const WmBurstHdr &h = c->h_hdr[order[j].idx];
@@ -1216,8 +1226,8 @@ static void decode_stream_range(wmbus_ctx *c, const std::vector<Entry> &order, s
                     line_timestamp(c, h.pos0 + (word >> 11), ts_fixed, ts, sizeof ts);
                     const size_t n = wm_decoder_format(&hd.dec, tag, ts, rssi, line, sizeof line, &ok);
                     LineRec r; r.sample = h.pos0 + (word >> 11); r.stream = h.stream; r.chain = h.chain; r.algo = h.algo;
-                    r.crc_ok = (uint8_t)ok; r.seq = seq++; r.text.assign(line, n);
-                    out.push_back(std::move(r));
+                    r.crc_ok = (uint8_t)ok; r.seq = seq++;
+                    keep(r, line, n);
                     st = WM_DEC_IDLE;
                 }
                 if (st == WM_DEC_IDLE) { k++; break; }
@@ -1306,24 +1316,27 @@ static int decode_host(wmbus_ctx *c)
     const double t0 = now_ms();
     const uint32_t n_hdr = c->done.n_hdr, n_pkts = c->done.n_pkts;
 
+    /* candidates in the order the decoders take them: (capture, chain, framer), a continuation first, then by chip.  The key is made
+     * ONCE per candidate (the comparator used to look every candidate's record up in the page-locked result area at every comparison) */
     std::vector<Entry> order(n_hdr + n_pkts);
-    for (uint32_t i = 0; i < n_hdr; i++) order[i] = Entry{i, 1};
-    for (uint32_t i = 0; i < n_pkts; i++) order[n_hdr + i] = Entry{i, 0};
-    std::sort(order.begin(), order.end(), [&](const Entry &x, const Entry &y) {
-        const EntryKey a = entry_key(c, x), b = entry_key(c, y);
-        if (a.stream != b.stream) return a.stream < b.stream;
-        if (a.chain != b.chain) return a.chain < b.chain;
-        if (a.algo != b.algo) return a.algo < b.algo;
-        if (a.cont != b.cont) return a.cont > b.cont;                                   /* continuation first */
-        return a.chip0 < b.chip0;
-    });
+    {
+        struct Keyed { uint64_t hi; uint32_t lo; Entry e; };
+        std::vector<Keyed> ks(n_hdr + n_pkts);
+        for (uint32_t i = 0; i < n_hdr + n_pkts; i++) {
+            const Entry e = i < n_hdr ? Entry{i, 1} : Entry{i - n_hdr, 0};
+            const EntryKey k = entry_key(c, e);
+            ks[i] = Keyed{((uint64_t)k.stream << 8) | ((uint64_t)k.chain << 4) | ((uint64_t)k.algo << 1) | (k.cont ? 0u : 1u), k.chip0, e};
+        }
+        std::stable_sort(ks.begin(), ks.end(), [](const Keyed &x, const Keyed &y) { return x.hi != y.hi ? x.hi < y.hi : x.lo < y.lo; });
+        for (size_t i = 0; i < ks.size(); i++) order[i] = ks[i].e;
+    }
     unsigned nt = c->cfg.host_threads ? c->cfg.host_threads : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     if (order.size() < 4096) nt = 1;
     const char *tsf = c->cfg.fixed_timestamp ? "TS" : nullptr;
     /* more pieces than threads (cut at stream boundaries): the decoders' cost per stream is uneven */
     const unsigned np = nt == 1 ? 1 : 4 * nt;
-    std::vector<std::vector<LineRec>> parts(np);
-    if (np == 1) decode_stream_range(c, order, 0, order.size(), parts[0], tsf);
+    std::vector<LinePart> parts(np);
+    if (np == 1) decode_stream_range(c, order, 0, order.size(), parts[0], 0u, tsf);
     else {
         std::vector<size_t> cut(np + 1, order.size());
         cut[0] = 0;
@@ -1333,7 +1346,7 @@ static int decode_host(wmbus_ctx *c)
             cut[t] = std::max(p, cut[t - 1]);
         }
         if (!c->pool || c->pool->size() + 1 != nt) c->pool.reset(new WorkerPool(nt - 1));
-        c->pool->run(np, [&](unsigned t) { decode_stream_range(c, order, cut[t], cut[t + 1], parts[t], tsf); });
+        c->pool->run(np, [&](unsigned t) { decode_stream_range(c, order, cut[t], cut[t + 1], parts[t], t, tsf); });
     }
     /* Burst storage ran out (a warning): a half-received telegram whose continuation was among the dropped bursts would
      * otherwise wait for it for ever and take the FIRST chips of the next push for its own -- it is lost, like the
@@ -1343,7 +1356,12 @@ static int decode_host(wmbus_ctx *c)
             if (hd.owed != 0 && hd.fed != c->done.seq) { wm_decoder_abort(&hd.dec); hd.owed = 0; }
     /* stdout order of the reference: by completing sample, then T1/C1 before S1, run-length before time2 */
     std::vector<LineRec> all;
-    for (auto &p : parts) for (auto &r : p) all.push_back(std::move(r));
+    {
+        size_t n_all = 0, n_text = 0;
+        for (auto &p : parts) { n_all += p.recs.size(); n_text += p.text.size(); }
+        all.reserve(n_all); c->text.reserve(n_text); c->lines.reserve(n_all);
+        for (auto &p : parts) all.insert(all.end(), p.recs.begin(), p.recs.end());
+    }
     std::stable_sort(all.begin(), all.end(), [](const LineRec &a, const LineRec &b) {
         if (a.stream != b.stream) return a.stream < b.stream;
         if (a.sample != b.sample) return a.sample < b.sample;
@@ -1362,16 +1380,16 @@ static int decode_host(wmbus_ctx *c)
         kept.reserve(all.size());
         for (auto &r : all) {
             if (c->cfg.only_crc_ok && !r.crc_ok) continue;
-            if (c->cfg.dedup_twins && wm_twin_check(&c->twins[((size_t)r.stream * 2 + r.chain) * 2], r.chain, r.algo, r.sample, r.text.data(), r.text.size())) continue;
-            kept.push_back(std::move(r));
+            if (c->cfg.dedup_twins && wm_twin_check(&c->twins[((size_t)r.stream * 2 + r.chain) * 2], r.chain, r.algo, r.sample, parts[r.part].text.data() + r.off, r.len)) continue;
+            kept.push_back(r);
         }
         all.swap(kept);
     }
     for (auto &r : all) {
         wmbus_line l{};
         l.stream = r.stream; l.chain = r.chain; l.algo = r.algo; l.crc_ok = r.crc_ok; l.sample = r.sample;
-        l.text_off = (uint32_t)c->text.size(); l.text_len = (uint32_t)r.text.size();
-        c->text += r.text;
+        l.text_off = (uint32_t)c->text.size(); l.text_len = r.len;
+        c->text.append(parts[r.part].text, r.off, r.len);
         c->lines.push_back(l);
     }
     c->tim.host_decode_ms = (float)(now_ms() - t0);
@@ -1388,6 +1406,27 @@ int wmbus_collect(wmbus_ctx *c)
     const int rc = wait_gpu(c);
     if (rc) { c->lines.clear(); c->text.clear(); return rc; }
     return decode_host(c);
+}
+
+/* The host half of wmbus_collect -- sort, strip / format, merge -- over the records of the context's LAST push again, `reps` times, with no
+ * GPU work at all: how many lines per second the host side sustains when several ranks' contexts decode at once (eight
+ * GPUs' worth of lines through one host; tools/host_replay.py).  The persistent packet decoders are put back after every repetition; the
+ * lines of the last one stay readable through wmbus_lines.  Returns the number of lines of one repetition, or a negative code. */
+long wmbus_debug_replay_decode(wmbus_ctx *c, unsigned reps, double *seconds)
+{
+    if (!c) return WMBUS_EINVAL;
+    const std::vector<HostDecoder> saved = c->decs;
+    const double t0 = now_ms();
+    long n = 0;
+    for (unsigned r = 0; r < reps; r++) {
+        c->decs = saved;
+        c->done.valid = true;
+        const int rc = decode_host(c);
+        if (rc) return rc;
+        n = (long)c->lines.size();
+    }
+    if (seconds) *seconds = (now_ms() - t0) * 1e-3;
+    return n;
 }
 
 size_t wmbus_lines(const wmbus_ctx *c, const wmbus_line **lines)

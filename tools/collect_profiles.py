@@ -75,7 +75,7 @@ def family(kernel):
             return None
         if len(args) >= 5 and args[4] == "2":
             return "k1_rssi"                             # RSSI on demand: the listed tiles' launch (the first pass is the RS = 1 instantiation)
-    return {"k2_clock_list": "k2_clock", "k2_rla_list": "k2_rla"}.get(base, base)
+    return {"k2_clock_list": "k2_clock", "k2_clock_sys": "k2_clock", "k2_clock_sys_list": "k2_clock", "k2_rla_list": "k2_rla", "k2_finish": "k2_verify"}.get(base, base)    # (round 6: the systolic clock kernels and the merged last verification ride with their families)
 
 
 def pick(d, prefix):
@@ -143,7 +143,7 @@ if n_k1:
         "algorithmic_bytes_per_input_sample": 2,
         "other_kernels_KB_per_step_as_reported": {},
     }
-    for pre in ("k1_rssi", "k2_clock", "k2_clock_rla", "k2_rla", "k3_scan", "k3_spans", "k3_bursts"):
+    for pre in ("k1_rssi", "k2_clock", "k2_rla", "k3_scan", "k3_spans", "k3_bursts"):
         traffic["other_kernels_KB_per_step_as_reported"][pre + "_fetch"] = round(pick(fetch, pre)[1] / 2, 1)   # two passes per run
         traffic["other_kernels_KB_per_step_as_reported"][pre + "_write"] = round(pick(write, pre)[1] / 2, 1)
     o = traffic["other_kernels_KB_per_step_as_reported"]
