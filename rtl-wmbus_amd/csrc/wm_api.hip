@@ -816,7 +816,9 @@ static int launch_k3(wmbus_ctx *c, bool again)
     }
     hipLaunchKernelGGL(k_sum_counts, dim3(std::min(64u, (2u * (c->nseg_cap[0] + c->nseg_cap[1]) * c->S + 255u) / 256u)), dim3(256), 0, c->stream, g,
                        c->d_counts[0], c->d_counts[1], c->d_scalars + SC_CHIPS);
-    hipLaunchKernelGGL(k3_scan, dim3((2u * (g.nseg[0] + g.nseg[1]) * g.S + 255u) / 256u), dim3(256), 0, c->stream, g, c->d_chips[0], c->d_chips[1],
+    /* grid.y: the parts a region is scanned in -- the run-length framer's regions can be longer than their capacity (spill chunks) */
+    const uint32_t scan_parts = (std::max(g.cap[0] + WM_SPILL_LEVELS * WM_SPILL_CHUNK, g.cap[1]) + WM_K3_SCAN_PART - 1u) / WM_K3_SCAN_PART;
+    hipLaunchKernelGGL(k3_scan, dim3((2u * (g.nseg[0] + g.nseg[1]) * g.S + 255u) / 256u, scan_parts), dim3(256), 0, c->stream, g, c->d_chips[0], c->d_chips[1],
                        c->d_counts[0], c->d_counts[1], c->d_sync_seen[0], c->d_sync_seen[1], c->d_hits, c->d_scalars + SC_NHITS,
                        c->hits_cap, c->d_scalars + SC_ERR);
     K3Args k3{};

@@ -90,6 +90,7 @@ __device__ uint32_t burst_need(uint32_t chain, uint32_t hb, uint32_t nb) { retur
  * per-region flag "an access-code chip was emitted here by some pass"; each lane of a wave looks at
  * the flag of one (framer, chain, capture, segment) region, and the wave then scans the flagged
  * regions (a minority) together, appending {lane | algo << 31, chip index}. */
+#define WM_K3_SCAN_PART 4096       /* a multiple of 1024 (a trip of the wave) */
 __global__ __launch_bounds__(256) void k3_scan(WmPush g, const uint32_t *chips0, const uint32_t *chips1, const uint32_t *counts0,
                                                const uint32_t *counts1, const uint32_t *seen0, const uint32_t *seen1,
                                                uint2 *hits, uint32_t *n_hits, uint32_t hits_cap, uint32_t *err)
@@ -115,18 +116,22 @@ __global__ __launch_bounds__(256) void k3_scan(WmPush g, const uint32_t *chips0,
         const uint32_t *prim = r_algo ? chips1 : chips0;
         /* four 16-byte loads in flight per lane (a region of the clock framer is 8 k chips: 32 dependent
          * trips of one load each were most of this kernel's time) */
-        for (uint32_t kb = 4u * ln; kb < cnt; kb += 1024u) {            /* regions and spill chunks are 32-byte aligned, cap % 8 == 0 */
+        /* a region is scanned in parts of WM_K3_SCAN_PART chips, one wave (blockIdx.y) per part: the scan of a flagged region is a chain
+         * of dependent trips as long as the region, and the clock framer's regions grew with its segments (65 536 samples: 16 392 chips,
+         * round 6 -- the launch went from 1.3 to 2.1 ms on its own) */
+        const uint32_t k_lo = blockIdx.y * (uint32_t)WM_K3_SCAN_PART, k_hi = min(cnt, k_lo + (uint32_t)WM_K3_SCAN_PART);
+        for (uint32_t kb = k_lo + 4u * ln; kb < k_hi; kb += 1024u) {    /* regions and spill chunks are 32-byte aligned, cap % 8 == 0 */
             uint4 v[4];
 #pragma unroll
             for (uint32_t u = 0; u < 4; u++)
-                v[u] = kb + 256u * u < cnt ? *(const uint4 *)wm_chip_ptr(g, prim, r_algo, sidx, kb + 256u * u) : uint4{0u, 0u, 0u, 0u};
+                v[u] = kb + 256u * u < k_hi ? *(const uint4 *)wm_chip_ptr(g, prim, r_algo, sidx, kb + 256u * u) : uint4{0u, 0u, 0u, 0u};
 #pragma unroll
             for (uint32_t u = 0; u < 4; u++) {
                 const uint32_t k4 = kb + 256u * u;
                 const uint32_t q[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
                 for (uint32_t j = 0; j < 4; j++)
-                    if (k4 + j < cnt && (q[j] & 2u)) {
+                    if (k4 + j < k_hi && (q[j] & 2u)) {
                         const uint32_t i = atomicAdd(n_hits, 1u);
                         if (i < hits_cap) hits[i] = make_uint2(r_lane | (r_algo << 31), k4 + j);
                         else atomicOr(err, WM_ERR_BURST_OVERFLOW);

@@ -68,11 +68,14 @@ long wm_emu_k3(const uint64_t *geo, const uint32_t *chips0, const uint32_t *chip
     std::vector<uint2> hits(hdr_cap);
     uint32_t n_hits = 0, err = 0, n_hdr = 0, n_words = 0;
     const uint32_t lanes = 2u * (g.nseg[0] + g.nseg[1]) * g.S;
-    gridDim = {(lanes + 255u) / 256u, 1, 1};
-    for (uint32_t b = 0; b < gridDim.x; b++) {
-        blockIdx = {b, 0, 0};
-        block_emu::run_block(256, [&] { k3_scan(g, chips0, chips1, counts0, counts1, seen0, seen1, hits.data(), &n_hits, hdr_cap, &err); });
-    }
+    const uint32_t scan_parts = (std::max(g.cap[0] + WM_SPILL_LEVELS * WM_SPILL_CHUNK, g.cap[1]) + WM_K3_SCAN_PART - 1u) / WM_K3_SCAN_PART;   /* as launch_k3 */
+    gridDim = {(lanes + 255u) / 256u, scan_parts, 1};
+    for (uint32_t part = 0; part < scan_parts; part++)
+        for (uint32_t b = 0; b < gridDim.x; b++) {
+            blockIdx = {b, part, 0};
+            block_emu::run_block(256, [&] { k3_scan(g, chips0, chips1, counts0, counts1, seen0, seen1, hits.data(), &n_hits, hdr_cap, &err); });
+        }
+    blockIdx = {0, 0, 0};
     K3Args k3{};
     k3.g = g; k3.rssi = rssi; k3.chips[0] = chips0; k3.chips[1] = chips1; k3.counts[0] = counts0; k3.counts[1] = counts1;
     k3.hits = hits.data(); k3.n_hits = &n_hits; k3.hits_cap = hdr_cap; k3.pending = pending;
