@@ -754,7 +754,12 @@ static void fr_launch(wmbus_ctx *c, int algo, uint32_t cnt, hipStream_t st = nul
      * framer resets inside the segment), so that state was right all along -- walking such runs serially made the round twice
      * as long on the bench workload (r04 A/B: 133 against 147 Gsamples/s).  What is STILL listed after that round is a true
      * cascade (a burst longer than a segment): from the second list round on a listed lane walks its chain (rla_lanes). */
-    if (!all && cnt == (algo == WMBUS_ALGO_RLA ? SC_RLA + 1u : (uint32_t)SC_CLK)) a.bad = nullptr;      /* the same for the clock kernel (clock_lanes) */
+    /* ... except with -s (round 6): S1 telegrams lie in both chains' bands there, a telegram is a run of twenty to forty listed segments, and
+     * re-running each of them on its own from a predecessor that is wrong as well is work in vain: 10 994 lanes in the first round, 5 088
+     * walking their chains in the second.  With the walk in the FIRST round the second finds 2 lanes (configs[2] at batch size: 174-177 ->
+     * 181-182 Gsamples/s, run-length stage 9.9 -> 8.3 ms). */
+    const bool walk_first = algo == WMBUS_ALGO_RLA && c->cfg.simultaneous;
+    if (!all && cnt == (algo == WMBUS_ALGO_RLA ? SC_RLA + 1u : (uint32_t)SC_CLK) && !walk_first) a.bad = nullptr;      /* the same for the clock kernel (clock_lanes) */
     /* (Round 5 tried a middle way for the clock kernel's first round: parallel, but a lane whose end state came out new carries it
      * on into an UNLISTED successor.  The second round shrank from 7 to 4 lanes and the job lost 1.8 %: 170.0 against 173.1.) */
     /* list launches: blocks for 3/16 of the lanes (a re-run list is a few percent of them; the blocks walk whatever is more) */
