@@ -150,9 +150,10 @@ unsigned wmbus_batch_plan(const wmbus_cfg *cfg, unsigned contexts, unsigned *cou
     /* Contexts of whole 64-capture waves where the batch allows it (the clock kernel's cooperative loads need that); by
      * default 8 of them, at most one per 64 captures: 8 x 128 for the 1024 captures of the headline configuration
      * (4 / 6 / 10 / 12 / 16 contexts measured 96 / 111 / 141 / 120 / 117 against 144 Gsamples/s with 8, DESIGN_HISTORY.md section 8).
-     * (tolerance mode: the demodulation kernel is a third shorter, the framers' share of a context's chain larger, and
-     * twelve contexts cover it better than eight: 167 against 162 Gsamples/s) */
-    unsigned nctx = contexts ? contexts : std::min(cfg->tolerance_mode ? 12u : 8u, std::max(1u, S / 64u));
+     * (rounds 4-5 gave tolerance mode twelve -- the demodulation kernel is a third shorter there and a context's chain of framer launches
+     * was the bound: 167 against 162 Gsamples/s.  With the clock recovery in its systolic form the chain is 4 ms shorter and eight are
+     * ahead again: 211-212 against 206-209, round 6.) */
+    unsigned nctx = contexts ? contexts : std::min(8u, std::max(1u, S / 64u));
     nctx = std::max(1u, std::min(nctx, S));
     /* whole groups of 64 wherever the batch has that many captures per context; a remainder (S not a multiple of 64) rides
      * with the last context, which alone then takes the clock kernel's lane-private load path */

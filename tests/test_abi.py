@@ -100,9 +100,9 @@ def test_synth_is_deterministic(wm):
 
 def test_batch_plan_splits_into_whole_groups_of_64(wm):
     """wmbus_batch_plan (no device needed): whole 64-capture groups per context where the batch has them, the remainder
-    with the last context, 8 contexts by default (12 in tolerance mode), never an empty context."""
+    with the last context, 8 contexts by default, never an empty context."""
     assert wm.batch_plan(1024) == [128] * 8
-    assert wm.batch_plan(1024, tolerance_mode=1) == [128] * 4 + [64] * 8
+    assert wm.batch_plan(1024, tolerance_mode=1) == [128] * 8
     assert wm.batch_plan(320) == [64] * 5
     assert wm.batch_plan(130) == [64, 66]
     assert wm.batch_plan(1500) == [192] * 7 + [156]
