@@ -55,8 +55,10 @@ typedef struct wmbus_cfg {
     int device;                 /* HIP device ordinal                                */
     size_t max_push_bytes;      /* capacity per stream per push, multiple of 4096    */
     /* tuning (0 = default) */
-    unsigned seg_len;           /* clock-recovery time segment, decimated samples (power of two, 1024 ... 2^20); 0: 32768 for
-                                   >= 64 captures, shorter for fewer (a small batch is bound by how long one lane walks) */
+    unsigned seg_len;           /* clock-recovery time segment, decimated samples (power of two, 1024 ... 2^20); 0: 32768 -- 65536 for
+                                   batches of >= 64 captures at decimation 2 with exact arithmetic and no -s, 16384 for batches of
+                                   < 64 captures whose pushes are 2^15 ... 2^19 decimated samples (a live stream); with
+                                   clock_waves = 1: 32768 / 16384 / 8192 by batch size */
     unsigned rla_seg_len;       /* run-length framer time segment                    */
     unsigned warmup_t1c1;       /* IIR warm-up before a segment, T1/C1 chain         */
     unsigned warmup_s1;         /* IIR warm-up before a segment, S1 chain            */
