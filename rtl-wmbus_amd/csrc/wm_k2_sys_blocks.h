@@ -107,6 +107,9 @@ __device__ __forceinline__ void sys_r2_block32(float &h1, float &h2, uint32_t &c
  * two blocks of soft symbols in flight across it; __syncthreads() would drain them) */
 __device__ __forceinline__ void wm_sys_barrier()
 {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(WM_SYS_SLEEP)
+    __builtin_amdgcn_s_sleep(WM_SYS_SLEEP);               /* timing experiment (tools/build_variant.sh): a longer step with no more instructions -- what does a clock block's RESIDENCE cost the job? */
+#endif
 #if defined(__HIP_DEVICE_COMPILE__) && defined(WM_SYS_BARRIER_ASM)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #elif defined(__HIP_DEVICE_COMPILE__)
