@@ -737,6 +737,14 @@ static void ema_commit(wmbus_ctx *c)
     hipLaunchKernelGGL(k1_commit, dim3((2 * c->S + 63) / 64), dim3(64), 0, c->stream, c->d_ema_tail, ema_carry(c, true), c->ntiles, 2 * c->S);
 }
 
+/* Does the launch that reads the re-run list whose length is scalar `cnt` walk chains (K2Args.bad), or re-run every listed segment on its own?
+ * The framers' FIRST list round is the parallel one -- except the run-length framer's with -s (fr_launch has the measurements). */
+static bool list_walks_chains(const wmbus_ctx *c, int algo, uint32_t cnt)
+{
+    if (algo == WMBUS_ALGO_RLA) return c->rla_chains && (c->cfg.simultaneous || cnt != SC_RLA + 1u);
+    return cnt != (uint32_t)SC_CLK;
+}
+
 static void fr_verify(wmbus_ctx *c, int algo, uint32_t cnt, hipStream_t st = nullptr)
 {
     if (!st) st = c->stream;
@@ -744,7 +752,7 @@ static void fr_verify(wmbus_ctx *c, int algo, uint32_t cnt, hipStream_t st = nul
     const uint32_t lanes = 2u * a.g.nseg[algo] * a.g.S, words = (algo == WMBUS_ALGO_RLA ? sizeof(WmRlaState) : sizeof(WmClkState)) / 4;
     hipLaunchKernelGGL(k2_verify, dim3((lanes + 255) / 256), dim3(256), 0, st, a.g, (uint32_t)algo, (const uint32_t *)a.st_start,
                        (const uint32_t *)a.st_final, words, algo == WMBUS_ALGO_RLA ? c->d_list2 : c->d_list, c->d_scalars + cnt,
-                       algo == WMBUS_ALGO_RLA ? (c->rla_chains ? c->d_bad : (uint32_t *)nullptr) : c->d_bad_clk);
+                       algo == WMBUS_ALGO_RLA ? (c->rla_chains ? c->d_bad : (uint32_t *)nullptr) : c->d_bad_clk, list_walks_chains(c, algo, cnt) ? 1u : 0u);
 }
 
 /* one framer's kernel alone: every lane (cnt == ~0) or the re-run list whose length is scalar `cnt` */
@@ -765,8 +773,7 @@ static void fr_launch(wmbus_ctx *c, int algo, uint32_t cnt, hipStream_t st = nul
      * re-running each of them on its own from a predecessor that is wrong as well is work in vain: 10 994 lanes in the first round, 5 088
      * walking their chains in the second.  With the walk in the FIRST round the second finds 2 lanes (configs[2] at batch size: 174-177 ->
      * 181-182 Gsamples/s, run-length stage 9.9 -> 8.3 ms). */
-    const bool walk_first = algo == WMBUS_ALGO_RLA && c->cfg.simultaneous;
-    if (!all && cnt == (algo == WMBUS_ALGO_RLA ? SC_RLA + 1u : (uint32_t)SC_CLK) && !walk_first) a.bad = nullptr;      /* the same for the clock kernel (clock_lanes) */
+    if (!all && !list_walks_chains(c, algo, cnt)) a.bad = nullptr;      /* (the clock kernel's first list round is parallel too: clock_lanes) */
     /* (Round 5 tried a middle way for the clock kernel's first round: parallel, but a lane whose end state came out new carries it
      * on into an UNLISTED successor.  The second round shrank from 7 to 4 lanes and the job lost 1.8 %: 170.0 against 173.1.) */
     /* list launches: blocks for 3/16 of the lanes (a re-run list is a few percent of them; the blocks walk whatever is more) */
@@ -1011,6 +1018,7 @@ static int enqueue_front_impl(wmbus_ctx *c, size_t nbytes)
             }
             f.list[0] = c->d_list2; f.list[1] = c->d_list; f.n_list[0] = c->d_scalars + SC_RLA + c->rla_fin; f.n_list[1] = c->d_scalars + SC_CLK + c->fr_rounds;
             f.bad[0] = c->rla_chains ? c->d_bad : nullptr; f.bad[1] = c->d_bad_clk;
+            f.heads[0] = list_walks_chains(c, WMBUS_ALGO_RLA, SC_RLA + c->rla_fin); f.heads[1] = list_walks_chains(c, WMBUS_ALGO_T2A, SC_CLK + c->fr_rounds);
             const uint32_t most = std::max(2u * g.S, 2u * std::max(g.nseg[0], g.nseg[1]) * g.S);
             hipLaunchKernelGGL(k2_finish, dim3((most + 255u) / 256u), dim3(256), 0, c->stream, g, f);
             HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
@@ -1281,6 +1289,17 @@ static int wait_gpu(wmbus_ctx *c)
         hipEventElapsedTime(&ms, c->ev[6], c->ev[7]); c->tim.d2h_ms = ms;
         hipEventElapsedTime(&ms, c->ev[2], c->ev[7]); c->tim.gpu_total_ms = ms;
         const uint32_t *hs = c->h_scalars;
+#ifdef WM_DBG_WALK_STATS
+        if (c->push_seq == 4) {
+            unsigned h[2][32];
+            hipMemcpyFromSymbol(h, HIP_SYMBOL(wm_walk_hist), sizeof h);
+            for (int ch = 0; ch < 2; ch++) {
+                fprintf(stderr, "run-length walks so far, %s chain, by segments walked:", ch ? "S1" : "T1/C1");
+                for (int i = 1; i < 32; i++) fprintf(stderr, " %u", h[ch][i]);
+                fprintf(stderr, "\n");
+            }
+        }
+#endif
         for (unsigned r = 0; r < c->ema_rounds; r++) c->tim.ema_retries += hs[SC_EMA + r];
         for (unsigned r = 0; r < c->fr_rounds; r++) c->tim.clock_reruns += hs[SC_CLK + r];
         for (unsigned r = 0; r < c->rla_fin; r++) c->tim.rla_reruns += hs[SC_RLA + r];

@@ -315,6 +315,9 @@ __device__ __forceinline__ void rla_segment(const K2Args &a, RlaLds &lds, const 
  * after the other, each from the exact end state of the one before (the others return at once), and goes on into the segment
  * behind the run as long as the end state it arrives with differs from that segment's recorded start -- unless that segment
  * has a lane of its own in this launch (listed behind an unlisted one), which the next round sorts out. */
+#ifdef WM_DBG_WALK_STATS
+__device__ unsigned wm_walk_hist[2][32];
+#endif
 template <int PASS = 2>
 __device__ __forceinline__ void rla_lanes(const K2Args &a, const uint32_t block_id, RlaLds &lds)
 {
@@ -336,16 +339,25 @@ __device__ __forceinline__ void rla_lanes(const K2Args &a, const uint32_t block_
      * listed segment X + 1 -- listed behind an unlisted one, so it has a lane of its own in this launch -- may be reading that
      * record as its start state: a torn read can drive that lane's whole segment from a mixed state.  Benign: the next k2_verify
      * sees the mismatch and lists it again, so the result stays exact; it costs a round where it happens.  ADVICE r4.) */
+#ifdef WM_DBG_WALK_STATS                                  /* tools/build_variant.sh walk -DWM_DBG_WALK_STATS: how long are the walks?  histogram per chain, read in wmbus_collect */
+    uint32_t walked = 0;
+#define WM_WALK_DONE() atomicAdd(&wm_walk_hist[ch][walked < 31u ? walked : 31u], 1u)
+#else
+#define WM_WALK_DONE() do {} while (0)
+#endif
     for (;;) {
         rla_segment<PASS>(a, lds, true, ch, stream, seg);
-        if (seg + 1u >= g.nseg[0]) return;
+#ifdef WM_DBG_WALK_STATS
+        walked++;
+#endif
+        if (seg + 1u >= g.nseg[0]) { WM_WALK_DONE(); return; }
         const uint64_t sidx = row * g.nseg_cap[0] + seg;
         const uint32_t *x = (const uint32_t *)((const WmRlaState *)a.st_final + sidx), *y = (const uint32_t *)((const WmRlaState *)a.st_start + sidx + 1u);
         bool same = true;
 #pragma unroll
         for (int k = 0; k < (int)(sizeof(WmRlaState) / 4); k++) same &= x[k] == y[k];
-        if (same) return;                                  /* the next segment started from exactly this state */
-        if (bad[(uint64_t)(seg + 1u) * g.S] && !bad[(uint64_t)seg * g.S]) return;      /* it is listed and has a lane of its own in this launch: next round */
+        if (same) { WM_WALK_DONE(); return; }                /* the next segment started from exactly this state */
+        if (bad[(uint64_t)(seg + 1u) * g.S] && !bad[(uint64_t)seg * g.S]) { WM_WALK_DONE(); return; }      /* it is listed and has a lane of its own in this launch: next round */
         seg++;
     }
 }
