@@ -121,7 +121,10 @@ long wm_emu_clock(const float *dphi, uint32_t S, uint32_t M, uint32_t Mcap, uint
             const size_t sidx = ((size_t)ch * S + stream) * nseg + seg;
             const bool differs = std::memcmp(&st_start[sidx], &st_final[sidx - 1], sizeof(WmClkState)) != 0;
             bad[((size_t)ch * nseg + seg) * S + stream] = differs;          /* the verdict per segment ([chain][segment][capture]), stable during the launch that follows */
-            if (differs) list.push_back(lane);
+            /* a launch that walks chains is given the HEADS of runs of listed segments only (k2_verify_lane's `heads`; lanes go segment-major,
+             * so the predecessor's verdict of this round is there already) */
+            const bool walks = wm_emu_chains && round >= 1;
+            if (differs && !(walks && seg > 1 && bad[((size_t)ch * nseg + seg - 1) * S + stream])) list.push_back(lane);
         }
         if (list.empty()) break;
         if (round > nseg + 1) return -1;
